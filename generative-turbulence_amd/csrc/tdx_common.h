@@ -1,0 +1,110 @@
+// Shared device helpers for the tdx kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include "../../include/tdx.h"
+
+typedef __hip_bfloat16 bf16;
+
+#define TDX_CHECK_ARG(cond) \
+    do {                    \
+        if (!(cond)) return TDX_EINVAL; \
+    } while (0)
+
+static inline int tdx_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TDX_OK : (int)e;
+}
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+// ---- scalar element access ---------------------------------------------------------
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16* p) { return __bfloat162float(*p); }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16* p, float v) { *p = __float2bfloat16(v); }
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    bf16 h = __float2bfloat16(f);
+    return *reinterpret_cast<unsigned short*>(&h);
+}
+
+// ---- 8-element vector access (16 B for bf16, 32 B for f32); pointer must be aligned ----
+template <typename T>
+struct Vec8;
+template <>
+struct Vec8<float> {
+    float v[8];
+    __device__ __forceinline__ void load(const float* p) {
+        const float4* q = reinterpret_cast<const float4*>(p);
+        float4 a = q[0], b = q[1];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        float4* q = reinterpret_cast<float4*>(p);
+        q[0] = make_float4(v[0], v[1], v[2], v[3]);
+        q[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <>
+struct Vec8<bf16> {
+    float v[8];
+    __device__ __forceinline__ void load(const bf16* p) {
+        uint4 u = *reinterpret_cast<const uint4*>(p);
+        unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ void store(bf16* p) const {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = (unsigned)f32_to_bf16_bits(v[2 * i]) | ((unsigned)f32_to_bf16_bits(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// ---- wave / block reductions (wave = 64 lanes) -----------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// d silu(x)/dx = s (1 + x (1 - s)), s = sigmoid(x)
+__device__ __forceinline__ float dsilu_f(float x) {
+    float s = 1.0f / (1.0f + __expf(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+
+// dtype dispatch for launchers: calls f.template operator()<T>()
+#define TDX_DISPATCH_DTYPE(dtype, ...)                 \
+    do {                                               \
+        if ((dtype) == TDX_F32) {                      \
+            typedef float T;                           \
+            __VA_ARGS__;                               \
+        } else if ((dtype) == TDX_BF16) {              \
+            typedef bf16 T;                            \
+            __VA_ARGS__;                               \
+        } else                                         \
+            return TDX_EDTYPE;                         \
+    } while (0)
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,171 @@
+// 1x1x1 convolution / per-row linear layer on NDHWC activations (vector-ALU version).
+//   y[r, :] = bias + [x1 | x2][r, :] @ w  (+ add[r, :])
+// 64 rows x 64 cols per 256-thread block, 4x4 register tile per thread, K staged through
+// LDS in 32-deep slices (x slice stored k-major so the inner loop reads conflict-free
+// float4 rows).  f32 accumulation.  These layers are HBM-bound at the U-Net's channel
+// counts (4-174 FLOP/B); the MFMA variant lives in tdx_conv3_mfma.hip (taps = 1).
+#include "tdx_common.h"
+
+#define C1_BM 64
+#define C1_BN 64
+#define C1_BK 32
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv1_fwd_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2, const float* __restrict__ w,
+                 int ldw, const float* __restrict__ bias, const T* __restrict__ add, T* __restrict__ y, int64_t rows,
+                 int Cout) {
+    __shared__ float xs[C1_BK][C1_BM + 4];
+    __shared__ float ws[C1_BK][C1_BN + 4];
+    const int Cin = C1 + C2;
+    const int64_t r0 = (int64_t)blockIdx.x * C1_BM;
+    const int n0 = blockIdx.y * C1_BN;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    for (int k0 = 0; k0 < Cin; k0 += C1_BK) {
+        // stage x slice: 64 rows x 32 k  (thread: row = tid/4, 8 consecutive k)
+        {
+            const int rr = tid >> 2, kk = (tid & 3) * 8;
+            const int64_t r = r0 + rr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + kk + j;
+                float v = 0.f;
+                if (r < rows && k < Cin) v = (k < C1) ? ldf(x1 + r * C1 + k) : ldf(x2 + r * C2 + (k - C1));
+                xs[kk + j][rr] = v;
+            }
+        }
+        // stage w slice: 32 k x 64 n
+        {
+            const int kk = tid >> 3, nn = (tid & 7) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + kk, n = n0 + nn + j;
+                ws[kk][nn + j] = (k < Cin && n < Cout) ? w[(size_t)k * ldw + n] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < C1_BK; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(&xs[k][ty * 4]);
+            const float4 b = *reinterpret_cast<const float4*>(&ws[k][tx * 4]);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = r0 + ty * 4 + i;
+        if (r >= rows) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= Cout) continue;
+            float v = acc[i][j];
+            if (bias) v += bias[n];
+            if (add) v += ldf(add + r * Cout + n);
+            stf(y + r * Cout + n, v);
+        }
+    }
+}
+
+extern "C" int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw,
+                             const float* bias, const void* add, void* y, int64_t rows, int Cout, int dtype,
+                             void* stream) {
+    TDX_CHECK_ARG(x1 && w && y && rows > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && ldw >= Cout);
+    TDX_CHECK_ARG(C2 == 0 || x2);
+    dim3 grid(ceil_div(rows, C1_BM), ceil_div(Cout, C1_BN));
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_fwd_kernel<T>), grid, dim3(256), 0, as_stream(stream),
+                                                  (const T*)x1, C1, (const T*)x2, C2, w, ldw, bias, (const T*)add,
+                                                  (T*)y, rows, Cout));
+    return tdx_launch_status();
+}
+
+// dw[ci][co] = sum_r x[r,ci] dy[r,co]; each block reduces a chunk of rows for one
+// 64x64 (ci, co) tile and merges with f32 atomics (dw is zeroed first).
+#define C1W_ROWS 4096
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv1_wgrad_kernel(const T* __restrict__ x, int Cin, const T* __restrict__ dy, int Cout, float* __restrict__ dw,
+                   int ldw, float* __restrict__ dbias, int64_t rows) {
+    __shared__ float xs[C1_BK][C1_BM + 4];  // [row slice][ci]
+    __shared__ float gs[C1_BK][C1_BN + 4];  // [row slice][co]
+    const int64_t rbeg = (int64_t)blockIdx.x * C1W_ROWS;
+    const int64_t rend = min(rows, rbeg + C1W_ROWS);
+    const int ci0 = blockIdx.y * C1_BM, co0 = blockIdx.z * C1_BN;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    float bsum = 0.f;  // thread tid < 64 sums column co0 + tid when ci tile == 0
+
+    for (int64_t rs = rbeg; rs < rend; rs += C1_BK) {
+        {
+            const int rr = tid >> 3, cc = (tid & 7) * 8;
+            const int64_t r = rs + rr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ci = ci0 + cc + j, co = co0 + cc + j;
+                xs[rr][cc + j] = (r < rend && ci < Cin) ? ldf(x + r * Cin + ci) : 0.f;
+                gs[rr][cc + j] = (r < rend && co < Cout) ? ldf(dy + r * Cout + co) : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < C1_BK; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(&xs[k][ty * 4]);
+            const float4 b = *reinterpret_cast<const float4*>(&gs[k][tx * 4]);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+        }
+        if (dbias && blockIdx.y == 0 && tid < C1_BN) {
+#pragma unroll 8
+            for (int k = 0; k < C1_BK; ++k) bsum += gs[k][tid];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = ci0 + ty * 4 + i;
+        if (ci >= Cin) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + tx * 4 + j;
+            if (co < Cout) atomicAdd(&dw[(size_t)ci * ldw + co], acc[i][j]);
+        }
+    }
+    if (dbias && blockIdx.y == 0 && tid < C1_BN && co0 + tid < Cout) atomicAdd(&dbias[co0 + tid], bsum);
+}
+
+extern "C" int tdx_conv1_bwd_weight(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw,
+                                    float* dbias, int64_t rows, int dtype, void* stream) {
+    TDX_CHECK_ARG(x && dy && dw && rows > 0 && Cin > 0 && Cout > 0 && ldw >= Cout);
+    hipStream_t st = as_stream(stream);
+    // zero the [Cin][ldw] block rows that are written (ldw may exceed Cout for sub-blocks)
+    hipError_t e = hipMemset2DAsync(dw, (size_t)ldw * sizeof(float), 0, (size_t)Cout * sizeof(float), (size_t)Cin, st);
+    if (e != hipSuccess) return (int)e;
+    if (dbias) {
+        e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(ceil_div(rows, C1W_ROWS), ceil_div(Cin, C1_BM), ceil_div(Cout, C1_BN));
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_wgrad_kernel<T>), grid, dim3(256), 0, st, (const T*)x, Cin,
+                                                  (const T*)dy, Cout, dw, ldw, dbias, rows));
+    return tdx_launch_status();
+}

@@ -1,0 +1,31 @@
+// Internal interface between tdx_conv3_direct.hip (entry points, vector-ALU kernels) and
+// tdx_conv3_mfma.hip (bf16 MFMA implicit-GEMM kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct Conv3Geom {
+    int B;
+    int Xi, Yi, Zi;  // input grid
+    int Xo, Yo, Zo;  // output grid
+    int off;         // output voxel o reads input voxel o + off + e, e in {-1,0,1}^3
+};
+
+// Packed-operand layouts (element index of weight (tap, k, n); K = input channels of the
+// conv being evaluated, N = its output channels):
+//   generic : (tap*K + k)*N + n                                   [27][K][N]
+//   mfma    : (((k/16)*27 + tap)*N + n)*16 + (k%16)               [K/16][27][N][16]
+// The mfma layout is used iff conv3_mfma_supported(K, 0, N) and dtype == bf16, so that
+// pack and consumers agree without carrying a flag through the ABI.
+bool conv3_mfma_supported(int C1, int C2, int Cout);
+static inline bool conv3_uses_mfma_layout(int dtype, int K, int N) { return dtype == 1 && conv3_mfma_supported(K, 0, N); }
+
+int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
+                      const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st);
+
+bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout);
+int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
+                            int B, int X, int Y, int Z, int Cout, hipStream_t st);
+
+int conv3_direct_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
+                        const Conv3Geom& g, int Cout, int dtype, bool zero_pad, hipStream_t st);

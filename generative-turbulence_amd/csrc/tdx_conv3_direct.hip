@@ -1,0 +1,390 @@
+// 3x3x3 convolution on NDHWC activations: weight packing, the vector-ALU implicit-GEMM
+// kernels (any dtype, exact f32 accumulation -- the f32 parity path and the cross-check
+// for the MFMA kernels), the halo fold of the data gradient, and the public entry points
+// that dispatch between this file and tdx_conv3_mfma.hip.
+//
+// Geometry shared by both implementations: an "output grid" (Xo,Yo,Zo) is produced from an
+// "input grid" (Xi,Yi,Zi); output voxel o reads input voxel o + off + e for the 27 taps
+// e in {-1,0,1}^3, either clamped to the grid (replicate padding, forward: off = 0, grids
+// equal) or treated as zero outside (data gradient: the adjoint is evaluated on the padded
+// grid Xi+2 with off = -1 and the halo is folded back onto the boundary afterwards).
+#include "tdx_common.h"
+#include "tdx_conv3.h"
+
+// ------------------------------------------------------------------ weight packing -------
+// element index of operand (tap, k, n) for a conv with K input / N output channels
+__host__ __device__ __forceinline__ int64_t wp_index(bool mfma_layout, int tap, int k, int n, int K, int N) {
+    return mfma_layout ? ((((int64_t)(k >> 4) * 27 + tap) * N + n) * 16 + (k & 15)) : (((int64_t)tap * K + k) * N + n);
+}
+
+// w (Cout, Cin, 27) f32 -> wf: forward operand (K = Cin, N = Cout);
+//                           wb: data-gradient operand (K = Cout, N = Cin, taps flipped)
+template <typename T>
+__global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cin,
+                                  int Cout, bool lf, bool lb) {
+    const int64_t n = (int64_t)Cout * Cin * 27;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 27);
+        const int64_t r = i / 27;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        const float v = w[i];
+        if (wf) stf(wf + wp_index(lf, tap, ci, co, Cin, Cout), v);
+        if (wb) stf(wb + wp_index(lb, 26 - tap, co, ci, Cout, Cin), v);
+    }
+}
+extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream) {
+    TDX_CHECK_ARG(w && (wf || wb) && Cin > 0 && Cout > 0);
+    const int64_t n = (int64_t)Cout * Cin * 27;
+    int grid = (int)min((int64_t)1024, (n + 255) / 256);
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv3_pack_kernel<T>), dim3(grid), dim3(256), 0, as_stream(stream),
+                                                  w, (T*)wf, (T*)wb, Cin, Cout,
+                                                  conv3_uses_mfma_layout(dtype, Cin, Cout),
+                                                  conv3_uses_mfma_layout(dtype, Cout, Cin)));
+    return tdx_launch_status();
+}
+
+// dwp [27][Cin][Cout] f32 -> dw (Cout, Cin, 27) f32
+__global__ void conv3_unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cin, int Cout) {
+    const int64_t n = (int64_t)Cout * Cin * 27;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 27);
+        const int64_t r = i / 27;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        dw[i] = dwp[((int64_t)tap * Cin + ci) * Cout + co];
+    }
+}
+
+// ------------------------------------------------------------------ direct implicit GEMM -
+#define D3_BM 64
+#define D3_BN 64
+#define D3_BK 32
+
+template <typename T, bool ZERO_PAD>
+__global__ void __launch_bounds__(256)
+conv3_direct_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2, const T* __restrict__ wp,
+                    const float* __restrict__ bias, T* __restrict__ y, Conv3Geom g, int Cout, bool mfma_layout) {
+    __shared__ float xs[D3_BK][D3_BM + 4];
+    __shared__ float ws[D3_BK][D3_BN + 4];
+    const int Cin = C1 + C2;
+    const int64_t nvox_out = (int64_t)g.B * g.Xo * g.Yo * g.Zo;
+    const int64_t m0 = (int64_t)blockIdx.x * D3_BM;
+    const int n0 = blockIdx.y * D3_BN;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+
+    // staging role: voxel row rr, 8-channel group kk
+    const int rr = tid >> 2, kk = (tid & 3) * 8;
+    const int64_t mv = m0 + rr;
+    const bool row_ok = mv < nvox_out;
+    int ob = 0, ox = 0, oy = 0, oz = 0;
+    if (row_ok) {
+        int64_t v = mv;
+        oz = (int)(v % g.Zo); v /= g.Zo;
+        oy = (int)(v % g.Yo); v /= g.Yo;
+        ox = (int)(v % g.Xo); ob = (int)(v / g.Xo);
+    }
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    for (int tap = 0; tap < 27; ++tap) {
+        const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
+        int sx = ox + g.off + ex, sy = oy + g.off + ey, sz = oz + g.off + ez;
+        bool src_ok = row_ok;
+        if (ZERO_PAD) {
+            src_ok = src_ok && sx >= 0 && sx < g.Xi && sy >= 0 && sy < g.Yi && sz >= 0 && sz < g.Zi;
+        } else {
+            sx = min(max(sx, 0), g.Xi - 1); sy = min(max(sy, 0), g.Yi - 1); sz = min(max(sz, 0), g.Zi - 1);
+        }
+        const int64_t sv = (((int64_t)ob * g.Xi + sx) * g.Yi + sy) * g.Zi + sz;
+        for (int k0 = 0; k0 < Cin; k0 += D3_BK) {
+            {
+                const int k = k0 + kk;
+                Vec8<T> a;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a.v[j] = 0.f;
+                if (src_ok && k < Cin) {
+                    if (k < C1) a.load(x1 + sv * C1 + k);
+                    else a.load(x2 + sv * C2 + (k - C1));
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xs[kk + j][rr] = a.v[j];
+            }
+            {
+                const int kq = tid >> 3, nn = (tid & 7) * 8;
+                const int k = k0 + kq;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = n0 + nn + j;
+                    ws[kq][nn + j] = (k < Cin && n < Cout) ? ldf(wp + wp_index(mfma_layout, tap, k, n, Cin, Cout)) : 0.f;
+                }
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int k = 0; k < D3_BK; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(&xs[k][ty * 4]);
+                const float4 b = *reinterpret_cast<const float4*>(&ws[k][tx * 4]);
+                const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + ty * 4 + i;
+        if (m >= nvox_out) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= Cout) continue;
+            float v = acc[i][j];
+            if (bias) v += bias[n];
+            stf(y + m * Cout + n, v);
+        }
+    }
+}
+
+int conv3_direct_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
+                        const Conv3Geom& g, int Cout, int dtype, bool zero_pad, hipStream_t st) {
+    if ((C1 % 8) || (C2 % 8)) return TDX_ESHAPE;
+    const int64_t nvox = (int64_t)g.B * g.Xo * g.Yo * g.Zo;
+    dim3 grid(ceil_div(nvox, D3_BM), ceil_div(Cout, D3_BN));
+    const bool ml = conv3_uses_mfma_layout(dtype, C1 + C2, Cout);
+    TDX_DISPATCH_DTYPE(dtype, {
+        if (zero_pad)
+            hipLaunchKernelGGL((conv3_direct_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x1, C1, (const T*)x2,
+                               C2, (const T*)wp, bias, (T*)y, g, Cout, ml);
+        else
+            hipLaunchKernelGGL((conv3_direct_kernel<T, false>), grid, dim3(256), 0, st, (const T*)x1, C1,
+                               (const T*)x2, C2, (const T*)wp, bias, (T*)y, g, Cout, ml);
+    });
+    return tdx_launch_status();
+}
+
+// ------------------------------------------------------------------ halo fold ------------
+// dx[b,u,:] (+)= sum over padded positions p with clamp(p) == u of dpad[b,p,:]
+// dpad grid is (X+2, Y+2, Z+2) with p' = p + 1.  Channels are split over dx1 | dx2.
+__device__ __forceinline__ void fold_range(int u, int n, int& lo, int& hi) {
+    lo = (u == 0) ? 0 : u + 1;
+    hi = (u == n - 1) ? n + 1 : u + 1;
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv3_fold_kernel(const T* __restrict__ dpad, T* __restrict__ dx1, int C1, T* __restrict__ dx2, int C2, int accumulate,
+                  int B, int X, int Y, int Z, int64_t total) {
+    const int C = C1 + C2;
+    const int L = C >> 3;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lc = (int)(i % L);
+    int64_t v = i / L;
+    const int64_t vox = v;
+    const int uz = (int)(v % Z); v /= Z;
+    const int uy = (int)(v % Y); v /= Y;
+    const int ux = (int)(v % X);
+    const int b = (int)(v / X);
+    int x0, x1, y0, y1, z0, z1;
+    fold_range(ux, X, x0, x1);
+    fold_range(uy, Y, y0, y1);
+    fold_range(uz, Z, z0, z1);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const int Xp = X + 2, Yp = Y + 2, Zp = Z + 2;
+    for (int px = x0; px <= x1; ++px)
+        for (int py = y0; py <= y1; ++py)
+            for (int pz = z0; pz <= z1; ++pz) {
+                Vec8<T> t;
+                t.load(dpad + ((((int64_t)b * Xp + px) * Yp + py) * Zp + pz) * C + lc * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += t.v[j];
+            }
+    const int c = lc * 8;
+    T* dst = (c < C1) ? dx1 + vox * C1 + c : dx2 + vox * C2 + (c - C1);
+    Vec8<T> o;
+    if (accumulate) {
+        o.load(dst);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] += acc[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    }
+    o.store(dst);
+}
+
+// ------------------------------------------------------------------ direct weight grad ---
+// dwp[tap][ci][co] += sum over a chunk of voxels of x[clamp(v+tap), ci] * dy[v, co]
+#define D3W_VOX 8192
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv3_wgrad_direct_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2,
+                          const T* __restrict__ dy, float* __restrict__ dwp, float* __restrict__ dbias, int B, int X,
+                          int Y, int Z, int Cout, int n_ci_tiles) {
+    __shared__ float xs[D3_BK][D3_BM + 4];  // [voxel slice][ci]
+    __shared__ float gs[D3_BK][D3_BN + 4];  // [voxel slice][co]
+    const int Cin = C1 + C2;
+    const int64_t nvox = (int64_t)B * X * Y * Z;
+    const int64_t vbeg = (int64_t)blockIdx.x * D3W_VOX;
+    const int64_t vend = min(nvox, vbeg + D3W_VOX);
+    const int tap = blockIdx.y;
+    const int ci0 = (blockIdx.z % n_ci_tiles) * D3_BM, co0 = (blockIdx.z / n_ci_tiles) * D3_BN;
+    const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int rr = tid >> 3, cc = (tid & 7) * 8;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = dbias && tap == 13 && ci0 == 0;
+
+    for (int64_t vs = vbeg; vs < vend; vs += D3_BK) {
+        const int64_t v = vs + rr;
+        Vec8<T> a, gq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a.v[j] = gq.v[j] = 0.f;
+        if (v < vend) {
+            int64_t t = v;
+            const int oz = (int)(t % Z); t /= Z;
+            const int oy = (int)(t % Y); t /= Y;
+            const int ox = (int)(t % X);
+            const int ob = (int)(t / X);
+            const int sx = min(max(ox + ex, 0), X - 1), sy = min(max(oy + ey, 0), Y - 1),
+                      sz = min(max(oz + ez, 0), Z - 1);
+            const int64_t sv = (((int64_t)ob * X + sx) * Y + sy) * Z + sz;
+            const int ci = ci0 + cc, co = co0 + cc;
+            if (ci < Cin) {
+                if (ci < C1) a.load(x1 + sv * C1 + ci);
+                else a.load(x2 + sv * C2 + (ci - C1));
+            }
+            if (co < Cout) gq.load(dy + v * Cout + co);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xs[rr][cc + j] = a.v[j]; gs[rr][cc + j] = gq.v[j]; }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < D3_BK; ++k) {
+            const float4 av4 = *reinterpret_cast<const float4*>(&xs[k][ty * 4]);
+            const float4 bv4 = *reinterpret_cast<const float4*>(&gs[k][tx * 4]);
+            const float av[4] = {av4.x, av4.y, av4.z, av4.w}, bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+        }
+        if (do_bias && tid < D3_BN) {
+#pragma unroll 8
+            for (int k = 0; k < D3_BK; ++k) bsum += gs[k][tid];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = ci0 + ty * 4 + i;
+        if (ci >= Cin) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = co0 + tx * 4 + j;
+            if (co < Cout) atomicAdd(&dwp[((int64_t)tap * Cin + ci) * Cout + co], acc[i][j]);
+        }
+    }
+    if (do_bias && tid < D3_BN && co0 + tid < Cout) atomicAdd(&dbias[co0 + tid], bsum);
+}
+
+// ------------------------------------------------------------------ entry points ---------
+static bool mfma_ok(int dtype, int Cin1, int Cin2, int Cout) {
+    return dtype == TDX_BF16 && conv3_mfma_supported(Cin1, Cin2, Cout);
+}
+
+extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, const void* wf, const float* bias,
+                             void* y, int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* stream) {
+    TDX_CHECK_ARG(x1 && wf && y && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && C2 >= 0 && Cout > 0);
+    TDX_CHECK_ARG(C2 == 0 || x2);
+    Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
+    const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout));
+    if (use_mfma) {
+        if (!mfma_ok(dtype, C1, C2, Cout)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
+        return conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));
+    }
+    return conv3_direct_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, dtype, false, as_stream(stream));
+}
+
+extern "C" size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z, int Cin, int dtype, int impl) {
+    (void)impl;
+    return (size_t)B * (X + 2) * (Y + 2) * (Z + 2) * Cin * (dtype == TDX_BF16 ? 2 : 4) + 256;
+}
+
+extern "C" int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2,
+                                  int accumulate, int B, int X, int Y, int Z, int Cout, int dtype, int impl,
+                                  void* workspace, void* stream) {
+    TDX_CHECK_ARG(dy && wb && dx1 && workspace && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && C2 >= 0 && Cout > 0);
+    TDX_CHECK_ARG(C2 == 0 || dx2);
+    const int Cin = C1 + C2;
+    if ((C1 % 8) || (C2 % 8) || (Cout % 8)) return TDX_ESHAPE;
+    // adjoint on the padded grid: dpad[p'] = sum_e wb[e] dy_zero[p' - 1 + e]
+    Conv3Geom g = {B, X, Y, Z, X + 2, Y + 2, Z + 2, -1};
+    const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, Cout, 0, Cin));
+    int rc;
+    if (use_mfma) {
+        if (!mfma_ok(dtype, Cout, 0, Cin)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
+        rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream));
+    } else {
+        rc = conv3_direct_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, dtype, true, as_stream(stream));
+    }
+    if (rc != TDX_OK) return rc;
+    const int64_t total = (int64_t)B * X * Y * Z * (Cin / 8);
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv3_fold_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0,
+                                                  as_stream(stream), (const T*)workspace, (T*)dx1, C1, (T*)dx2, C2,
+                                                  accumulate, B, X, Y, Z, total));
+    return tdx_launch_status();
+}
+
+extern "C" size_t tdx_conv3_bwd_weight_workspace_bytes(int Cin, int Cout, int impl) {
+    (void)impl;
+    return (size_t)27 * Cin * Cout * sizeof(float) + 256;
+}
+
+extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dw,
+                                    float* dbias, int B, int X, int Y, int Z, int Cout, int dtype, int impl,
+                                    void* workspace, void* stream) {
+    TDX_CHECK_ARG(x1 && dy && dw && workspace && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && C2 >= 0 && Cout > 0);
+    TDX_CHECK_ARG(C2 == 0 || x2);
+    const int Cin = C1 + C2;
+    if ((C1 % 8) || (C2 % 8) || (Cout % 8)) return TDX_ESHAPE;
+    hipStream_t st = as_stream(stream);
+    float* dwp = (float*)workspace;
+    hipError_t e = hipMemsetAsync(dwp, 0, (size_t)27 * Cin * Cout * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (dbias) {
+        e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && dtype == TDX_BF16 &&
+                                                     conv3_wgrad_mfma_supported(C1, C2, Cout));
+    if (use_mfma) {
+        if (dtype != TDX_BF16) return TDX_EDTYPE;
+        if (!conv3_wgrad_mfma_supported(C1, C2, Cout)) return TDX_ESHAPE;
+        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st);
+        if (rc != TDX_OK) return rc;
+    } else {
+        const int64_t nvox = (int64_t)B * X * Y * Z;
+        const int nci = ceil_div(Cin, D3_BM), nco = ceil_div(Cout, D3_BN);
+        dim3 grid(ceil_div(nvox, D3W_VOX), 27, nci * nco);
+        TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv3_wgrad_direct_kernel<T>), grid, dim3(256), 0, st,
+                                                      (const T*)x1, C1, (const T*)x2, C2, (const T*)dy, dwp, dbias, B,
+                                                      X, Y, Z, Cout, nci));
+    }
+    const int64_t n = (int64_t)Cout * Cin * 27;
+    hipLaunchKernelGGL(conv3_unpack_wgrad_kernel, dim3((int)min((int64_t)1024, (n + 255) / 256)), dim3(256), 0, st, dwp,
+                       dw, Cin, Cout);
+    return tdx_launch_status();
+}

@@ -1,0 +1,322 @@
+// GroupNorm (+ FiLM + SiLU + residual) forward / backward on NDHWC activations.
+//
+// HBM-bound: every pass streams the activation once with 8 channels (16 B bf16 / 32 B f32)
+// per lane.  A thread always owns the same 8-channel vector (tid % (C/8)), so per-channel
+// coefficients live in registers and per-channel partial sums are reduced once per block
+// through LDS, then merged across blocks with one f64 atomic per channel.
+//   forward : stats pass (sum, sumsq per channel -> per group mean/rstd) + apply pass
+//   backward: reduce pass (P = sum dn, Q = sum dn*xhat per channel) + finalize + apply pass
+#include "tdx_common.h"
+
+#define GN_THREADS 256
+#define GN_VOX_PER_BLOCK 1024
+
+// per-channel partial sums of two quantities, reduced over the block and added (f64 atomics)
+// into acc[(b*C + c)*2 + {0,1}]
+template <int NQ>
+__device__ __forceinline__ void block_channel_reduce(float (&s)[NQ][8], int L, int lane_c, bool active,
+                                                     double* __restrict__ acc, int C) {
+    __shared__ float red[GN_THREADS][NQ * 8 + 1];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[tid][q * 8 + j] = active ? s[q][j] : 0.f;
+    __syncthreads();
+    const int rows = GN_THREADS / L;  // threads tid < rows*L are the active ones
+    // C*NQ outputs, each summed over `rows` entries
+    for (int o = tid; o < C * NQ; o += GN_THREADS) {
+        const int q = o / C, c = o - q * C;
+        const int lc = c >> 3, j = c & 7;
+        double t = 0.0;
+        for (int r = 0; r < rows; ++r) t += (double)red[r * L + lc][q * 8 + j];
+        atomicAdd(&acc[(size_t)c * NQ + q], t);
+    }
+    (void)lane_c;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS)
+gn_stats_kernel(const T* __restrict__ x, double* __restrict__ acc, int64_t V, int C) {
+    const int b = blockIdx.y;
+    const int L = C >> 3;
+    const int rows = GN_THREADS / L;
+    const int tid = threadIdx.x;
+    const int lc = tid % L, r = tid / L;
+    const bool active = r < rows;
+    const int64_t v0 = (int64_t)blockIdx.x * GN_VOX_PER_BLOCK;
+    const int64_t v1 = min(V, v0 + GN_VOX_PER_BLOCK);
+    float s[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[0][j] = s[1][j] = 0.f;
+    if (active) {
+        const T* xb = x + ((int64_t)b * V) * C + lc * 8;
+        for (int64_t v = v0 + r; v < v1; v += rows) {
+            Vec8<T> a;
+            a.load(xb + v * C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[0][j] += a.v[j]; s[1][j] += a.v[j] * a.v[j]; }
+        }
+    }
+    block_channel_reduce<2>(s, L, lc, active, acc + (size_t)b * C * 2, C);
+}
+
+// per (b, g): mean / rstd from per-channel (sum, sumsq)
+__global__ void gn_stats_finalize(const double* __restrict__ acc, float* __restrict__ stats, int B, int C, int G,
+                                  int64_t V, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G;
+    const int cpg = C / G;
+    double s = 0.0, ss = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        s += acc[((size_t)b * C + c) * 2];
+        ss += acc[((size_t)b * C + c) * 2 + 1];
+    }
+    const double n = (double)cpg * (double)V;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+extern "C" size_t tdx_gn_workspace_bytes(int B, int C) {
+    return (size_t)B * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + 64;
+}
+
+static int gn_shape_ok(int C, int G) { return C > 0 && G > 0 && C % 8 == 0 && C % G == 0 && (C / 8) <= GN_THREADS; }
+
+extern "C" int tdx_gn_stats(const void* x, float* stats, int B, int64_t V, int C, int G, float eps, int dtype,
+                            void* workspace, void* stream) {
+    TDX_CHECK_ARG(x && stats && workspace && B > 0 && V > 0);
+    if (!gn_shape_ok(C, G)) return TDX_ESHAPE;
+    double* acc = (double*)workspace;
+    hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * C * 2 * sizeof(double), as_stream(stream));
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(ceil_div(V, GN_VOX_PER_BLOCK), B);
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(GN_THREADS), 0, as_stream(stream),
+                                                  (const T*)x, acc, V, C));
+    hipLaunchKernelGGL(gn_stats_finalize, dim3(ceil_div(B * G, 64)), dim3(64), 0, as_stream(stream), acc, stats, B, C, G,
+                       V, eps);
+    return tdx_launch_status();
+}
+
+// per-thread affine coefficients of its 8 channels: n = x*a + c0  (FiLM folded in)
+struct GnCoef {
+    float a[8], c0[8];
+};
+__device__ __forceinline__ void gn_load_coef(GnCoef& k, float (&mean)[8], float (&rstd)[8], float (&gam)[8],
+                                             float (&film)[8], const float* __restrict__ stats,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             const float* __restrict__ scale, const float* __restrict__ shift, int b,
+                                             int C, int G, int cbase) {
+    const int cpg = C / G;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cbase + j;
+        const int g = c / cpg;
+        mean[j] = stats[((size_t)b * G + g) * 2];
+        rstd[j] = stats[((size_t)b * G + g) * 2 + 1];
+        gam[j] = gamma[c];
+        const float be = beta[c];
+        film[j] = scale ? 1.0f + scale[(size_t)b * C + c] : 1.0f;
+        const float sh = shift ? shift[(size_t)b * C + c] : 0.0f;
+        k.a[j] = rstd[j] * gam[j] * film[j];
+        k.c0[j] = (be - mean[j] * rstd[j] * gam[j]) * film[j] + sh;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS)
+gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                const float* __restrict__ beta, const float* __restrict__ scale, const float* __restrict__ shift,
+                const T* __restrict__ res, T* __restrict__ y, int64_t V, int C, int G, int act) {
+    const int b = blockIdx.y;
+    const int L = C >> 3;
+    const int rows = GN_THREADS / L;
+    const int tid = threadIdx.x;
+    const int lc = tid % L, r = tid / L;
+    if (r >= rows) return;
+    GnCoef k;
+    float mean[8], rstd[8], gam[8], film[8];
+    gn_load_coef(k, mean, rstd, gam, film, stats, gamma, beta, scale, shift, b, C, G, lc * 8);
+    const int64_t v0 = (int64_t)blockIdx.x * GN_VOX_PER_BLOCK;
+    const int64_t v1 = min(V, v0 + GN_VOX_PER_BLOCK);
+    const int64_t base = ((int64_t)b * V) * C + lc * 8;
+    for (int64_t v = v0 + r; v < v1; v += rows) {
+        Vec8<T> a, o;
+        a.load(x + base + v * C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float n = a.v[j] * k.a[j] + k.c0[j];
+            o.v[j] = act ? silu_f(n) : n;
+        }
+        if (res) {
+            Vec8<T> rr;
+            rr.load(res + base + v * C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.v[j] += rr.v[j];
+        }
+        o.store(y + base + v * C);
+    }
+}
+
+extern "C" int tdx_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta,
+                            const float* scale, const float* shift, const void* res, void* y, int B, int64_t V, int C,
+                            int G, int act, int dtype, void* stream) {
+    TDX_CHECK_ARG(x && stats && gamma && beta && y && B > 0 && V > 0);
+    TDX_CHECK_ARG((scale == nullptr) == (shift == nullptr));
+    if (!gn_shape_ok(C, G)) return TDX_ESHAPE;
+    dim3 grid(ceil_div(V, GN_VOX_PER_BLOCK), B);
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(GN_THREADS), 0, as_stream(stream),
+                                                  (const T*)x, stats, gamma, beta, scale, shift, (const T*)res, (T*)y,
+                                                  V, C, G, act));
+    return tdx_launch_status();
+}
+
+// ------------------------------------------------------------------ backward -------------
+// reduce pass: P[b,c] = sum_v dn, Q[b,c] = sum_v dn * xhat, dn = dy * act'(n)
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS)
+gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
+                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
+                     const float* __restrict__ shift, double* __restrict__ acc, int64_t V, int C, int G, int act) {
+    const int b = blockIdx.y;
+    const int L = C >> 3;
+    const int rows = GN_THREADS / L;
+    const int tid = threadIdx.x;
+    const int lc = tid % L, r = tid / L;
+    const bool active = r < rows;
+    float s[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[0][j] = s[1][j] = 0.f;
+    if (active) {
+        GnCoef k;
+        float mean[8], rstd[8], gam[8], film[8];
+        gn_load_coef(k, mean, rstd, gam, film, stats, gamma, beta, scale, shift, b, C, G, lc * 8);
+        const int64_t v0 = (int64_t)blockIdx.x * GN_VOX_PER_BLOCK;
+        const int64_t v1 = min(V, v0 + GN_VOX_PER_BLOCK);
+        const int64_t base = ((int64_t)b * V) * C + lc * 8;
+        for (int64_t v = v0 + r; v < v1; v += rows) {
+            Vec8<T> a, g;
+            a.load(x + base + v * C);
+            g.load(dy + base + v * C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float n = a.v[j] * k.a[j] + k.c0[j];
+                const float dn = act ? g.v[j] * dsilu_f(n) : g.v[j];
+                const float xh = (a.v[j] - mean[j]) * rstd[j];
+                s[0][j] += dn;
+                s[1][j] += dn * xh;
+            }
+        }
+    }
+    block_channel_reduce<2>(s, L, lc, active, acc + (size_t)b * C * 2, C);
+}
+
+// finalize: one thread per (b, g) for the group sums, then per-channel parameter grads.
+__global__ void gn_bwd_group_kernel(const double* __restrict__ acc, const float* __restrict__ gamma,
+                                    const float* __restrict__ scale, float* __restrict__ gsum, int B, int C, int G,
+                                    int64_t V) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G;
+    const int cpg = C / G;
+    double A = 0.0, Bq = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        const double k = (double)gamma[c] * (scale ? 1.0 + (double)scale[(size_t)b * C + c] : 1.0);
+        A += k * acc[((size_t)b * C + c) * 2];
+        Bq += k * acc[((size_t)b * C + c) * 2 + 1];
+    }
+    const double n = (double)cpg * (double)V;
+    gsum[2 * i] = (float)(A / n);
+    gsum[2 * i + 1] = (float)(Bq / n);
+}
+__global__ void gn_bwd_param_kernel(const double* __restrict__ acc, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ scale,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dscale,
+                                    float* __restrict__ dshift, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double dg = 0.0, db = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const double P = acc[((size_t)b * C + c) * 2], Q = acc[((size_t)b * C + c) * 2 + 1];
+        const double f = scale ? 1.0 + (double)scale[(size_t)b * C + c] : 1.0;
+        dg += f * Q;
+        db += f * P;
+        if (dscale) {
+            dshift[(size_t)b * C + c] = (float)P;
+            dscale[(size_t)b * C + c] = (float)((double)gamma[c] * Q + (double)beta[c] * P);
+        }
+    }
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)db;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS)
+gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
+                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
+                    const float* __restrict__ shift, const float* __restrict__ gsum, T* __restrict__ dx, int64_t V,
+                    int C, int G, int act) {
+    const int b = blockIdx.y;
+    const int L = C >> 3;
+    const int rows = GN_THREADS / L;
+    const int tid = threadIdx.x;
+    const int lc = tid % L, r = tid / L;
+    if (r >= rows) return;
+    GnCoef k;
+    float mean[8], rstd[8], gam[8], film[8], ga[8], gb[8];
+    gn_load_coef(k, mean, rstd, gam, film, stats, gamma, beta, scale, shift, b, C, G, lc * 8);
+    const int cpg = C / G;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (lc * 8 + j) / cpg;
+        ga[j] = gsum[((size_t)b * G + g) * 2];
+        gb[j] = gsum[((size_t)b * G + g) * 2 + 1];
+    }
+    const int64_t v0 = (int64_t)blockIdx.x * GN_VOX_PER_BLOCK;
+    const int64_t v1 = min(V, v0 + GN_VOX_PER_BLOCK);
+    const int64_t base = ((int64_t)b * V) * C + lc * 8;
+    for (int64_t v = v0 + r; v < v1; v += rows) {
+        Vec8<T> a, g, o;
+        a.load(x + base + v * C);
+        g.load(dy + base + v * C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float n = a.v[j] * k.a[j] + k.c0[j];
+            const float dn = act ? g.v[j] * dsilu_f(n) : g.v[j];
+            const float xh = (a.v[j] - mean[j]) * rstd[j];
+            o.v[j] = rstd[j] * (gam[j] * film[j] * dn - ga[j] - xh * gb[j]);
+        }
+        o.store(dx + base + v * C);
+    }
+}
+
+extern "C" int tdx_gn_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
+                          const float* scale, const float* shift, void* dx, float* dgamma, float* dbeta, float* dscale,
+                          float* dshift, int B, int64_t V, int C, int G, int act, int dtype, void* workspace,
+                          void* stream) {
+    TDX_CHECK_ARG(x && dy && stats && gamma && beta && dx && dgamma && dbeta && workspace && B > 0 && V > 0);
+    TDX_CHECK_ARG((scale == nullptr) == (shift == nullptr));
+    TDX_CHECK_ARG((scale == nullptr) == (dscale == nullptr) && (dscale == nullptr) == (dshift == nullptr));
+    if (!gn_shape_ok(C, G)) return TDX_ESHAPE;
+    double* acc = (double*)workspace;
+    float* gsum = (float*)(acc + (size_t)B * C * 2);
+    hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * C * 2 * sizeof(double), as_stream(stream));
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(ceil_div(V, GN_VOX_PER_BLOCK), B);
+    hipStream_t st = as_stream(stream);
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T>), grid, dim3(GN_THREADS), 0, st,
+                                                  (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, acc, V,
+                                                  C, G, act));
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(ceil_div(B * G, 64)), dim3(64), 0, st, acc, gamma, scale, gsum, B, C, G,
+                       V);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, acc, gamma, beta, scale, dgamma,
+                       dbeta, dscale, dshift, B, C);
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), grid, dim3(GN_THREADS), 0, st,
+                                                  (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, gsum,
+                                                  (T*)dx, V, C, G, act));
+    return tdx_launch_status();
+}

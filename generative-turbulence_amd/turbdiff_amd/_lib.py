@@ -1,0 +1,113 @@
+"""ctypes binding of libtdx_hip.so -- the C ABI declared in include/tdx.h.
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C csrc``) and lives next
+to this file.  There is no CPU implementation behind this module: if the shared object is
+missing, or a kernel launch fails, a RuntimeError is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libtdx_hip.so"
+
+F32, BF16 = 0, 1
+CONV_AUTO, CONV_DIRECT, CONV_MFMA = 0, 1, 2
+
+_vp, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/tdx.h
+SIGNATURES = {
+    "tdx_version": (_i, []),
+    "tdx_arch": (C.c_char_p, []),
+    "tdx_ncv_to_nvc": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _vp]),
+    "tdx_nvc_to_ncv": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _vp]),
+    "tdx_cast": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "tdx_conv3_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tdx_conv3_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tdx_conv3_bwd_data_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "tdx_conv3_bwd_data": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "tdx_conv3_bwd_weight_workspace_bytes": (_sz, [_i, _i, _i]),
+    "tdx_conv3_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "tdx_conv1_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "tdx_conv1_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i64, _i, _vp]),
+    "tdx_gn_workspace_bytes": (_sz, [_i, _i]),
+    "tdx_gn_stats": (_i, [_vp, _vp, _i, _i64, _i, _i, _f, _i, _vp, _vp]),
+    "tdx_gn_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
+    "tdx_gn_bwd": (_i, [_vp] * 12 + [_i, _i64, _i, _i, _i, _i, _vp, _vp]),
+    "tdx_resize_fwd": (_i, [_vp, _vp] + [_i] * 9 + [_vp]),
+    "tdx_resize_bwd": (_i, [_vp, _vp] + [_i] * 9 + [_vp]),
+    "tdx_attn_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tdx_attn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "tdx_attn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "tdx_cell_mask": (_i, [_vp, _i64, _vp, _i64, _vp]),
+    "tdx_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i64, _vp]),
+    "tdx_p_sample_step": (_i, [_vp] * 7 + [_i, _vp, _i, _i, _vp, _i, _i, _i64, _vp]),
+    "tdx_masked_loss": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i64, _vp, _vp]),
+    "tdx_masked_loss_workspace_bytes": (_sz, []),
+    "tdx_randn": (_i, [_vp, _i64, _u64, _u64, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP kernels have not been built. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C generative-turbulence_amd/csrc`)."
+            )
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise TypeError(f"tdx kernels support float32 and bfloat16 activations, got {dt}")
+
+
+def conv_impl() -> int:
+    return {"auto": CONV_AUTO, "direct": CONV_DIRECT, "mfma": CONV_MFMA}[os.environ.get("TDX_CONV_IMPL", "auto")]
+
+
+def ptr(t: torch.Tensor | None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("tdx kernels need device tensors (no CPU path exists in the product)")
+    if not t.is_contiguous():
+        raise RuntimeError("tdx kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_ERR = {-1: "TDX_EINVAL (bad argument)", -2: "TDX_ESHAPE (unsupported shape)", -3: "TDX_EDTYPE (unsupported dtype)"}
+
+
+def call(name: str, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, f'hipError {rc}')}")
+
+
+def query(name: str, *args) -> int:
+    return int(getattr(load(), name)(*args))

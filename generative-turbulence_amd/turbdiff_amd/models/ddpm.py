@@ -1,0 +1,498 @@
+"""DenoisingModel (3D U-Net) and GaussianDiffusion (DDPM) on the MI355X HIP kernels.
+
+Drop-in for the public surface of the reference's ``turbdiff/models/ddpm.py``:
+same class names, constructor keywords, method names / arguments and -- because the
+parameter containers are the same torch modules in the same attribute tree -- the same
+``state_dict`` keys and default initialisation.  What differs is the
+execution: module ``forward``s do not call ``nn.Conv3d``/``nn.GroupNorm``; they hand their
+parameters to the fused NDHWC operators in ``turbdiff_amd.ops``.
+
+Layout contract: ``DenoisingModel.forward`` and every ``GaussianDiffusion`` method take and
+return the reference's NCDHW float32 tensors ``(B, F, X, Y, Z)``.  The building blocks below
+(``Block``, ``ResnetBlock``, ``Attention``, ``UNet``) run on NDHWC tensors ``(B, X, Y, Z, C)``
+in the model's compute dtype (float32 or bfloat16 storage, fp32 accumulation).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from functools import partial
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops, schedules
+from ..sequential import KwargsSequential
+from .conditioning import global_conditioning, local_conditioning
+from .utils import broadcast_right
+
+
+@dataclass
+class ModelPrediction:
+    noise: torch.Tensor
+    x_start: torch.Tensor
+    mean: torch.Tensor
+    log_var: torch.Tensor
+
+
+# --------------------------------------------------------------------------- time embedding
+
+
+class NyquistFrequencyEmbedding(nn.Module):
+    """sin(bias + scale t) with k = dim/2 geometric frequencies, each as sin and cos
+    (reference ddpm.py:103-148).  B x dim values: stays a torch op."""
+
+    def __init__(self, dim: int, timesteps: int):
+        super().__init__()
+        scale, bias = schedules.nyquist_embedding_tables(dim, timesteps)
+        self.register_buffer("scale", scale, persistent=False)
+        self.register_buffer("bias", bias, persistent=False)
+
+    def forward(self, t):
+        return torch.addcmul(self.bias, self.scale, t[..., None]).sin()
+
+
+class SinusoidalPosEmb(nn.Module):
+    """Transformer-style embedding; unused by the default model, kept for API parity
+    (reference ddpm.py:88-100)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, t):
+        half = self.dim // 2
+        freq = torch.exp(torch.arange(half, device=t.device) * (-math.log(10000) / (half - 1)))
+        ang = t[:, None] * freq[None, :]
+        return torch.cat((ang.sin(), ang.cos()), dim=-1)
+
+
+# --------------------------------------------------------------------------- blocks (NDHWC)
+
+
+def _norm_groups(norm: nn.GroupNorm) -> int:
+    return norm.num_groups
+
+
+class Block(nn.Module):
+    """conv3x3x3(replicate) -> GroupNorm -> [FiLM] -> activation  (reference ddpm.py:154-177).
+
+    ``forward`` fuses GroupNorm, the FiLM affine, SiLU and an optional residual add into one
+    stats pass + one apply pass over the conv output."""
+
+    def __init__(self, dim, dim_out, actfn, norm_klass=None):
+        super().__init__()
+        self.conv = nn.Conv3d(dim, dim_out, 3, padding=1, padding_mode="replicate")
+        self.norm = norm_klass(dim_out)
+        self.act = actfn()
+        self._fused_act = isinstance(self.act, nn.SiLU)
+
+    def forward(self, x, scale_shift=None, x2=None, res=None):
+        h = ops.conv3(x, self.conv.weight, self.conv.bias, x2=x2)
+        scale, shift = scale_shift if scale_shift is not None else (None, None)
+        if self._fused_act:
+            return ops.gn_film_silu(h, self.norm.weight, self.norm.bias, _norm_groups(self.norm), scale, shift,
+                                    res=res, act=True, eps=self.norm.eps)
+        h = ops.gn_film_silu(h, self.norm.weight, self.norm.bias, _norm_groups(self.norm), scale, shift, act=False,
+                             eps=self.norm.eps)
+        h = self.act(h)
+        return h if res is None else h + res
+
+
+class ResnetBlock(nn.Module):
+    """Two Blocks, FiLM-conditioned on `c` in the first, plus a 1x1-projected (or identity)
+    skip of the block input (reference ddpm.py:180-197).  The input may be given as two
+    tensors whose channel concatenation is never materialised (`x2`)."""
+
+    def __init__(self, dim_in, dim_out, *, c_dim: int, actfn, norm_klass):
+        super().__init__()
+        self.project_onto_scale_shift = nn.Linear(c_dim, dim_out * 2)
+        self.block1 = Block(dim_in, dim_out, actfn=actfn, norm_klass=norm_klass)
+        self.block2 = Block(dim_out, dim_out, actfn=actfn, norm_klass=norm_klass)
+        self.conv = nn.Conv3d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
+        self.dim_out = dim_out
+
+    def forward(self, x, c, x2=None):
+        film = self.project_onto_scale_shift(c)  # (B, 2*dim_out): [scale | shift]
+        scale, shift = film[:, : self.dim_out], film[:, self.dim_out :]
+        h = self.block1(x, scale_shift=(scale, shift), x2=x2)
+        if isinstance(self.conv, nn.Identity):
+            skip = x if x2 is None else torch.cat((x, x2), dim=-1)
+        else:
+            skip = ops.conv1(x, self.conv.weight, self.conv.bias, x2=x2)
+        return self.block2(h, res=skip)
+
+
+class Attention(nn.Module):
+    """Multi-head self-attention over all voxels (reference ddpm.py:286-308).  to_qkv's NDHWC
+    output already is the token-major q|k|v matrix the attention kernel reads, and the
+    surrounding residual add is folded into the to_out projection."""
+
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        self.heads = heads
+        hidden = dim_head * heads
+        self.to_qkv = nn.Conv3d(dim, hidden * 3, 1, bias=False)
+        self.to_out = nn.Conv3d(hidden, dim, 1)
+
+    def forward(self, x, residual=None):
+        B, X, Y, Z, _ = x.shape
+        qkv = ops.conv1(x, self.to_qkv.weight)
+        out = ops.attention(qkv.reshape(B, X * Y * Z, -1), self.heads)
+        return ops.conv1(out.reshape(B, X, Y, Z, -1), self.to_out.weight, self.to_out.bias, add=residual)
+
+
+class PreNorm(nn.Module):
+    def __init__(self, norm: nn.Module, fn: nn.Module, enabled: bool = True):
+        super().__init__()
+        self.norm = norm
+        self.fn = fn
+
+    def forward(self, x, residual=None):
+        xn = ops.gn_film_silu(x, self.norm.weight, self.norm.bias, _norm_groups(self.norm), act=False, eps=self.norm.eps)
+        return self.fn(xn) if residual is None else self.fn(xn, residual=residual)
+
+
+class Residual(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        if isinstance(self.fn, PreNorm) and isinstance(self.fn.fn, Attention):
+            return self.fn(x, residual=x)
+        return self.fn(x) + x
+
+
+def down_size(spatial):
+    """Halve each extent, never below the kernel size 3 (reference ddpm.py:358)."""
+    return [max(int(s * 0.5), 3) for s in spatial]
+
+
+class UNet(nn.Module):
+    """Encoder / bottleneck / decoder with trilinear resampling between levels and skip
+    concatenation (reference ddpm.py:326-372).  Skips are passed to the decoder blocks as a
+    second conv input instead of being concatenated."""
+
+    def __init__(self, downsampling_blocks, upsampling_blocks, center_block, *, downsampling_factor: float = 2.0):
+        super().__init__()
+        assert len(downsampling_blocks) == len(upsampling_blocks)
+        self.downsampling_blocks = nn.ModuleList(downsampling_blocks)
+        self.upsampling_blocks = nn.ModuleList(upsampling_blocks)
+        self.center_block = center_block
+        self.downsampling_factor = downsampling_factor
+        self.scale_factor = 1 / downsampling_factor
+
+    def forward(self, x, c):
+        skips = []
+        for blk in self.downsampling_blocks:
+            x = blk(x, c)
+            skips.append(x)
+            x = ops.resize(x, [max(int(s * self.scale_factor), 3) for s in x.shape[1:4]])
+        x = self.center_block(x, c=c)
+        for blk in self.upsampling_blocks:
+            skip = skips.pop()
+            x = blk(ops.resize(x, skip.shape[1:4]), c, x2=skip)
+        return x
+
+
+class GeometryEmbedding(nn.Module):
+    """Strided-conv summary of the obstacle region (reference ddpm.py:375-395); off in the
+    shipped configuration (config/model/diffusion.yaml:30), kept on stock torch ops."""
+
+    def __init__(self, in_features, out_features, actfn):
+        super().__init__()
+        self.in_features, self.out_features, self.actfn = in_features, out_features, actfn
+        self.extract_features = nn.Sequential(
+            nn.Conv3d(in_features, out_features, kernel_size=5, stride=5),
+            actfn(),
+            nn.Conv3d(out_features, out_features, kernel_size=5, stride=1),
+            actfn(),
+            nn.Conv3d(out_features, out_features, kernel_size=5, stride=5),
+        )
+
+    def forward(self, c_local):
+        front = torch.narrow(c_local, dim=-3, start=0, length=50)
+        return self.extract_features(front).mean(dim=(-3, -2, -1))
+
+
+# --------------------------------------------------------------------------- the denoiser
+
+
+class DenoisingModel(nn.Module):
+    """eps_theta(x_t, t, C): the turbdiff 3D U-Net (reference ddpm.py:398-505)."""
+
+    def __init__(self, *, in_features: int, out_features: int, c_local_features: int, c_global_features: int,
+                 timesteps: int, dim: int, u_net_levels: int, actfn=nn.SiLU, norm_type: str = "instance",
+                 with_geometry_embedding: bool = False):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.c_local_features = c_local_features
+        self.c_global_features = c_global_features
+        self.dim = dim
+        self.timesteps = timesteps
+        self.u_net_levels = u_net_levels
+        self.with_geometry_embedding = with_geometry_embedding
+        self.compute_dtype = torch.float32
+
+        groups_of = {"instance": lambda ch: ch, "layer": lambda ch: 1, "group": lambda ch: 8}
+        if norm_type not in groups_of:
+            raise RuntimeError(f"Unknown norm type {norm_type}")
+        norm_klass = lambda ch: nn.GroupNorm(groups_of[norm_type](ch), ch)
+
+        # construction order follows the reference so that seeded default init matches
+        self.encode_x = nn.Conv3d(in_features, dim, 1)
+        c_local_dim = 0
+        if c_local_features > 0:
+            self.encode_c_local = nn.Conv3d(c_local_features, dim, 1)
+            c_local_dim = dim
+        c_dim = dim
+        self.encode_t = NyquistFrequencyEmbedding(dim, timesteps)
+        if c_global_features > 0:
+            self.encode_c_global = nn.Linear(c_global_features, dim)
+            c_dim += dim
+        if with_geometry_embedding and c_local_features > 0:
+            self.geometry_embedding = GeometryEmbedding(c_local_features, dim, actfn)
+            c_dim += dim
+        self.process_c = nn.Sequential(nn.Linear(c_dim, 4 * c_dim), actfn(), nn.Linear(4 * c_dim, c_dim), actfn())
+
+        rb = partial(ResnetBlock, c_dim=c_dim, actfn=actfn, norm_klass=norm_klass)
+        self.decode = KwargsSequential(rb(dim, dim), nn.Conv3d(dim, out_features, 1))
+        down = [rb(dim + c_local_dim, dim * 2)] + [rb(dim * 2**i, dim * 2 ** (i + 1)) for i in range(1, u_net_levels)]
+        up = [rb(2 * dim * 2 ** (i + 1), dim * 2**i) for i in reversed(range(u_net_levels))]
+        mid = dim * 2**u_net_levels
+        center = KwargsSequential(rb(mid, mid), Residual(PreNorm(norm_klass(mid), Attention(mid))), rb(mid, mid))
+        self.u_net = UNet(down, up, center)
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        """float32 (parity mode) or bfloat16 (activation storage + MFMA operands)."""
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        return self
+
+    def conditioning_vector(self, t, C, batch_size):
+        parts = [self.encode_t(t)]
+        c_global = global_conditioning(C)
+        if c_global is not None:
+            parts.append(self.encode_c_global(c_global))
+        if self.with_geometry_embedding:
+            c_local = local_conditioning(C)
+            if c_local is not None:
+                parts.append(self.geometry_embedding(c_local).expand((batch_size, -1)))
+        return self.process_c(torch.cat(parts, dim=-1))
+
+    def encode_local(self, C):
+        """encode_c_local(c_local) as a (1, X, Y, Z, dim) NDHWC tensor (None without local
+        conditioning).  Independent of x and t: sampling computes it once per trajectory batch
+        (the reference recomputes it every step, TODO at ddpm.py:480)."""
+        c_local = local_conditioning(C)
+        if c_local is None:
+            return None
+        cl = ops.to_nvc(c_local[None].float(), self.compute_dtype)
+        return ops.conv1(cl, self.encode_c_local.weight, self.encode_c_local.bias)
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
+        B = x.shape[0]
+        c = self.conditioning_vector(t, C, B)
+        h = ops.conv1(ops.to_nvc(x, self.compute_dtype), self.encode_x.weight, self.encode_x.bias)
+        e = encoded_local if encoded_local is not None else self.encode_local(C)
+        if e is not None:
+            h = torch.cat((h, e.expand(B, -1, -1, -1, -1)), dim=-1)
+        h = self.u_net(h, c)
+        h = self.decode[0](h, c)
+        y = ops.conv1(h, self.decode[1].weight, self.decode[1].bias)
+        return ops.to_ncv(y, torch.float32)
+
+
+# --------------------------------------------------------------------------- schedules (API)
+
+
+def linear_beta_schedule(timesteps):
+    return schedules.betas_for("linear", timesteps)
+
+
+def log_linear_beta_schedule(timesteps):
+    return schedules.betas_for("log-linear", timesteps)
+
+
+def log_snr_linear_beta_schedule(timesteps, snr_1=1e3, snr_T=1e-5):
+    assert (snr_1, snr_T) == (1e3, 1e-5), "only the reference's default SNR end points are tabulated"
+    return schedules.betas_for("log-snr-linear", timesteps)
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    assert s == 0.008
+    return schedules.betas_for("cosine", timesteps)
+
+
+def sigmoid_beta_schedule(timesteps, start=-3, end=3, tau=1, clamp_min=1e-5):
+    assert (start, end, tau) == (-3, 3, 1)
+    return schedules.betas_for("sigmoid", timesteps)
+
+
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """KL(N(mean1, e^logvar1) || N(mean2, e^logvar2)) elementwise (reference ddpm.py:597-607)."""
+    return 0.5 * (logvar2 - logvar1 - 1.0 + torch.exp(logvar1 - logvar2) + (mean1 - mean2) ** 2 * torch.exp(-logvar2))
+
+
+def normal_log_lk(x, mean, log_var):
+    return -0.5 * (log_var + math.log(2 * math.pi) + (x - mean) ** 2 * torch.exp(-log_var))
+
+
+def batch_mean(x: torch.Tensor):
+    return x.flatten(1).mean(dim=1)
+
+
+# --------------------------------------------------------------------------- the diffusion
+
+
+class GaussianDiffusion(nn.Module):
+    """DDPM training loss and ancestral sampler around a DenoisingModel
+    (reference ddpm.py:620-882).
+
+    The q_sample / loss / reverse-step arithmetic runs in fused HIP kernels over a dense
+    in-domain mask built once per ``cell_idx`` tensor; the learned-variance + ELBO branch
+    (off in the shipped configuration) is evaluated with torch ops on the same tensors.
+    """
+
+    def __init__(self, model, *, timesteps: int = 1000, loss_type: str = "l2", beta_schedule: str = "sigmoid",
+                 clip_denoised: bool = False, noise_bcs: bool = False, learned_variances: bool = False,
+                 elbo_weight: float | None = None, detach_elbo_mean: bool = True):
+        super().__init__()
+        self.model = model
+        self.clip_denoised = clip_denoised
+        self.noise_bcs = noise_bcs
+        self.learned_variances = learned_variances
+        self.elbo_weight = elbo_weight
+        self.detach_elbo_mean = detach_elbo_mean
+        self.num_timesteps = timesteps
+        self.loss_type = loss_type
+        if loss_type not in ("l1", "l2"):
+            raise ValueError(f"invalid loss type {loss_type}")
+        tables = schedules.diffusion_tables(beta_schedule, timesteps)
+        for name, tab in tables.items():
+            self.register_buffer(name, tab, persistent=False)
+        self.register_buffer("step_tables", schedules.pack_step_tables(tables), persistent=False)
+        self._mask_cache = None
+
+    # ---- helpers
+    def domain_mask(self, cell_idx: torch.Tensor, V: int):
+        """(uint8 [V] mask, n_cells) for a flat in-domain cell index list; cached per tensor."""
+        key = (cell_idx.data_ptr(), cell_idx.numel(), V, cell_idx.device)
+        if self._mask_cache is None or self._mask_cache[0] != key:
+            self._mask_cache = (key, ops.cell_mask(cell_idx, V), int(cell_idx.numel()))
+        return self._mask_cache[1], self._mask_cache[2]
+
+    @property
+    def loss_fn(self):
+        return F.l1_loss if self.loss_type == "l1" else F.mse_loss
+
+    # ---- closed-form pieces (torch; used by the general / learned-variance paths)
+    def predict_start_from_noise(self, x_t, t, noise):
+        return (broadcast_right(self.sqrt_recip_alphas_cumprod[t], x_t) * x_t
+                - broadcast_right(self.sqrt_recipm1_alphas_cumprod[t], x_t) * noise)
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        return ((broadcast_right(self.sqrt_recip_alphas_cumprod[t], x_t) * x_t - x0)
+                / broadcast_right(self.sqrt_recipm1_alphas_cumprod[t], x_t))
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = (broadcast_right(self.posterior_mean_coef1[t], x_t) * x_start
+                + broadcast_right(self.posterior_mean_coef2[t], x_t) * x_t)
+        return mean, broadcast_right(self.posterior_log_var[t], x_t)
+
+    def q_sample(self, x_start, t, noise):
+        return ops.q_sample(x_start, noise, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, t)
+
+    def _outside_keep(self, mask, inside_vals, outside_vals):
+        m = mask.view(inside_vals.shape[-3:]).bool()
+        return torch.where(m, inside_vals, outside_vals)
+
+    def model_predictions(self, x_t, t, C, cell_idx, clip_x_start=False, **model_kwargs):
+        out = self.model(x_t, t, C, **model_kwargs)
+        if self.learned_variances:
+            pred_noise, vw = out.chunk(2, dim=1)
+            log_var = torch.lerp(broadcast_right(self.log_betas[t], vw), broadcast_right(self.posterior_log_var[t], vw),
+                                 torch.sigmoid(vw))
+        else:
+            pred_noise, log_var = out, self.log_betas[t]
+        x_start = self.predict_start_from_noise(x_t, t, pred_noise)
+        if not self.noise_bcs:
+            mask, _ = self.domain_mask(cell_idx, x_t[0, 0].numel())
+            x_start = self._outside_keep(mask, x_start, x_t)
+        if clip_x_start:
+            x_start = torch.clamp(x_start, min=-1.0, max=1.0)
+        mean, _ = self.q_posterior(x_start, x_t, t)
+        return ModelPrediction(noise=pred_noise, x_start=x_start, mean=mean, log_var=log_var)
+
+    @torch.no_grad()
+    def p_sample(self, x_t, t: int, C, cell_idx):
+        times = torch.full((x_t.shape[0],), t, dtype=torch.long, device=x_t.device)
+        pred = self.model_predictions(x_t, times, C, cell_idx, clip_x_start=self.clip_denoised)
+        return pred.mean, pred.log_var
+
+    @torch.no_grad()
+    def p_sample_loop(self, x_bcs, C, cell_idx, pbar=False, start_from: int | None = None, noise_fn=None):
+        """Ancestral sampling.  Noise is drawn in the reference's order (x_T; then per step
+        t > 0: z, and z' if noise_bcs); ``noise_fn(like)`` replaces ``torch.randn_like``."""
+        if self.learned_variances:
+            raise NotImplementedError("sampling with learned variances is not on the accelerated path")
+        randn = noise_fn if noise_fn is not None else torch.randn_like
+        x_bcs = x_bcs.contiguous().float()
+        B, Fd = x_bcs.shape[:2]
+        V = x_bcs[0, 0].numel()
+        dev = x_bcs.device
+        mask, _ = self.domain_mask(cell_idx, V)
+        ts = torch.arange(self.num_timesteps, dtype=torch.long, device=dev)
+        if start_from is None:
+            x_t, T = randn(x_bcs), self.num_timesteps
+        else:
+            x_t = ops.q_sample(x_bcs, randn(x_bcs), self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod,
+                               ts[start_from - 1 : start_from])
+            T = start_from
+        if not self.noise_bcs:
+            x_t = self._outside_keep(mask, x_t, x_bcs)
+        enc = self.model.encode_local(C) if hasattr(self.model, "encode_local") else None
+        kw = {"encoded_local": enc} if enc is not None else {}
+        steps = reversed(range(T))
+        if pbar:
+            from tqdm.auto import tqdm
+
+            steps = tqdm(steps, desc="sampling loop time step", total=T, position=1)
+        for t in steps:
+            eps = self.model(x_t, ts[t].expand(B), C, **kw)
+            z = randn(x_t) if t > 0 else None
+            z2 = randn(x_bcs) if (t > 0 and self.noise_bcs) else None
+            x_t = ops.p_sample_step(x_t, eps, z, z2, x_bcs, mask, self.step_tables, self.num_timesteps, ts[t : t + 1],
+                                    self.noise_bcs, self.clip_denoised)
+        return x_t
+
+    def p_losses(self, x_start, t, C, metadata, variables, noise=None):
+        x_start = x_start.contiguous().float()
+        cell_idx = metadata.cell_idx
+        mask, n_cells = self.domain_mask(cell_idx, x_start[0, 0].numel())
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        x_t = ops.q_sample(x_start, noise, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, t,
+                           mask=mask, keep_bcs=not self.noise_bcs)
+        if not (self.learned_variances and self.elbo_weight is not None):
+            out = self.model(x_t, t, C)
+            pred_noise = out.chunk(2, dim=1)[0].contiguous() if self.learned_variances else out
+            return ops.masked_loss(pred_noise, noise, mask, n_cells, l1=self.loss_type == "l1"), t
+        # learned variances + ELBO term (reference ddpm.py:853-870), torch ops
+        pred = self.model_predictions(x_t, t, C, cell_idx, clip_x_start=self.clip_denoised)
+        loss = ops.masked_loss(pred.noise.contiguous(), noise, mask, n_cells, l1=self.loss_type == "l1")
+        true_mean, true_log_var = self.q_posterior(x_start, x_t, t)
+        model_mean = pred.mean.detach() if self.detach_elbo_mean else pred.mean
+        sel = lambda v: v.flatten(-3)[..., cell_idx]
+        kl = sel(normal_kl(true_mean, true_log_var, model_mean, pred.log_var))
+        ll = sel(normal_log_lk(x_t, model_mean, pred.log_var))
+        elbo = torch.where(t == 0, -batch_mean(ll), batch_mean(kl))
+        return loss + self.elbo_weight * elbo.mean(), t
+
+    def forward(self, x, *args, **kwargs):
+        t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=x.device, dtype=torch.long)
+        return self.p_losses(x, t, *args, **kwargs)

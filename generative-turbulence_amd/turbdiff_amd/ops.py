@@ -1,0 +1,403 @@
+"""Differentiable operators of the hot path, executed by the HIP kernels in libtdx_hip.so.
+
+Activations are NDHWC tensors ``(B, X, Y, Z, C)`` in float32 or bfloat16; parameters stay in
+the reference's shapes and float32 (so state_dicts round-trip).  Each
+``torch.autograd.Function`` here replaces one stock PyTorch call of the reference:
+
+    conv3            nn.Conv3d(k=3, padding_mode="replicate")            ddpm.py:164
+    conv1            nn.Conv3d(k=1) incl. the torch.cat that feeds it     ddpm.py:188,292,293,433,436,459
+    gn_film_silu     GroupNorm -> addcmul(shift, scale+1, x) -> SiLU (+x)  ddpm.py:165-176,197
+    resize           F.interpolate(trilinear, align_corners=True)         ddpm.py:359-369
+    attention        F.scaled_dot_product_attention                       attention.py:9-15
+    q_sample / p_sample_step / masked_loss                                ddpm.py:745-852
+
+There is no CPU implementation: tensors must live on the GPU.
+"""
+
+from __future__ import annotations
+
+import weakref
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _grid(x: torch.Tensor):
+    assert x.dim() == 5, "expected an NDHWC tensor (B, X, Y, Z, C)"
+    return x.shape[0], x.shape[1], x.shape[2], x.shape[3], x.shape[4]
+
+
+# --------------------------------------------------------------------------- layout
+
+
+class _ToNVC(torch.autograd.Function):
+    """(B, C, X, Y, Z) float32 -> (B, X, Y, Z, C) compute dtype."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        B, Cc, X, Y, Z = x.shape
+        x = x.contiguous()
+        y = torch.empty((B, X, Y, Z, Cc), dtype=dtype, device=x.device)
+        L.call("tdx_ncv_to_nvc", L.ptr(x), L.ptr(y), B, Cc, X * Y * Z, L.dtype_code(x.dtype), L.dtype_code(dtype), L.stream())
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        B, X, Y, Z, Cc = gy.shape
+        gy = gy.contiguous()
+        gx = torch.empty((B, Cc, X, Y, Z), dtype=ctx.in_dtype, device=gy.device)
+        L.call("tdx_nvc_to_ncv", L.ptr(gy), L.ptr(gx), B, Cc, X * Y * Z, L.dtype_code(gy.dtype), L.dtype_code(ctx.in_dtype), L.stream())
+        return gx, None
+
+
+class _ToNCV(torch.autograd.Function):
+    """(B, X, Y, Z, C) -> (B, C, X, Y, Z) in `dtype`."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        B, X, Y, Z, Cc = x.shape
+        x = x.contiguous()
+        y = torch.empty((B, Cc, X, Y, Z), dtype=dtype, device=x.device)
+        L.call("tdx_nvc_to_ncv", L.ptr(x), L.ptr(y), B, Cc, X * Y * Z, L.dtype_code(x.dtype), L.dtype_code(dtype), L.stream())
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        B, Cc, X, Y, Z = gy.shape
+        gy = gy.contiguous()
+        gx = torch.empty((B, X, Y, Z, Cc), dtype=ctx.in_dtype, device=gy.device)
+        L.call("tdx_ncv_to_nvc", L.ptr(gy), L.ptr(gx), B, Cc, X * Y * Z, L.dtype_code(gy.dtype), L.dtype_code(ctx.in_dtype), L.stream())
+        return gx, None
+
+
+def to_nvc(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    return _ToNVC.apply(x, dtype)
+
+
+def to_ncv(x: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    return _ToNCV.apply(x, dtype)
+
+
+# --------------------------------------------------------------------------- conv 3x3x3
+
+# packed operands are cached per (parameter, version, dtype): repacked once per optimiser
+# step in training, once per model in sampling
+_pack_cache: dict = {}
+
+
+def _packed_conv3(weight: torch.Tensor, dtype: torch.dtype):
+    key = (id(weight), dtype)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3], hit[4]
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    w = weight.detach().contiguous()
+    wf = torch.empty(27 * Cin * Cout, dtype=dtype, device=w.device)
+    wb = torch.empty(27 * Cin * Cout, dtype=dtype, device=w.device)
+    L.call("tdx_conv3_pack_weight", L.ptr(w), L.ptr(wf), L.ptr(wb), Cin, Cout, L.dtype_code(dtype), L.stream())
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+    _pack_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wf, wb)
+    return wf, wb
+
+
+class _Conv3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias):
+        B, X, Y, Z, C1 = _grid(x1)
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Cout = weight.shape[0]
+        assert weight.shape[1] == C1 + C2 and tuple(weight.shape[2:]) == (3, 3, 3)
+        x1 = x1.contiguous()
+        x2 = None if x2 is None else x2.contiguous()
+        dt = x1.dtype
+        wf, wb = _packed_conv3(weight, dt)
+        y = torch.empty((B, X, Y, Z, Cout), dtype=dt, device=x1.device)
+        L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Cout,
+               L.dtype_code(dt), L.conv_impl(), L.stream())
+        ctx.save_for_backward(x1, x2, wb)
+        ctx.has_bias = bias is not None
+        ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x1, x2, wb = ctx.saved_tensors
+        B, X, Y, Z, C1 = _grid(x1)
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Cout, Cin = ctx.wshape[0], ctx.wshape[1]
+        gy = gy.contiguous()
+        dt, dev = gy.dtype, gy.device
+        code, impl, st = L.dtype_code(dt), L.conv_impl(), L.stream()
+        gx1 = gx2 = gw = gb = None
+        if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
+            gx1 = torch.empty_like(x1)
+            gx2 = None if x2 is None else torch.empty_like(x2)
+            ws = _ws(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, Cin, code, impl), dev)
+            L.call("tdx_conv3_bwd_data", L.ptr(gy), L.ptr(wb), L.ptr(gx1), C1, L.ptr(gx2), C2, 0, B, X, Y, Z, Cout,
+                   code, impl, L.ptr(ws), st)
+        if ctx.needs_input_grad[2]:
+            gw = torch.empty(ctx.wshape, dtype=torch.float32, device=dev)
+            gb = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+            ws = _ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cin, Cout, impl), dev)
+            L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z,
+                   Cout, code, impl, L.ptr(ws), st)
+        return gx1, gx2, gw, gb
+
+
+def conv3(x1, weight, bias=None, x2=None):
+    """Replicate-padded 3x3x3 convolution of the channel concatenation [x1 | x2]."""
+    return _Conv3.apply(x1, x2, weight, bias)
+
+
+# --------------------------------------------------------------------------- conv 1x1x1
+
+
+class _Conv1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, add):
+        C1 = x1.shape[-1]
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Cout = weight.shape[0]
+        w2 = weight.detach().reshape(Cout, -1)
+        assert w2.shape[1] == C1 + C2
+        x1 = x1.contiguous()
+        x2 = None if x2 is None else x2.contiguous()
+        add = None if add is None else add.contiguous()
+        rows = x1.numel() // C1
+        wt = w2.t().contiguous()  # [Cin][Cout]
+        y = torch.empty(x1.shape[:-1] + (Cout,), dtype=x1.dtype, device=x1.device)
+        L.call("tdx_conv1_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wt), Cout, L.ptr(bias), L.ptr(add), L.ptr(y), rows,
+               Cout, L.dtype_code(x1.dtype), L.stream())
+        ctx.save_for_backward(x1, x2, w2.contiguous())
+        ctx.has_bias = bias is not None
+        ctx.has_add = add is not None
+        ctx.wshape = tuple(weight.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x1, x2, w2 = ctx.saved_tensors  # w2: [Cout][Cin]
+        C1 = x1.shape[-1]
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Cout, Cin = w2.shape
+        gy = gy.contiguous()
+        rows = gy.numel() // Cout
+        code, st, dev = L.dtype_code(gy.dtype), L.stream(), gy.device
+        gx1 = gx2 = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx1 = torch.empty_like(x1)
+            L.call("tdx_conv1_fwd", L.ptr(gy), Cout, None, 0, w2.data_ptr(), Cin, None, None, L.ptr(gx1), rows, C1, code, st)
+        if x2 is not None and ctx.needs_input_grad[1]:
+            gx2 = torch.empty_like(x2)
+            L.call("tdx_conv1_fwd", L.ptr(gy), Cout, None, 0, w2.data_ptr() + 4 * C1, Cin, None, None, L.ptr(gx2), rows, C2, code, st)
+        if ctx.needs_input_grad[2]:
+            gwt = torch.empty((Cin, Cout), dtype=torch.float32, device=dev)
+            gb = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+            L.call("tdx_conv1_bwd_weight", L.ptr(x1), C1, L.ptr(gy), Cout, gwt.data_ptr(), Cout, L.ptr(gb), rows, code, st)
+            if x2 is not None:
+                L.call("tdx_conv1_bwd_weight", L.ptr(x2), C2, L.ptr(gy), Cout, gwt.data_ptr() + 4 * C1 * Cout, Cout, None, rows, code, st)
+            gw = gwt.t().reshape(ctx.wshape)
+        return gx1, gx2, gw, gb, (gy if ctx.has_add else None)
+
+
+def conv1(x1, weight, bias=None, x2=None, add=None):
+    """Per-voxel channel GEMM of [x1 | x2] (+ add); weight is (Cout, Cin[,1,1,1])."""
+    return _Conv1.apply(x1, x2, weight, bias, add)
+
+
+# --------------------------------------------------------------------------- GroupNorm + FiLM + SiLU
+
+
+class _GnFilmSilu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale, shift, res, groups, act, eps):
+        B, X, Y, Z, Cc = _grid(x)
+        V = X * Y * Z
+        x = x.contiguous()
+        res = None if res is None else res.contiguous()
+        dev, code, st = x.device, L.dtype_code(x.dtype), L.stream()
+        gamma, beta = gamma.detach().contiguous(), beta.detach().contiguous()
+        if scale is not None:
+            scale = scale.detach().reshape(B, Cc).float().contiguous()
+            shift = shift.detach().reshape(B, Cc).float().contiguous()
+        stats = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
+        ws = _ws(L.query("tdx_gn_workspace_bytes", B, Cc), dev)
+        L.call("tdx_gn_stats", L.ptr(x), L.ptr(stats), B, V, Cc, groups, float(eps), code, L.ptr(ws), st)
+        y = torch.empty_like(x)
+        L.call("tdx_gn_apply", L.ptr(x), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), L.ptr(res),
+               L.ptr(y), B, V, Cc, groups, int(act), code, st)
+        ctx.save_for_backward(x, stats, gamma, beta, scale, shift)
+        ctx.cfg = (groups, int(act), res is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, stats, gamma, beta, scale, shift = ctx.saved_tensors
+        groups, act, has_res = ctx.cfg
+        B, X, Y, Z, Cc = _grid(x)
+        V = X * Y * Z
+        gy = gy.contiguous()
+        dev, code, st = x.device, L.dtype_code(x.dtype), L.stream()
+        gx = torch.empty_like(x)
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=dev)
+        dscale = dshift = None
+        if scale is not None:
+            dscale = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+            dshift = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+        ws = _ws(L.query("tdx_gn_workspace_bytes", B, Cc), dev)
+        L.call("tdx_gn_bwd", L.ptr(x), L.ptr(gy), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift),
+               L.ptr(gx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dscale), L.ptr(dshift), B, V, Cc, groups, act, code,
+               L.ptr(ws), st)
+        return gx, dgamma, dbeta, dscale, dshift, (gy if has_res else None), None, None, None
+
+
+def gn_film_silu(x, gamma, beta, groups, scale=None, shift=None, res=None, act=True, eps=1e-5):
+    """y = [silu]( GN(x) * (1 + scale) + shift ) + res;  scale/shift are (B, C) or None."""
+    return _GnFilmSilu.apply(x, gamma, beta, scale, shift, res, groups, act, eps)
+
+
+# --------------------------------------------------------------------------- trilinear resize
+
+
+class _Resize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        B, Xi, Yi, Zi, Cc = _grid(x)
+        Xo, Yo, Zo = (int(s) for s in size)
+        x = x.contiguous()
+        y = torch.empty((B, Xo, Yo, Zo, Cc), dtype=x.dtype, device=x.device)
+        L.call("tdx_resize_fwd", L.ptr(x), L.ptr(y), B, Xi, Yi, Zi, Xo, Yo, Zo, Cc, L.dtype_code(x.dtype), L.stream())
+        ctx.geom = (B, Xi, Yi, Zi, Xo, Yo, Zo, Cc)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        B, Xi, Yi, Zi, Xo, Yo, Zo, Cc = ctx.geom
+        gy = gy.contiguous()
+        gx = torch.empty((B, Xi, Yi, Zi, Cc), dtype=gy.dtype, device=gy.device)
+        L.call("tdx_resize_bwd", L.ptr(gy), L.ptr(gx), B, Xi, Yi, Zi, Xo, Yo, Zo, Cc, L.dtype_code(gy.dtype), L.stream())
+        return gx, None
+
+
+def resize(x, size):
+    """Trilinear resample (align_corners=True) of an NDHWC tensor to grid `size`."""
+    return _Resize.apply(x, tuple(size))
+
+
+# --------------------------------------------------------------------------- attention
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        B, N, C3 = qkv.shape
+        D = C3 // (3 * heads)
+        qkv = qkv.contiguous()
+        out = torch.empty((B, N, heads * D), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+        L.call("tdx_attn_fwd", L.ptr(qkv), L.ptr(out), L.ptr(lse), B, N, heads, D, L.dtype_code(qkv.dtype), L.stream())
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        qkv, out, lse = ctx.saved_tensors
+        B, N, C3 = qkv.shape
+        H = ctx.heads
+        D = C3 // (3 * H)
+        gout = gout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        ws = _ws(L.query("tdx_attn_bwd_workspace_bytes", B, N, H, D), qkv.device)
+        L.call("tdx_attn_bwd", L.ptr(qkv), L.ptr(out), L.ptr(lse), L.ptr(gout), L.ptr(dqkv), B, N, H, D,
+               L.dtype_code(qkv.dtype), L.ptr(ws), L.stream())
+        return dqkv, None
+
+
+def attention(qkv, heads):
+    """softmax(q k^T / sqrt(d)) v on a token-major (B, N, 3*heads*d) q|k|v tensor."""
+    return _Attention.apply(qkv, heads)
+
+
+# --------------------------------------------------------------------------- DDPM arithmetic
+
+
+def cell_mask(cell_idx: torch.Tensor, V: int) -> torch.Tensor:
+    """Dense uint8 in-domain mask from the reference's flat cell index list (utils.py:22-28)."""
+    cell_idx = cell_idx.to(torch.int64).contiguous()
+    mask = torch.empty(V, dtype=torch.uint8, device=cell_idx.device)
+    L.call("tdx_cell_mask", L.ptr(cell_idx), cell_idx.numel(), L.ptr(mask), V, L.stream())
+    return mask
+
+
+def q_sample(x0, noise, sqrt_ac, sqrt_1mac, t, mask=None, keep_bcs=False):
+    """sqrt(abar_t) x0 + sqrt(1 - abar_t) noise on (B, F, X, Y, Z) float32 tensors."""
+    B, F = x0.shape[:2]
+    V = x0[0, 0].numel()
+    x0, noise = x0.contiguous(), noise.contiguous()
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty_like(x0)
+    L.call("tdx_q_sample", L.ptr(x0), L.ptr(noise), L.ptr(sqrt_ac), L.ptr(sqrt_1mac), L.ptr(t), 1 if t.numel() > 1 else 0,
+           L.ptr(mask), int(keep_bcs), L.ptr(out), B, F, V, L.stream())
+    return out
+
+
+def p_sample_step(x_t, eps, z, z2, x_bcs, mask, sched, T, t_dev, noise_bcs, clip, out=None):
+    """One fused reverse-diffusion update; t_dev is a device int64 scalar tensor."""
+    B, F = x_t.shape[:2]
+    V = x_t[0, 0].numel()
+    if out is None:
+        out = torch.empty_like(x_t)
+    L.call("tdx_p_sample_step", L.ptr(x_t), L.ptr(eps), L.ptr(z), L.ptr(z2), L.ptr(x_bcs), L.ptr(mask), L.ptr(sched), T,
+           L.ptr(t_dev), int(noise_bcs), int(clip), L.ptr(out), B, F, V, L.stream())
+    return out
+
+
+class _MaskedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eps_hat, noise, mask, n_cells, l1):
+        B, F = eps_hat.shape[:2]
+        V = eps_hat[0, 0].numel()
+        eps_hat, noise = eps_hat.contiguous(), noise.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=eps_hat.device)
+        grad = torch.empty_like(eps_hat) if eps_hat.requires_grad else None
+        ws = _ws(L.query("tdx_masked_loss_workspace_bytes"), eps_hat.device)
+        L.call("tdx_masked_loss", L.ptr(eps_hat), L.ptr(noise), L.ptr(mask), n_cells, int(l1), L.ptr(loss), L.ptr(grad),
+               B, F, V, L.ptr(ws), L.stream())
+        if grad is not None:
+            ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None
+
+
+def masked_loss(eps_hat, noise, mask, n_cells, l1=False):
+    """mean over batch of the mean error over (features, in-domain cells), ddpm.py:845-852."""
+    return _MaskedLoss.apply(eps_hat, noise, mask, int(n_cells), l1)
+
+
+def randn_philox(out: torch.Tensor, seed: int, stream_id: int, offset_dev: torch.Tensor):
+    """Fill `out` (float32) with N(0,1) draws; advances the device-side offset counter."""
+    L.call("tdx_randn", L.ptr(out), out.numel(), seed, stream_id, L.ptr(offset_dev), L.stream())
+    return out

@@ -1,0 +1,183 @@
+/*
+ * tdx.h -- C ABI of the MI355X (gfx950) turbdiff denoising-diffusion hot path.
+ *
+ * The upstream reference (martenlienen/generative-turbulence) has no FFI layer: its hot
+ * path is stock PyTorch ops called from turbdiff/models/ddpm.py.  Each entry point below
+ * replaces the ATen call(s) at the cited reference line; the host-side mirror
+ * (generative-turbulence_amd/turbdiff_amd) binds them with ctypes and INTEGRATION.md shows
+ * the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Activations are NDHWC ("voxel-major"): element (b, x, y, z, c) of a tensor with
+ *     grid (X, Y, Z) and C channels lives at ((((b*X + x)*Y + y)*Z + z)*C + c).  The
+ *     reference's NCDHW tensors (B, C, X, Y, Z) are converted at the model boundary by
+ *     tdx_ncv_to_nvc / tdx_nvc_to_ncv (or fused into encode/decode).
+ *   - dtype: TDX_F32 = 0 (float), TDX_BF16 = 1 (bfloat16 storage, fp32 accumulation).
+ *     Parameters, statistics, gradients of parameters and schedule tables are always f32.
+ *   - Every pointer is a DEVICE pointer.  No entry point allocates, frees or synchronises;
+ *     work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     so a caller may capture any sequence of calls into a hipGraph.
+ *   - Workspaces are caller-provided; sizes come from the *_workspace_bytes queries.
+ *   - Return value: 0 on success, negative TDX_E* on bad arguments, positive hipError_t if
+ *     a launch failed.  No exceptions cross the ABI.
+ */
+#ifndef TDX_H
+#define TDX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDX_F32 0
+#define TDX_BF16 1
+
+#define TDX_OK 0
+#define TDX_EINVAL (-1)   /* bad argument (null pointer, non-positive size)            */
+#define TDX_ESHAPE (-2)   /* shape not supported by this kernel (e.g. C % 8 != 0)       */
+#define TDX_EDTYPE (-3)   /* dtype not supported by this entry point                    */
+
+/* conv3 implementation selector (tdx_conv3_*'s `impl` argument) */
+#define TDX_CONV_AUTO 0    /* MFMA implicit GEMM when dtype/shape allow, else direct     */
+#define TDX_CONV_DIRECT 1  /* vector-ALU reference kernels (any dtype)                    */
+#define TDX_CONV_MFMA 2    /* MFMA implicit GEMM (bf16 only); TDX_ESHAPE if unsupported  */
+
+int tdx_version(void);
+/* name of the gfx target the library was built for ("gfx950") */
+const char* tdx_arch(void);
+
+/* ------------------------------------------------------------------ layout ------------- */
+/* (B, C, V) -> (B, V, C) and back; replaces the implicit NCDHW layout of every op in
+ * ddpm.py.  dtype_in/dtype_out may differ (f32 <-> bf16 cast fused). */
+int tdx_ncv_to_nvc(const void* x, void* y, int B, int C, int64_t V, int dtype_in, int dtype_out, void* stream);
+int tdx_nvc_to_ncv(const void* x, void* y, int B, int C, int64_t V, int dtype_in, int dtype_out, void* stream);
+/* plain cast of n elements */
+int tdx_cast(const void* x, void* y, int64_t n, int dtype_in, int dtype_out, void* stream);
+
+/* ------------------------------------------------------------------ conv 3x3x3 --------- */
+/* nn.Conv3d(k=3, padding=1, padding_mode="replicate"), ddpm.py:164.
+ *
+ * Weight packing: w (Cout, Cin, 3, 3, 3) f32 as stored in the reference's state_dict ->
+ *   wf [27][Cin][Cout]  tap-major forward operand  (tap = (dx+1)*9 + (dy+1)*3 + (dz+1))
+ *   wb [27][Cout][Cin]  flipped + transposed operand of the data-gradient conv
+ * either output may be NULL.  Elements are `dtype`. */
+int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream);
+
+/* y[b,v,:] = bias + sum_tap sum_ci x[b, clamp(v+tap), ci] * wf[tap][ci][:]
+ * The input may be the channel concatenation of two tensors (x1: C1 channels, x2: C2
+ * channels, C2 = 0 and x2 = NULL for a single input) -- replaces torch.cat (ddpm.py:370).
+ * bias may be NULL. */
+int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, const void* wf, const float* bias, void* y,
+                  int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* stream);
+
+/* Data gradient of the above: dx[b,u,:] = sum over (v,tap) with clamp(v+tap) == u of
+ * wf[tap][:, :] dy[b,v,:]  (adjoint of the replicate-padded conv, halo folded back onto
+ * the boundary).  The result has C1 + C2 channels and is split into dx1 / dx2 (dx2 may be
+ * NULL when C2 == 0).  If `accumulate` != 0 the result is added to dx1/dx2 instead of
+ * overwriting.  workspace: tdx_conv3_bwd_data_workspace_bytes(). */
+size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z, int Cin, int dtype, int impl);
+int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2, int accumulate,
+                       int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* workspace, void* stream);
+
+/* Weight + bias gradient.  dw is written in the reference's parameter layout
+ * (Cout, Cin, 3, 3, 3) f32, dbias (Cout) f32 (may be NULL).  Overwrites.
+ * workspace: tdx_conv3_bwd_weight_workspace_bytes(). */
+size_t tdx_conv3_bwd_weight_workspace_bytes(int Cin, int Cout, int impl);
+int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dw, float* dbias,
+                         int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ conv 1x1x1 / linear - */
+/* nn.Conv3d(k=1) (ddpm.py:188,292-293,433,436,459) and nn.Linear seen as a per-row GEMM:
+ *   y[r, :] = bias + x1[r, :] @ w[0:C1, :] + x2[r, :] @ w[C1:C1+C2, :]   (+ add[r, :])
+ * w is [Cin][ldw] f32 row-major with Cout <= ldw (the transposed reference weight).
+ * x2/add/bias may be NULL. */
+int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
+                  const void* add, void* y, int64_t rows, int Cout, int dtype, void* stream);
+/* dw[ci][co] (+)= sum_r x[r, ci] dy[r, co]  (f32, [Cin][ldw]); dbias[co] = sum_r dy[r, co].
+ * Overwrites (buffers are zeroed inside).  x has Cin channels (call twice for a concat). */
+int tdx_conv1_bwd_weight(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
+                         int64_t rows, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ GroupNorm+FiLM+SiLU - */
+/* nn.GroupNorm(G, C, eps) -> [x*(scale+1)+shift] -> [SiLU] (-> [+ residual]),
+ * ddpm.py:165-176, 197, 429, 472.
+ * stats [B][G][2] f32 = (mean, rstd) with biased variance. */
+size_t tdx_gn_workspace_bytes(int B, int C);
+int tdx_gn_stats(const void* x, float* stats, int B, int64_t V, int C, int G, float eps, int dtype, void* workspace,
+                 void* stream);
+/* n = (x-mean)*rstd*gamma + beta; if scale: n = n*(1+scale[b,c]) + shift[b,c];
+ * a = act ? silu(n) : n; y = a + (res ? res : 0).   scale/shift: [B][C] f32 or NULL. */
+int tdx_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, const float* scale,
+                 const float* shift, const void* res, void* y, int B, int64_t V, int C, int G, int act, int dtype,
+                 void* stream);
+/* Backward of tdx_gn_apply w.r.t. x, gamma, beta, scale, shift (the residual's gradient is
+ * dy itself).  dgamma/dbeta [C], dscale/dshift [B][C] (NULL when no FiLM); overwritten.
+ * workspace: tdx_gn_workspace_bytes(). */
+int tdx_gn_bwd(const void* x, const void* dy, const float* stats, const float* gamma, const float* beta,
+               const float* scale, const float* shift, void* dx, float* dgamma, float* dbeta, float* dscale,
+               float* dshift, int B, int64_t V, int C, int G, int act, int dtype, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ trilinear resize --- */
+/* F.interpolate(mode="trilinear", align_corners=True), ddpm.py:359-361, 367-369. */
+int tdx_resize_fwd(const void* x, void* y, int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C, int dtype,
+                   void* stream);
+/* adjoint: dx (input grid) from dy (output grid); overwrites dx */
+int tdx_resize_bwd(const void* dy, void* dx, int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C, int dtype,
+                   void* stream);
+
+/* ------------------------------------------------------------------ attention ---------- */
+/* F.scaled_dot_product_attention on the to_qkv output (attention.py:9-15, ddpm.py:295-308).
+ * qkv [B][N][3*H*D]: channels [0,HD) = q, [HD,2HD) = k, [2HD,3HD) = v, head-major inside
+ * each third.  out [B][N][H*D].  lse [B][H][N] f32 (log-sum-exp of the scaled scores). */
+int tdx_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, int dtype, void* stream);
+int tdx_attn_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, int B, int N, int H,
+                 int D, int dtype, void* workspace, void* stream);
+size_t tdx_attn_bwd_workspace_bytes(int B, int N, int H, int D);
+
+/* ------------------------------------------------------------------ DDPM arithmetic ---- */
+/* All tensors here are the reference's NCDHW (B, F, V) f32 tensors; t is int64 on device:
+ * per-sample (t_stride = 1) or one shared scalar (t_stride = 0).  mask is a dense uint8
+ * [V] with 1 = in-domain cell (the reference's flat `cell_idx` list, utils.py:22-28). */
+
+/* mask[i] = 1 for i in cell_idx, else 0 */
+int tdx_cell_mask(const int64_t* cell_idx, int64_t n_cells, uint8_t* mask, int64_t V, void* stream);
+
+/* q_sample (ddpm.py:818-822): out = sqrt_ac[t] x0 + sqrt_1mac[t] noise; if keep_bcs
+ * (noise_bcs = False, ddpm.py:837-838) cells outside the mask keep x0. */
+int tdx_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, const int64_t* t,
+                 int t_stride, const uint8_t* mask, int keep_bcs, float* out, int B, int F, int64_t V, void* stream);
+
+/* One fused reverse step (ddpm.py:745-752 + 797-811 [+ 814 on the last step]):
+ *   x0h  = recip[t] x_t - recipm1[t] eps;  [!noise_bcs: x0h = x_t outside mask]; [clip +-1]
+ *   mean = coef1[t] x0h + coef2[t] x_t
+ *   t == 0:  out = mean, then out = x_bcs outside the mask
+ *   t  > 0:  out = mean + exp(log_betas[t]/2) z   (z masked to the domain if !noise_bcs)
+ *            noise_bcs: outside the mask out = sqrt_ac[t] x_bcs + sqrt_1mac[t] z2
+ * sched = 7 consecutive f32 tables of length T:
+ *   recip, recipm1, coef1, coef2, log_betas, sqrt_ac, sqrt_1mac.
+ * t is a device int64 scalar (graph replay updates it on device). z, z2 may be NULL when
+ * unused. */
+int tdx_p_sample_step(const float* x_t, const float* eps, const float* z, const float* z2, const float* x_bcs,
+                      const uint8_t* mask, const float* sched, int T, const int64_t* t, int noise_bcs, int clip,
+                      float* out, int B, int F, int64_t V, void* stream);
+
+/* Masked loss (ddpm.py:845-852): loss = mean_b mean_{f, cells} err(eps_hat, noise),
+ * err = squared (l1 = 0) or absolute (l1 = 1) error.  n_cells = number of mask ones.
+ * Writes loss[0] and, if grad != NULL, d loss / d eps_hat (zero outside the mask). */
+int tdx_masked_loss(const float* eps_hat, const float* noise, const uint8_t* mask, int64_t n_cells, int l1,
+                    float* loss, float* grad, int B, int F, int64_t V, void* workspace, void* stream);
+size_t tdx_masked_loss_workspace_bytes(void);
+
+/* Counter-based N(0,1) generator (Philox4x32-10 + Box-Muller), graph-replay safe: the
+ * 64-bit offset is read from device memory and advanced by the kernel itself.
+ * Replaces torch.randn_like (ddpm.py:777,801,810,835) inside captured sampling graphs.
+ * Stream `stream_id` separates trajectories so results do not depend on how trajectories
+ * are sharded over GPUs. */
+int tdx_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t* offset_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDX_H */

@@ -1,0 +1,180 @@
+"""End-to-end parity of the HIP hot path against the golden vectors generated from the
+reference (tests/golden) and, at the full BASELINE size, against the CPU oracle.
+
+Tolerances (rel-L2): fp32 mode 1e-4 on outputs (north_star gate), 1e-3 on gradients;
+bf16 mode (bf16 activation storage + bf16 MFMA operands, fp32 accumulation) 3e-2.
+"""
+
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from conftest import assert_grad_close, rel_l2
+from oracle import turbdiff_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def build_cfg1(golden, noise_bcs=True, dtype=torch.float32, sd=None):
+    from turbdiff_amd.models.ddpm import DenoisingModel, GaussianDiffusion
+
+    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=10, dim=8,
+                         u_net_levels=2, norm_type="group")
+    net.load_state_dict(sd if sd is not None else golden("model_cfg1").sub("sd/"), strict=True)
+    net.set_compute_dtype(dtype)
+    return GaussianDiffusion(net, timesteps=10, beta_schedule="log-snr-linear", loss_type="l2", noise_bcs=noise_bcs).to(dev())
+
+
+def cond(c_local):
+    from turbdiff_amd.models.conditioning import Conditioning
+
+    return {Conditioning.Type.CELL_TYPE: c_local.to(dev())}
+
+
+def test_schedule_buffers_match_golden_on_device(golden):
+    g = golden("schedules")
+    diff = build_cfg1(golden)
+    for k in ["betas", "posterior_log_var", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef2"]:
+        assert torch.equal(getattr(diff, k).cpu(), g[f"log-snr-linear/10/{k}"])
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+def test_denoiser_forward_golden(golden, dtype, tol):
+    g = golden("model_cfg1")
+    diff = build_cfg1(golden, dtype=dtype)
+    with torch.no_grad():
+        y = diff.model(g["x"].to(dev()), g["t"].to(dev()), cond(g["c_local"]))
+    assert y.shape == g["eps_hat"].shape and y.dtype == torch.float32
+    assert rel_l2(y.cpu(), g["eps_hat"]) < tol
+    g2 = golden("model_cfg1_48")
+    with torch.no_grad():
+        y = diff.model(g2["x"].float().to(dev()), g2["t"].to(dev()), cond(g2["c_local"].float()))
+    assert rel_l2(y.cpu(), g2["eps_hat"]) < tol
+
+
+@pytest.mark.parametrize("nb", [1, 0])
+def test_p_losses_and_grads_golden(golden, nb):
+    g = golden("model_cfg1")
+    diff = build_cfg1(golden, noise_bcs=bool(nb))
+    loss, t = diff.p_losses(g["x"].to(dev()), g["t"].to(dev()), cond(g["c_local"]),
+                            SimpleNamespace(cell_idx=g["cell_idx"].to(dev())), None, noise=g[f"loss_nb{nb}/noise"].to(dev()))
+    loss.backward()
+    ref = g[f"loss_nb{nb}/loss"].item()
+    assert abs(loss.item() - ref) < 1e-4 * abs(ref)
+    n = 0
+    for name, p in diff.model.named_parameters():
+        assert p.grad is not None, name
+        assert_grad_close(name, p.grad.cpu(), g[f"loss_nb{nb}/grad/{name}"], 1e-3)
+        n += 1
+    assert n == len(g.keys(f"loss_nb{nb}/grad/"))
+
+
+def test_p_losses_bf16_close(golden):
+    g = golden("model_cfg1")
+    diff = build_cfg1(golden, dtype=torch.bfloat16)
+    loss, _ = diff.p_losses(g["x"].to(dev()), g["t"].to(dev()), cond(g["c_local"]),
+                            SimpleNamespace(cell_idx=g["cell_idx"].to(dev())), None, noise=g["loss_nb1/noise"].to(dev()))
+    loss.backward()
+    ref = g["loss_nb1/loss"].item()
+    assert abs(loss.item() - ref) < 2e-2 * abs(ref)
+    w = "u_net.downsampling_blocks.1.block2.conv.weight"
+    p = dict(diff.model.named_parameters())[w]
+    assert rel_l2(p.grad.cpu(), g[f"loss_nb1/grad/{w}"]) < 0.1
+
+
+@pytest.mark.parametrize("tag,nb,start", [("nb1", True, None), ("nb0", False, None), ("nb1_from5", True, 5)])
+def test_p_sample_loop_golden(golden, tag, nb, start):
+    g = golden("sample_cfg1")
+    diff = build_cfg1(golden, noise_bcs=nb)
+    noises = [g[f"{tag}/noise/{i}"].to(dev()) for i in range(int(g[f"{tag}/n_noise"]))]
+    it = iter(noises)
+    out = diff.p_sample_loop(g["x_bcs"].to(dev()), cond(g["c_local"]), g["cell_idx"].to(dev()), start_from=start,
+                             noise_fn=lambda like: next(it))
+    assert next(it, None) is None, "sampler drew fewer noise tensors than the reference"
+    assert rel_l2(out.cpu(), g[f"{tag}/out"]) < 1e-4
+    # boundary / outside cells are clamped to the data values at the end (ddpm.py:814)
+    inside = torch.zeros(out[0, 0].numel(), dtype=torch.bool)
+    inside[g["cell_idx"]] = True
+    assert torch.equal(out.cpu().flatten(-3)[..., ~inside], g["x_bcs"].flatten(-3)[..., ~inside])
+
+
+def test_p_sample_mean_logvar_golden(golden):
+    g = golden("sample_cfg1")
+    diff = build_cfg1(golden)
+    mean, log_var = diff.p_sample(g["x_bcs"].to(dev()), 6, cond(g["c_local"]), g["cell_idx"].to(dev()))
+    assert rel_l2(mean.cpu(), g["p_sample_t6/mean"]) < 1e-4
+    assert torch.equal(log_var.cpu(), g["p_sample_t6/log_var"])
+
+
+def test_three_training_steps_golden(golden):
+    """clip 0.1 -> RAdam(1e-4) -> exp LambdaLR, as DiffusionTraining.configure_optimizers
+    (diffusion.py:210-235) with trainer.gradient_clip_val = 0.1 (train.yaml:30-31)."""
+    import math
+
+    g = golden("train_cfg1")
+    diff = build_cfg1(golden)
+    opt = torch.optim.RAdam(diff.parameters(), lr=1e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: math.exp(math.log(1e-6 / 1e-4) / 20 * min(s, 20)))
+    x, C, md = g["x"].to(dev()), cond(g["c_local"]), SimpleNamespace(cell_idx=g["cell_idx"].to(dev()))
+    for step in range(3):
+        loss, _ = diff.p_losses(x, g[f"step{step}/t"].to(dev()), C, md, None, noise=g[f"step{step}/noise"].to(dev()))
+        opt.zero_grad()
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(diff.parameters(), 0.1)
+        opt.step()
+        sched.step()
+        assert abs(loss.item() - g[f"step{step}/loss"].item()) < 2e-4 * abs(g[f"step{step}/loss"].item())
+        assert abs(gn.item() - g[f"step{step}/grad_norm"].item()) < 2e-3 * g[f"step{step}/grad_norm"].item()
+        assert abs(sched.get_last_lr()[0] - g[f"step{step}/lr_after"].item()) < 1e-12
+    for k, v in diff.model.state_dict().items():
+        assert rel_l2(v.cpu(), g[f"final_sd/{k}"]) < 1e-5, k
+
+
+def test_full_size_forward_matches_oracle_fp32():
+    """BASELINE config 2 geometry (192x64x48, dim 32, 4 levels, GN(8)), B = 1, fp32 mode,
+    default-initialised weights (seed 0) vs the CPU oracle: the 1e-4 rel-L2 gate."""
+    from turbdiff_amd.models.ddpm import DenoisingModel
+
+    torch.manual_seed(0)
+    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=500, dim=32,
+                         u_net_levels=4, norm_type="group")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    g1, g2 = torch.Generator().manual_seed(1234), torch.Generator().manual_seed(1235)
+    x = torch.randn(1, 4, 192, 64, 48, generator=g1)
+    c_local = torch.randn(4, 192, 64, 48, generator=g2)
+    t = torch.tensor([123])
+    with torch.no_grad():
+        ref = O.denoiser(sd, x, t, c_local, timesteps=500)
+        net.to(dev())
+        y = net(x.to(dev()), t.to(dev()), cond(c_local))
+    assert rel_l2(y.cpu(), ref) < 1e-4
+    net.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        yb = net(x.to(dev()), t.to(dev()), cond(c_local))
+    assert rel_l2(yb.cpu(), ref) < 3e-2
+
+
+def test_sampling_is_linear_in_boundary_values_property():
+    """size-independent property at the full grid: with eps_theta == 0 the fused reverse
+    step is affine in (x_t, z); checked on the 192x64x48 grid through the C ABI."""
+    from turbdiff_amd import ops, schedules
+
+    d = dev()
+    T = 500
+    sched = schedules.pack_step_tables(schedules.diffusion_tables("log-snr-linear", T)).to(d)
+    shape = (2, 4, 192, 64, 48)
+    V = 192 * 64 * 48
+    g = torch.Generator(device=d).manual_seed(0)
+    a, b, z, xb = (torch.randn(shape, device=d, generator=g) for _ in range(4))
+    zero = torch.zeros(shape, device=d)
+    mask = torch.ones(V, dtype=torch.uint8, device=d)
+    tt = torch.tensor([250], device=d)
+    step = lambda x, zz: ops.p_sample_step(x, zero, zz, zero, xb, mask, sched, T, tt, True, False)
+    lhs = step(a + b, z)
+    rhs = step(a, z) + step(b, zero)
+    assert rel_l2(lhs, rhs) < 1e-6

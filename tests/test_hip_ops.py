@@ -1,0 +1,346 @@
+"""Per-operator parity of the HIP kernels (through the C ABI) against the CPU oracle.
+
+fp32 kernels must match to ~1e-5 rel-L2 (different summation order only); bf16 kernels are
+compared with the oracle evaluated on the same bf16-rounded inputs, so the remaining error
+is the bf16 rounding of the output (2^-9 relative per element, ~2e-3 rel-L2) plus fp32
+accumulation order.
+"""
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import turbdiff_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 2e-5
+BF16_TOL = 6e-3
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def nvc(x):  # (B,C,X,Y,Z) -> (B,X,Y,Z,C)
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def ncv(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(x, dtype):
+    """round to the compute dtype and back (what the kernel sees)"""
+    return x.to(dtype).float()
+
+
+def tol_for(dtype):
+    return F32_TOL if dtype == torch.float32 else BF16_TOL
+
+
+@pytest.fixture(autouse=True)
+def _conv_impl_env(monkeypatch):
+    monkeypatch.delenv("TDX_CONV_IMPL", raising=False)
+
+
+def test_library_loads_on_gpu_box():
+    from turbdiff_amd import _lib
+
+    lib = _lib.load()
+    assert lib.tdx_version() >= 1 and lib.tdx_arch() == b"gfx950"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layout_roundtrip(dtype):
+    from turbdiff_amd import ops
+
+    x = rnd(2, 5, 7, 3, 9).to(dev())
+    y = ops.to_nvc(x, dtype)
+    assert y.shape == (2, 7, 3, 9, 5)
+    assert torch.equal(y.float().cpu(), nvc(q(x.cpu(), dtype)))
+    back = ops.to_ncv(y, torch.float32)
+    assert torch.equal(back.cpu(), q(x.cpu(), dtype))
+
+
+CONV_CASES = [
+    # B, Cin1, Cin2, Cout, X, Y, Z
+    (2, 8, 0, 16, 7, 5, 6),
+    (1, 32, 0, 32, 9, 8, 8),
+    (2, 64, 0, 64, 5, 9, 11),
+    (1, 32, 32, 64, 6, 10, 7),
+    (1, 128, 0, 32, 4, 8, 8),
+    (1, 16, 0, 96, 3, 3, 3),
+    (1, 64, 0, 64, 12, 4, 3),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("mode", ["f32-direct", "bf16-direct", "bf16-auto"])
+def test_conv3_fwd_bwd(case, mode, monkeypatch):
+    from turbdiff_amd import ops
+
+    B, C1, C2, Cout, X, Y, Z = case
+    dtype = torch.float32 if mode.startswith("f32") else torch.bfloat16
+    monkeypatch.setenv("TDX_CONV_IMPL", "direct" if mode.endswith("direct") else "auto")
+    Cin = C1 + C2
+    x = q(rnd(B, Cin, X, Y, Z, seed=1), dtype)
+    w = q(rnd(Cout, Cin, 3, 3, 3, seed=2, scale=1 / math.sqrt(27 * Cin)), dtype)
+    b = rnd(Cout, seed=3)
+    gy = q(rnd(B, Cout, X, Y, Z, seed=4), dtype)
+    # oracle (CPU, fp64 accumulate for a clean reference)
+    xr, wr, br = x.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    yr = O.conv3_replicate(xr, wr, br)
+    yr.backward(gy.double())
+
+    xd = nvc(x).to(dev()).to(dtype)
+    x1 = xd[..., :C1].contiguous().requires_grad_()
+    x2 = xd[..., C1:].contiguous().requires_grad_() if C2 else None
+    wd = w.to(dev()).requires_grad_()
+    bd = b.to(dev()).requires_grad_()
+    y = ops.conv3(x1, wd, bd, x2=x2)
+    y.backward(nvc(gy).to(dev()).to(dtype))
+    tol = tol_for(dtype)
+    assert rel_l2(ncv(y.float().cpu()), yr) < tol
+    gx = torch.cat([x1.grad] + ([x2.grad] if C2 else []), dim=-1)
+    assert rel_l2(ncv(gx.float().cpu()), xr.grad) < tol
+    assert rel_l2(wd.grad.cpu(), wr.grad) < (1e-4 if dtype == torch.float32 else tol)
+    assert rel_l2(bd.grad.cpu(), br.grad) < (1e-4 if dtype == torch.float32 else tol)
+
+
+def test_conv3_mfma_matches_direct_bf16(monkeypatch):
+    """same bf16 inputs through both implementations: only accumulation order differs"""
+    from turbdiff_amd import ops
+
+    x = rnd(2, 9, 17, 10, 64, seed=5).to(dev()).bfloat16()
+    w = rnd(64, 64, 3, 3, 3, seed=6, scale=0.03).to(dev())
+    outs = {}
+    for impl in ("direct", "mfma"):
+        monkeypatch.setenv("TDX_CONV_IMPL", impl)
+        xi = x.clone().requires_grad_()
+        y = ops.conv3(xi, w, None)
+        y.backward(torch.ones_like(y))
+        outs[impl] = (y.float(), xi.grad.float())
+    assert rel_l2(outs["mfma"][0], outs["direct"][0]) < 3e-3
+    assert rel_l2(outs["mfma"][1], outs["direct"][1]) < 3e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 4, 0, 32, 100), (1, 64, 64, 32, 333), (3, 128, 0, 384, 70), (2, 32, 0, 4, 257)])
+def test_conv1_fwd_bwd(dtype, case):
+    from turbdiff_amd import ops
+
+    B, C1, C2, Cout, V = case
+    Cin = C1 + C2
+    x = q(rnd(B, V, Cin, seed=1), dtype)
+    w = rnd(Cout, Cin, 1, 1, 1, seed=2, scale=1 / math.sqrt(Cin))
+    b = rnd(Cout, seed=3)
+    add = q(rnd(B, V, Cout, seed=4), dtype)
+    gy = q(rnd(B, V, Cout, seed=5), dtype)
+    xr, wr, br, ar = (t.double().requires_grad_() for t in (x, w, b, add))
+    yr = xr @ wr.reshape(Cout, Cin).t() + br + ar
+    yr.backward(gy.double())
+
+    xd = x.to(dev()).to(dtype).reshape(B, V, 1, 1, Cin)
+    x1 = xd[..., :C1].contiguous().requires_grad_()
+    x2 = xd[..., C1:].contiguous().requires_grad_() if C2 else None
+    wd, bd = w.to(dev()).requires_grad_(), b.to(dev()).requires_grad_()
+    ad = add.to(dev()).to(dtype).reshape(B, V, 1, 1, Cout).requires_grad_()
+    y = ops.conv1(x1, wd, bd, x2=x2, add=ad)
+    y.backward(gy.to(dev()).to(dtype).reshape(B, V, 1, 1, Cout))
+    tol = tol_for(dtype)
+    assert rel_l2(y.float().cpu().reshape(B, V, Cout), yr) < tol
+    gx = torch.cat([x1.grad] + ([x2.grad] if C2 else []), dim=-1).reshape(B, V, Cin)
+    assert rel_l2(gx.float().cpu(), xr.grad) < tol
+    assert rel_l2(wd.grad.cpu(), wr.grad) < (1e-4 if dtype == torch.float32 else tol)
+    assert rel_l2(bd.grad.cpu(), br.grad) < (1e-4 if dtype == torch.float32 else tol)
+    assert rel_l2(ad.grad.float().cpu().reshape(B, V, Cout), ar.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(2, 16, 8, 7, 5, 6, True, True), (1, 64, 8, 9, 4, 3, False, True), (2, 32, 32, 5, 5, 5, True, False),
+                                  (1, 512, 8, 12, 4, 3, True, True), (2, 24, 1, 6, 5, 4, False, False)])
+def test_gn_film_silu(dtype, case):
+    from turbdiff_amd import ops
+
+    B, Cc, G, X, Y, Z, film, res = case
+    x = q(rnd(B, Cc, X, Y, Z, seed=1) * 1.5 + 0.3, dtype)
+    gamma, beta = 1 + 0.3 * rnd(Cc, seed=2), 0.2 * rnd(Cc, seed=3)
+    scale, shift = 0.5 * rnd(B, Cc, seed=4), 0.5 * rnd(B, Cc, seed=5)
+    r = q(rnd(B, Cc, X, Y, Z, seed=6), dtype)
+    gy = q(rnd(B, Cc, X, Y, Z, seed=7), dtype)
+    leaves = [t.double().requires_grad_() for t in (x, gamma, beta, scale, shift, r)]
+    xr, gr, br, sr, hr, rr = leaves
+    n = O.group_norm(xr, G, gr, br)
+    if film:
+        n = hr[..., None, None, None] + (sr[..., None, None, None] + 1) * n
+    yr = F.silu(n) + (rr if res else 0)
+    yr.backward(gy.double())
+
+    d = dev()
+    xd = nvc(x).to(d).to(dtype).requires_grad_()
+    gd, bd = gamma.to(d).requires_grad_(), beta.to(d).requires_grad_()
+    sd_, hd = scale.to(d).requires_grad_(), shift.to(d).requires_grad_()
+    rd = nvc(r).to(d).to(dtype).requires_grad_()
+    y = ops.gn_film_silu(xd, gd, bd, G, sd_ if film else None, hd if film else None, res=rd if res else None)
+    y.backward(nvc(gy).to(d).to(dtype))
+    tol = tol_for(dtype)
+    assert rel_l2(ncv(y.float().cpu()), yr) < tol
+    assert rel_l2(ncv(xd.grad.float().cpu()), xr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    ptol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel_l2(gd.grad.cpu(), gr.grad) < ptol
+    assert rel_l2(bd.grad.cpu(), br.grad) < ptol
+    if film:
+        assert rel_l2(sd_.grad.cpu(), sr.grad) < ptol
+        assert rel_l2(hd.grad.cpu(), hr.grad) < ptol
+    if res:
+        assert rel_l2(ncv(rd.grad.float().cpu()), rr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("sizes", [((13, 7, 6), (6, 3, 3)), ((6, 3, 3), (13, 7, 6)), ((12, 8, 9), (6, 4, 4)),
+                                   ((6, 4, 4), (12, 8, 9)), ((3, 3, 3), (3, 3, 3)), ((5, 4, 3), (3, 3, 3)), ((3, 3, 3), (5, 4, 3))])
+def test_resize(dtype, sizes):
+    from turbdiff_amd import ops
+
+    si, so = sizes
+    x = q(rnd(2, 16, *si, seed=1), dtype)
+    gy = q(rnd(2, 16, *so, seed=2), dtype)
+    xr = x.double().requires_grad_()
+    yr = O.resize(xr, so)
+    yr.backward(gy.double())
+    xd = nvc(x).to(dev()).to(dtype).requires_grad_()
+    y = ops.resize(xd, so)
+    y.backward(nvc(gy).to(dev()).to(dtype))
+    tol = tol_for(dtype)
+    assert rel_l2(ncv(y.float().cpu()), yr) < tol
+    assert rel_l2(ncv(xd.grad.float().cpu()), xr.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N", [37, 144, 200])
+def test_attention(dtype, N):
+    from turbdiff_amd import ops
+
+    B, H, D = 2, 4, 32
+    qkv = q(rnd(B, N, 3 * H * D, seed=1), dtype)
+    go = q(rnd(B, N, H * D, seed=2), dtype)
+    ref = qkv.double().requires_grad_()
+    qq, kk, vv = (p.reshape(B, N, H, D).transpose(1, 2) for p in ref.chunk(3, dim=-1))
+    o = O.sdpa(qq, kk, vv).transpose(1, 2).reshape(B, N, H * D)
+    o.backward(go.double())
+    qd = qkv.to(dev()).to(dtype).requires_grad_()
+    out = ops.attention(qd, H)
+    out.backward(go.to(dev()).to(dtype))
+    tol = 1e-5 if dtype == torch.float32 else 8e-3
+    assert rel_l2(out.float().cpu(), o) < tol
+    assert rel_l2(qd.grad.float().cpu(), ref.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+def test_fused_attention_api(golden):
+    from turbdiff_amd.models.attention import fused_attention
+
+    g = golden("ops")
+    o = fused_attention(*(g[f"sdpa/{n}"].to(dev()) for n in "qkv"))
+    assert rel_l2(o.cpu(), g["sdpa/o"]) < 1e-5
+
+
+# ------------------------------------------------------------------ DDPM arithmetic
+
+
+def _mask_idx(V, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.sort(torch.randperm(V, generator=g)[: (2 * V) // 3]).values
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 5, 4, 3), (3, 4, 8, 8, 4)])
+@pytest.mark.parametrize("keep_bcs", [False, True])
+def test_q_sample(shape, keep_bcs):
+    from turbdiff_amd import ops
+
+    buf = O.schedule_buffers("log-snr-linear", 10)
+    x0, nz = rnd(*shape, seed=1), rnd(*shape, seed=2)
+    V = x0[0, 0].numel()
+    idx = _mask_idx(V)
+    t = torch.tensor([3, 9, 0][: shape[0]])
+    ref = O.q_sample(buf, x0, t, nz)
+    if keep_bcs:
+        ref = O.where_cells(idx, ref, x0)
+    d = dev()
+    mask = ops.cell_mask(idx.to(d), V)
+    assert mask.sum().item() == idx.numel()
+    out = ops.q_sample(x0.to(d), nz.to(d), buf["sqrt_alphas_cumprod"].to(d), buf["sqrt_one_minus_alphas_cumprod"].to(d),
+                       t.to(d), mask=mask, keep_bcs=keep_bcs)
+    assert torch.allclose(out.cpu(), ref, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("noise_bcs", [True, False])
+@pytest.mark.parametrize("t", [0, 1, 7])
+def test_p_sample_step(noise_bcs, t):
+    from turbdiff_amd import ops, schedules
+
+    T = 10
+    buf = O.schedule_buffers("log-snr-linear", T)
+    shape = (2, 4, 6, 5, 4)
+    x_t, eps, z, z2, xb = (rnd(*shape, seed=s) for s in range(5))
+    V = 120
+    idx = _mask_idx(V)
+    tt = torch.full((2,), t)
+    _, mean = O.model_mean(buf, x_t, tt, eps, idx, noise_bcs)
+    if t == 0:
+        ref = O.where_cells(idx, mean, xb)
+    else:
+        zz = z if noise_bcs else O.where_cells(idx, z)
+        ref = mean + (buf["log_betas"][t] / 2).exp() * zz
+        if noise_bcs:
+            ref = O.where_cells(idx, ref, O.q_sample(buf, xb, tt, z2))
+    d = dev()
+    sched = schedules.pack_step_tables(schedules.diffusion_tables("log-snr-linear", T)).to(d)
+    mask = ops.cell_mask(idx.to(d), V)
+    out = ops.p_sample_step(x_t.to(d), eps.to(d), z.to(d), z2.to(d), xb.to(d), mask, sched, T,
+                            torch.tensor([t], device=d), noise_bcs, False)
+    assert torch.allclose(out.cpu(), ref, rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("l1", [False, True])
+def test_masked_loss(l1):
+    from turbdiff_amd import ops
+
+    shape = (3, 4, 7, 6, 5)
+    e, n = rnd(*shape, seed=1), rnd(*shape, seed=2)
+    V = 210
+    idx = _mask_idx(V)
+    er = e.clone().requires_grad_()
+    err = (er - n).abs() if l1 else (er - n) ** 2
+    ref = err.flatten(-3)[..., idx].flatten(1).mean(1).mean()
+    ref.backward()
+    d = dev()
+    ed = e.to(d).requires_grad_()
+    loss = ops.masked_loss(ed, n.to(d), ops.cell_mask(idx.to(d), V), idx.numel(), l1=l1)
+    (loss * 2).backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 * abs(ref.item())
+    assert rel_l2(ed.grad.cpu(), 2 * er.grad) < 1e-6
+
+
+def test_philox_randn_moments_and_replay():
+    from turbdiff_amd import ops
+
+    d = dev()
+    off = torch.zeros(1, dtype=torch.int64, device=d)
+    a = ops.randn_philox(torch.empty(1 << 20, device=d), 1234, 7, off)
+    assert off.item() == (1 << 18)
+    assert abs(a.mean().item()) < 5e-3 and abs(a.std().item() - 1) < 5e-3
+    assert abs((a**4).mean().item() - 3) < 0.05
+    off.zero_()
+    b = ops.randn_philox(torch.empty(1 << 20, device=d), 1234, 7, off)
+    assert torch.equal(a, b)  # same (seed, stream, offset) -> same numbers
+    c = ops.randn_philox(torch.empty(1 << 20, device=d), 1234, 8, torch.zeros(1, dtype=torch.int64, device=d))
+    assert abs((a * c).mean().item()) < 5e-3  # other trajectory stream: independent
