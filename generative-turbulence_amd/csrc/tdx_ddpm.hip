@@ -284,6 +284,44 @@ __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int
 }
 __global__ void advance_offset(uint64_t* offp, uint64_t by) { *offp += by; }
 
+__global__ void __launch_bounds__(256) randn_batched_kernel(float* __restrict__ out, int64_t n, uint64_t seed,
+                                                            const uint64_t* __restrict__ sids,
+                                                            const uint64_t* __restrict__ offp) {
+    const uint64_t off = *offp;
+    const uint64_t sid = sids[blockIdx.y];
+    float* o = out + (int64_t)blockIdx.y * n;
+    const int64_t n4 = (n + 3) >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        uint64_t ctr = off + (uint64_t)i;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float u1 = ((float)c[2 * k] + 1.0f) * 2.3283064365386963e-10f;
+            float u2 = (float)c[2 * k + 1] * 2.3283064365386963e-10f;
+            float rad = sqrtf(-2.0f * __logf(u1));
+            float sn, cs;
+            __sincosf(6.283185307179586f * u2, &sn, &cs);
+            r[2 * k] = rad * cs; r[2 * k + 1] = rad * sn;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * i + k < n) o[4 * i + k] = r[k];
+    }
+}
+
+extern "C" int tdx_randn_batched(float* out, int B, int64_t n, uint64_t seed, const uint64_t* stream_ids,
+                                 uint64_t* offset_dev, void* stream) {
+    TDX_CHECK_ARG(out && stream_ids && offset_dev && n > 0 && B > 0);
+    const int64_t n4 = (n + 3) >> 2;
+    dim3 grid((unsigned)min((int64_t)512, (n4 + 255) / 256), B);
+    hipLaunchKernelGGL(randn_batched_kernel, grid, dim3(256), 0, as_stream(stream), out, n, seed, stream_ids, offset_dev);
+    hipLaunchKernelGGL(advance_offset, dim3(1), dim3(1), 0, as_stream(stream), offset_dev, (uint64_t)n4);
+    return tdx_launch_status();
+}
+
 extern "C" int tdx_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t* offset_dev, void* stream) {
     TDX_CHECK_ARG(out && offset_dev && n > 0);
     const int64_t n4 = (n + 3) >> 2;

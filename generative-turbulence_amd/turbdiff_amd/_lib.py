@@ -51,6 +51,7 @@ SIGNATURES = {
     "tdx_masked_loss": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i64, _vp, _vp]),
     "tdx_masked_loss_workspace_bytes": (_sz, []),
     "tdx_randn": (_i, [_vp, _i64, _u64, _u64, _vp, _vp]),
+    "tdx_randn_batched": (_i, [_vp, _i, _i64, _u64, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -103,8 +104,39 @@ def stream():
 _ERR = {-1: "TDX_EINVAL (bad argument)", -2: "TDX_ESHAPE (unsupported shape)", -3: "TDX_EDTYPE (unsupported dtype)"}
 
 
-def call(name: str, *args):
-    rc = getattr(load(), name)(*args)
+class KernelTimer:
+    """HIP-event timing of selected entry points on the stream they are launched on
+    (bench.py's roofline leg).  `work` is an optional per-call amount (flops or bytes)."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []  # (name, start_event, end_event, work)
+        self.pending_work = 0.0
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, work in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["work"] += work
+        return out
+
+
+TIMER: KernelTimer | None = None
+
+
+def call(name: str, *args, work: float = 0.0):
+    t = TIMER
+    if t is not None and name in t.names:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(load(), name)(*args)
+        e.record()
+        t.records.append((name, s, e, work))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {_ERR.get(rc, f'hipError {rc}')}")
 

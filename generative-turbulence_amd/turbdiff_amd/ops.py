@@ -124,7 +124,7 @@ class _Conv3(torch.autograd.Function):
         wf, wb = _packed_conv3(weight, dt)
         y = torch.empty((B, X, Y, Z, Cout), dtype=dt, device=x1.device)
         L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Cout,
-               L.dtype_code(dt), L.conv_impl(), L.stream())
+               L.dtype_code(dt), L.conv_impl(), L.stream(), work=54.0 * (C1 + C2) * Cout * B * X * Y * Z)
         ctx.save_for_backward(x1, x2, wb)
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
@@ -146,13 +146,13 @@ class _Conv3(torch.autograd.Function):
             gx2 = None if x2 is None else torch.empty_like(x2)
             ws = _ws(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, Cin, code, impl), dev)
             L.call("tdx_conv3_bwd_data", L.ptr(gy), L.ptr(wb), L.ptr(gx1), C1, L.ptr(gx2), C2, 0, B, X, Y, Z, Cout,
-                   code, impl, L.ptr(ws), st)
+                   code, impl, L.ptr(ws), st, work=54.0 * Cin * Cout * B * X * Y * Z)
         if ctx.needs_input_grad[2]:
             gw = torch.empty(ctx.wshape, dtype=torch.float32, device=dev)
             gb = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
             ws = _ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cin, Cout, impl), dev)
             L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z,
-                   Cout, code, impl, L.ptr(ws), st)
+                   Cout, code, impl, L.ptr(ws), st, work=54.0 * Cin * Cout * B * X * Y * Z)
         return gx1, gx2, gw, gb
 
 
@@ -400,4 +400,12 @@ def masked_loss(eps_hat, noise, mask, n_cells, l1=False):
 def randn_philox(out: torch.Tensor, seed: int, stream_id: int, offset_dev: torch.Tensor):
     """Fill `out` (float32) with N(0,1) draws; advances the device-side offset counter."""
     L.call("tdx_randn", L.ptr(out), out.numel(), seed, stream_id, L.ptr(offset_dev), L.stream())
+    return out
+
+
+def randn_philox_batched(out: torch.Tensor, seed: int, stream_ids: torch.Tensor, offset_dev: torch.Tensor):
+    """Row b of `out` (B, ...) gets trajectory stream `stream_ids[b]` (int64 device tensor);
+    all rows share the offset counter, advanced once.  Graph-capturable."""
+    B = out.shape[0]
+    L.call("tdx_randn_batched", L.ptr(out), B, out[0].numel(), seed, L.ptr(stream_ids), L.ptr(offset_dev), L.stream())
     return out

@@ -176,6 +176,10 @@ size_t tdx_masked_loss_workspace_bytes(void);
  * Stream `stream_id` separates trajectories so results do not depend on how trajectories
  * are sharded over GPUs. */
 int tdx_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t* offset_dev, void* stream);
+/* Batched form: out is [B][n]; row b uses Philox stream stream_ids[b] (device array of B
+ * uint64 trajectory ids) and every row the same offset, which is then advanced once. */
+int tdx_randn_batched(float* out, int B, int64_t n, uint64_t seed, const uint64_t* stream_ids, uint64_t* offset_dev,
+                      void* stream);
 
 #ifdef __cplusplus
 }
