@@ -6,6 +6,19 @@
 // counts (4-174 FLOP/B); the MFMA variant lives in tdx_conv3_mfma.hip (taps = 1).
 #include "tdx_common.h"
 
+#include <stdlib.h>
+// MFMA versions (tdx_conv1_mfma.hip); TDX_CONV1_IMPL=direct forces the vector-ALU kernels
+bool conv1_mfma_supported(int C1, int C2, int Cout);
+int conv1_mfma_fwd_launch(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
+                          const void* add, void* y, int64_t rows, int Cout, hipStream_t st);
+bool conv1_wgrad_mfma_supported(int Cin, int Cout);
+int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
+                            int64_t rows, hipStream_t st);
+static bool conv1_force_direct() {
+    const char* e = getenv("TDX_CONV1_IMPL");
+    return e && e[0] == 'd';
+}
+
 #define C1_BM 64
 #define C1_BN 64
 #define C1_BK 32
@@ -84,6 +97,8 @@ extern "C" int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, con
                              void* stream) {
     TDX_CHECK_ARG(x1 && w && y && rows > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && ldw >= Cout);
     TDX_CHECK_ARG(C2 == 0 || x2);
+    if (dtype == TDX_BF16 && !conv1_force_direct() && conv1_mfma_supported(C1, C2, Cout))
+        return conv1_mfma_fwd_launch(x1, C1, x2, C2, w, ldw, bias, add, y, rows, Cout, as_stream(stream));
     dim3 grid(ceil_div(rows, C1_BM), ceil_div(Cout, C1_BN));
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_fwd_kernel<T>), grid, dim3(256), 0, as_stream(stream),
                                                   (const T*)x1, C1, (const T*)x2, C2, w, ldw, bias, (const T*)add,
@@ -164,6 +179,8 @@ extern "C" int tdx_conv1_bwd_weight(const void* x, int Cin, const void* dy, int 
         e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
+    if (dtype == TDX_BF16 && !conv1_force_direct() && conv1_wgrad_mfma_supported(Cin, Cout))
+        return conv1_wgrad_mfma_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, st);
     dim3 grid(ceil_div(rows, C1W_ROWS), ceil_div(Cin, C1_BM), ceil_div(Cout, C1_BN));
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_wgrad_kernel<T>), grid, dim3(256), 0, st, (const T*)x, Cin,
                                                   (const T*)dy, Cout, dw, ldw, dbias, rows));

@@ -1,0 +1,324 @@
+// bf16 MFMA 1x1x1 convolution (per-voxel channel GEMM) and its weight gradient for gfx950.
+//
+// These layers are HBM-bound (4-174 FLOP/B): the job of the kernels is to stream the
+// activation once in full 128-B lines, keep many loads in flight (small LDS footprint ->
+// 4 workgroups per CU) and never let the arithmetic show, which at 1x1-conv sizes takes the
+// matrix cores (the vector-ALU version ran at ~1/10 of the HBM rate).
+//
+// forward:  y[r, n] = bias[n] + sum_k [x1|x2][r, k] w[k, n] (+ add[r, n])
+//   workgroup = 256 rows x BN = 32*NT columns; K walked in 32-channel slices.  The x slice
+//   ([256][32] bf16, 64-B rows) and the weight slice (f32 [k][n] in memory, converted and
+//   transposed to [n][32] bf16 while staging) go through LDS; 16-B chunks are XOR-swizzled
+//   with (row >> 2) & 3 so that ds_read_b128 fragment reads are conflict-free.  The MFMA is
+//   issued as D^T = W^T X^T (weights as the A operand): each lane then owns one voxel row
+//   and 4 consecutive channels per accumulator quad, which packs to 8-B LDS writes of an
+//   output tile that is finally stored with 16-B coalesced rows (+ bias, + residual).
+//
+// weight gradient:  dw[ci, co] = sum_r x[r, ci] dy[r, co]   (TN GEMM over rows)
+//   both operands are row(K)-major, so fragments are transposed LDS reads
+//   (ds_read_b64_tr_b16) from [256][32]-channel planes (64-B rows: conflict-free).  Each wave
+//   reduces its own 64 rows of every 256-row chunk into a private (32*MT) x (32*NT) tile;
+//   tiles are merged with f32 atomics.
+#include "tdx_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+#define C1M_ROWS 256
+#define C1M_KC 32
+
+bool conv1_mfma_supported(int C1, int C2, int Cout) {
+    return C1 > 0 && (C1 % C1M_KC) == 0 && (C2 % C1M_KC) == 0 && (Cout % 32) == 0;
+}
+
+// 64-B rows, 4 chunks of 16 B; chunk c of row r lives at chunk position c ^ ((r >> 2) & 3)
+__device__ __forceinline__ int sw64(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
+// 128-B rows (64 bf16), 8 chunks; chunk c of row r at c ^ (r & 7)
+__device__ __forceinline__ int sw128(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
+                      const float* __restrict__ w, int ldw, const float* __restrict__ bias,
+                      const bf16* __restrict__ add, bf16* __restrict__ y, int64_t rows, int Cout) {
+    constexpr int BN = 32 * NT;
+    // LDS: staging (x slice 16 KB + w slice BN*64 B) and the output tile [256][64] bf16 (32 KB)
+    // share one region
+    __shared__ __attribute__((aligned(16))) unsigned char smem[32768];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + C1M_ROWS * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * C1M_ROWS;
+    const int n0 = blockIdx.y * BN;
+    const int Cin = C1 + C2;
+
+    f32x16 acc[NT][2];  // [n tile][m tile]: D[row = channel][col = voxel]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
+
+    for (int k0 = 0; k0 < Cin; k0 += C1M_KC) {
+        const bf16* xs; int Cs, kk;
+        if (k0 < C1) { xs = x1; Cs = C1; kk = k0; } else { xs = x2; Cs = C2; kk = k0 - C1; }
+        uint4 areg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = tid + i * 256;          // 1024 pieces: row = pc >> 2, chunk = pc & 3
+            const int64_t rr = row0 + (pc >> 2);
+            areg[i] = make_uint4(0, 0, 0, 0);
+            if (rr < rows) areg[i] = *reinterpret_cast<const uint4*>(xs + rr * Cs + kk + (pc & 3) * 8);
+        }
+        // weight slice: BN rows (n) x 4 chunks of 8 k; thread -> (n = p % BN, chunk = p / BN)
+        uint4 breg[(BN * 4 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (BN * 4 + 255) / 256; ++i) {
+            const int pc = tid + i * 256;
+            breg[i] = make_uint4(0, 0, 0, 0);
+            if (pc < BN * 4) {
+                const int n = pc % BN, c = pc / BN;
+                const float* wp = w + (size_t)(k0 + c * 8) * ldw + n0 + n;
+                unsigned u[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    u[j] = (unsigned)f32_to_bf16_bits(wp[(size_t)(2 * j) * ldw]) |
+                           ((unsigned)f32_to_bf16_bits(wp[(size_t)(2 * j + 1) * ldw]) << 16);
+                breg[i] = make_uint4(u[0], u[1], u[2], u[3]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = tid + i * 256;
+            *reinterpret_cast<uint4*>(sA + sw64(pc >> 2, pc & 3)) = areg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < (BN * 4 + 255) / 256; ++i) {
+            const int pc = tid + i * 256;
+            if (pc < BN * 4) *reinterpret_cast<uint4*>(sB + sw64(pc % BN, pc / BN)) = breg[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xf[2], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                xf[mt] = *reinterpret_cast<const bf16x8*>(sA + sw64(wave * 64 + mt * 32 + r, 2 * ks + hh));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const bf16x8*>(sB + sw64(nt * 32 + r, 2 * ks + hh));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue through LDS, 64 output channels (2 n-tiles) per pass
+    // lane owns voxel row (wave*64 + mt*32 + r) and channels nt*32 + 8 j + 4 hh + (0..3)
+#pragma unroll
+    for (int np = 0; np < NT; np += 2) {
+        constexpr int PW = (NT >= 2) ? 64 : 32;  // channels per pass
+        __syncthreads();
+#pragma unroll
+        for (int nn = 0; nn < (NT >= 2 ? 2 : 1); ++nn) {
+            const int nt = np + nn;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int vr = wave * 64 + mt * 32 + r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = nn * 32 + 8 * j + 4 * hh;  // channel within the pass
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (bias) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bv[e] = bias[n0 + np * 32 + ch + e];
+                    }
+                    const unsigned lo = (unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j] + bv[0]) |
+                                        ((unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 1] + bv[1]) << 16);
+                    const unsigned hi = (unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 2] + bv[2]) |
+                                        ((unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 3] + bv[3]) << 16);
+                    int a;
+                    if (PW == 64) a = sw128(vr, ch >> 3) + (ch & 7) * 2;
+                    else a = sw64(vr, ch >> 3) + (ch & 7) * 2;
+                    *reinterpret_cast<uint2*>(smem + a) = make_uint2(lo, hi);
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int CHUNKS = PW / 8;  // 16-B chunks per row
+#pragma unroll
+        for (int i = 0; i < (C1M_ROWS * CHUNKS) / 256; ++i) {
+            const int pc = tid + i * 256;
+            const int vr = pc / CHUNKS, c = pc % CHUNKS;
+            const int64_t rr = row0 + vr;
+            if (rr < rows) {
+                uint4 v = *reinterpret_cast<const uint4*>(smem + (PW == 64 ? sw128(vr, c) : sw64(vr, c)));
+                const int64_t off = rr * Cout + n0 + np * 32 + c * 8;
+                if (add) {
+                    Vec8<bf16> a, b;
+                    a.load(reinterpret_cast<const bf16*>(&v));
+                    b.load(add + off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a.v[e] += b.v[e];
+                    a.store(y + off);
+                } else {
+                    *reinterpret_cast<uint4*>(y + off) = v;
+                }
+            }
+        }
+    }
+}
+
+int conv1_mfma_fwd_launch(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
+                          const void* add, void* y, int64_t rows, int Cout, hipStream_t st) {
+    const int NT = (Cout % 64 == 0) ? 2 : 1;  // NT = 4 needs 270 registers: 1 wave/SIMD, too few loads in flight
+    dim3 grid(ceil_div(rows, C1M_ROWS), Cout / (32 * NT));
+#define C1M_LAUNCH(NTV)                                                                                             \
+    hipLaunchKernelGGL((conv1_mfma_fwd_kernel<NTV>), grid, dim3(256), 0, st, (const bf16*)x1, C1, (const bf16*)x2, \
+                       C2, w, ldw, bias, (const bf16*)add, (bf16*)y, rows, Cout)
+    if (NT == 2) C1M_LAUNCH(2); else C1M_LAUNCH(1);
+#undef C1M_LAUNCH
+    return tdx_launch_status();
+}
+
+// ------------------------------------------------------------------ weight gradient ------
+__device__ __forceinline__ bf16x8 tr_frag8(const unsigned char* lo, const unsigned char* hi) {
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(hi));
+    s16x8 rr = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, rr);
+}
+
+bool conv1_wgrad_mfma_supported(int Cin, int Cout) { return (Cin % 32) == 0 && (Cout % 32) == 0; }
+
+#define C1W_PLANE (C1M_ROWS * 64)  // one [256][32] bf16 plane
+
+template <int MT, int NT>  // tile = (32 MT) ci x (32 NT) co
+__global__ void __launch_bounds__(256)
+conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restrict__ dy, int Cout,
+                        float* __restrict__ dw, int ldw, float* __restrict__ dbias, int64_t rows, int nsplit,
+                        int n_ci_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(MT + NT) * C1W_PLANE];
+    unsigned char* sX = smem;
+    unsigned char* sG = smem + MT * C1W_PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
+    const int ci0 = (tile % n_ci_tiles) * 32 * MT, co0 = (tile / n_ci_tiles) * 32 * NT;
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int col_off = (16 * (g & 1) + 4 * p) * 2;
+    const int kh = g >> 1;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = dbias != nullptr && ci0 == 0;
+    const int64_t nchunks = (rows + C1M_ROWS - 1) / C1M_ROWS;
+
+    for (int64_t ch = split; ch < nchunks; ch += nsplit) {
+        const int64_t row0 = ch * C1M_ROWS;
+        uint4 xr[MT * 4], gr[NT * 4];
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+            const int pc = tid + i * 256;  // (row, plane, chunk): chunk fastest
+            const int c = pc & 3, pl = (pc >> 2) % MT, rr = pc / (4 * MT);
+            xr[i] = make_uint4(0, 0, 0, 0);
+            if (row0 + rr < rows) xr[i] = *reinterpret_cast<const uint4*>(x + (row0 + rr) * Cin + ci0 + pl * 32 + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i) {
+            const int pc = tid + i * 256;
+            const int c = pc & 3, pl = (pc >> 2) % NT, rr = pc / (4 * NT);
+            gr[i] = make_uint4(0, 0, 0, 0);
+            if (row0 + rr < rows) gr[i] = *reinterpret_cast<const uint4*>(dy + (row0 + rr) * Cout + co0 + pl * 32 + c * 8);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+            const int pc = tid + i * 256;
+            const int c = pc & 3, pl = (pc >> 2) % MT, rr = pc / (4 * MT);
+            *reinterpret_cast<uint4*>(sX + pl * C1W_PLANE + rr * 64 + c * 16) = xr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i) {
+            const int pc = tid + i * 256;
+            const int c = pc & 3, pl = (pc >> 2) % NT, rr = pc / (4 * NT);
+            *reinterpret_cast<uint4*>(sG + pl * C1W_PLANE + rr * 64 + c * 16) = gr[i];
+        }
+        __syncthreads();
+        if (do_bias) {
+            constexpr int NCO = 32 * NT;
+            const int co = tid % NCO, part = tid / NCO, nparts = 256 / NCO;
+            const unsigned char* gp = sG + (co >> 5) * C1W_PLANE + (co & 31) * 2;
+            float s = 0.f;
+            for (int v = part; v < C1M_ROWS; v += nparts) s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(gp + v * 64));
+            bsum += s;
+        }
+        // wave reduces rows [64 wave, 64 wave + 64): 4 K-steps of 16 rows
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int row = wave * 64 + 16 * s + 8 * kh + q;
+            bf16x8 af[MT], bfv[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const unsigned char* ap = sX + m * C1W_PLANE + row * 64 + col_off;
+                af[m] = tr_frag8(ap, ap + 4 * 64);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const unsigned char* bp = sG + n * C1W_PLANE + row * 64 + col_off;
+                bfv[n] = tr_frag8(bp, bp + 4 * 64);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfv[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ci = ci0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                atomicAdd(&dw[(size_t)ci * ldw + co0 + n * 32 + r], acc[m][n][i]);
+            }
+    if (do_bias) atomicAdd(&dbias[co0 + tid % (32 * NT)], bsum);
+}
+
+int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
+                            int64_t rows, hipStream_t st) {
+    const int MT = (Cin % 64 == 0) ? 2 : 1, NT = (Cout % 64 == 0) ? 2 : 1;
+    const int n_ci = Cin / (32 * MT), n_co = Cout / (32 * NT);
+    const int ntiles = n_ci * n_co;
+    const int64_t nchunks = (rows + C1M_ROWS - 1) / C1M_ROWS;
+    int nsplit = (1024 + ntiles - 1) / ntiles;
+    if (nsplit > nchunks) nsplit = (int)nchunks;
+    if (nsplit < 1) nsplit = 1;
+    dim3 grid((unsigned)(ntiles * nsplit));
+#define C1W_LAUNCH(M, N)                                                                                          \
+    hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<M, N>), grid, dim3(256), 0, st, (const bf16*)x, Cin, (const bf16*)dy, \
+                       Cout, dw, ldw, dbias, rows, nsplit, n_ci)
+    if (MT == 2 && NT == 2) C1W_LAUNCH(2, 2);
+    else if (MT == 2) C1W_LAUNCH(2, 1);
+    else if (NT == 2) C1W_LAUNCH(1, 2);
+    else C1W_LAUNCH(1, 1);
+#undef C1W_LAUNCH
+    return tdx_launch_status();
+}

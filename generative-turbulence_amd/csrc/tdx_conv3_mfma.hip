@@ -224,15 +224,3 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
 #undef M3_LAUNCH
     return tdx_launch_status();
 }
-
-// ------------------------------------------------------------------ weight gradient ------
-// (MFMA version added in a later milestone; the entry point falls back to the vector-ALU
-// kernel while this reports "unsupported".)
-bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout) {
-    (void)C1; (void)C2; (void)Cout;
-    return false;
-}
-int conv3_wgrad_mfma_launch(const void*, int, const void*, int, const void*, float*, float*, int, int, int, int, int,
-                            hipStream_t) {
-    return TDX_ESHAPE;
-}

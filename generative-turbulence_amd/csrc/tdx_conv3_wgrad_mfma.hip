@@ -1,0 +1,231 @@
+// bf16 MFMA weight gradient of the replicate-padded 3x3x3 convolution (gfx950).
+//
+//   dW[tap][ci][co] = sum_v x[clamp(v + tap)][ci] * dy[v][co]
+//
+// A "TN" GEMM per tap: M = ci, N = co, K = voxels -- both operands are stored voxel-major
+// (NDHWC), i.e. K-major, so every MFMA fragment is a transposed LDS read
+// (ds_read_b64_tr_b16: 4 voxel rows x 16 channels per 16-lane group, delivered
+// channel-major).  Rows are 64 B (32 channels), so the four consecutive-z rows a lane
+// group reads are 256 contiguous bytes: conflict-free by construction.
+//
+// One workgroup (4 waves, one per SIMD, whole 512-register file) owns a 32(ci) x 32*NT(co)
+// tile of all 27 taps and walks a strided subset of 4x8x8-voxel bricks.  Per brick it
+// stages the halo'd x brick (600 voxels x 32 ch = 38 KB) and the dy brick (256 voxels x
+// 32*NT ch) into LDS; wave w accumulates taps w, w+4, ... (7 taps x NT tiles x 16 regs)
+// over the brick's 16 K-steps of 16 voxels, so a dy fragment is read once per K-step and
+// reused by the wave's 7 taps.  Global loads for the next brick are issued before the MFMA
+// phase of the current one and written to LDS after it.  Partial tiles are merged with f32
+// atomics (128-B contiguous per half-wave) into dwp[27][Cin][Cout].
+#include "tdx_common.h"
+#include "tdx_conv3.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+#define W3_BX 4
+#define W3_BY 8
+#define W3_BZ 8
+#define W3_HY 10
+#define W3_HZ 10
+#define W3_NHALO 600
+#define W3_XBYTES (W3_NHALO * 64)   // 38400
+#define W3_GPLANE (256 * 64)        // one 32-channel dy plane
+#define W3_TAPS_PER_WAVE 7
+
+bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout) {
+    return C1 > 0 && (C1 % 32) == 0 && (C2 % 32) == 0 && (Cout % 32) == 0;
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_lo, const unsigned char* base_hi) {
+    // two transposed 4-row reads -> 8 consecutive k for this lane's column
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base_lo));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base_hi));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 1)
+conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
+                        const bf16* __restrict__ dy, float* __restrict__ dwp, float* __restrict__ dbias, int B, int X,
+                        int Y, int Z, int Cout, int nbx, int nby, int nbz, int nsplit, int n_ci_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sX = smem;
+    unsigned char* sG = smem + W3_XBYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Cin = C1 + C2;
+    const int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
+    const int ci0 = (tile % n_ci_tiles) * 32;
+    const int co0 = (tile / n_ci_tiles) * (32 * NT);
+    const bf16* xs;
+    int Cs, cbase;
+    if (ci0 < C1) { xs = x1; Cs = C1; cbase = ci0; } else { xs = x2; Cs = C2; cbase = ci0 - C1; }
+
+    const int nbricks = B * nbx * nby * nbz;
+
+    // ---- fragment lane geometry (see file header)
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int col_off = (16 * (g & 1) + 4 * p) * 2;   // byte offset of this lane's 4 columns in a 64-B row
+    const int kh = g >> 1;                            // which 8-voxel half of the 16-voxel K-step
+
+    f32x16 acc[W3_TAPS_PER_WAVE][NT];
+#pragma unroll
+    for (int t = 0; t < W3_TAPS_PER_WAVE; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][nt][i] = 0.f;
+    float bsum = 0.f;
+    const bool do_bias = dbias != nullptr && ci0 == 0;
+
+    // halo offsets (in voxels) of this wave's taps
+    int toff[W3_TAPS_PER_WAVE];
+#pragma unroll
+    for (int t = 0; t < W3_TAPS_PER_WAVE; ++t) {
+        const int tap = min(wave + 4 * t, 26);
+        const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
+        toff[t] = (ex * W3_HY + ey) * W3_HZ + ez;
+    }
+
+    constexpr int XP = (W3_NHALO * 4 + 255) / 256;  // 10 pieces of 16 B per thread
+    constexpr int GP = (256 * 4 * NT) / 256;         // 4*NT pieces per thread
+    uint4 xreg[XP], greg[GP];
+
+    auto load_brick = [&](int brick) {
+        int bb = brick;
+        const int bz = bb % nbz; bb /= nbz;
+        const int by = bb % nby; bb /= nby;
+        const int bx = bb % nbx; bb /= nbx;
+        const int b = bb;
+        const int ox0 = bx * W3_BX, oy0 = by * W3_BY, oz0 = bz * W3_BZ;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int pc = tid + i * 256;
+            xreg[i] = make_uint4(0, 0, 0, 0);
+            if (pc < W3_NHALO * 4) {
+                const int hv = pc >> 2, q4 = pc & 3;
+                const int hx = hv / (W3_HY * W3_HZ), rem = hv - hx * (W3_HY * W3_HZ);
+                const int hy = rem / W3_HZ, hz = rem - hy * W3_HZ;
+                const int sx = min(max(ox0 + hx - 1, 0), X - 1), sy = min(max(oy0 + hy - 1, 0), Y - 1),
+                          sz = min(max(oz0 + hz - 1, 0), Z - 1);
+                const int64_t vox = (((int64_t)b * X + sx) * Y + sy) * Z + sz;
+                xreg[i] = *reinterpret_cast<const uint4*>(xs + vox * Cs + cbase + q4 * 8);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GP; ++i) {
+            const int pc = tid + i * 256;
+            const int v = pc / (4 * NT), q8 = pc - v * (4 * NT);
+            const int vx = ox0 + (v >> 6), vy = oy0 + ((v >> 3) & 7), vz = oz0 + (v & 7);
+            greg[i] = make_uint4(0, 0, 0, 0);
+            if (vx < X && vy < Y && vz < Z) {
+                const int64_t vox = (((int64_t)b * X + vx) * Y + vy) * Z + vz;
+                greg[i] = *reinterpret_cast<const uint4*>(dy + vox * Cout + co0 + q8 * 8);
+            }
+        }
+    };
+    auto store_brick = [&]() {
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int pc = tid + i * 256;
+            if (pc < W3_NHALO * 4) *reinterpret_cast<uint4*>(sX + pc * 16) = xreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < GP; ++i) {
+            const int pc = tid + i * 256;
+            const int v = pc / (4 * NT), q8 = pc - v * (4 * NT);
+            *reinterpret_cast<uint4*>(sG + (q8 >> 2) * W3_GPLANE + v * 64 + (q8 & 3) * 16) = greg[i];
+        }
+    };
+
+    int brick = split;
+    if (brick < nbricks) load_brick(brick);
+    for (; brick < nbricks; brick += nsplit) {
+        __syncthreads();  // previous brick's fragment reads are done
+        store_brick();
+        __syncthreads();
+        if (brick + nsplit < nbricks) load_brick(brick + nsplit);  // in flight during the MFMA phase
+
+        if (do_bias) {
+            // column sums of the dy brick: thread -> (co = tid & (32 NT - 1), voxel slice)
+            constexpr int NCO = 32 * NT;
+            const int co = tid % NCO, part = tid / NCO, nparts = 256 / NCO;
+            const unsigned char* gp = sG + (co >> 5) * W3_GPLANE + (co & 31) * 2;
+            float s = 0.f;
+            for (int v = part; v < 256; v += nparts) s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(gp + v * 64));
+            bsum += s;
+        }
+
+#pragma unroll 2
+        for (int s = 0; s < 16; ++s) {
+            // K-step s: voxels (x = s >> 2, y = 2 (s & 3) + kh, z = q (+4))
+            const int vrow = 16 * s + 8 * kh + q;                                  // dy row
+            const int hrow = (((s >> 2) + 1) * W3_HY + (2 * (s & 3) + kh + 1)) * W3_HZ + (q + 1);  // x halo row, tap (0,0,0)
+            bf16x8 bfrag[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned char* bp = sG + nt * W3_GPLANE + vrow * 64 + col_off;
+                bfrag[nt] = tr_frag(bp, bp + 4 * 64);
+            }
+#pragma unroll
+            for (int t = 0; t < W3_TAPS_PER_WAVE; ++t) {
+                const unsigned char* ap = sX + (hrow + toff[t]) * 64 + col_off;
+                const bf16x8 afrag = tr_frag(ap, ap + 4 * 64);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[nt], acc[t][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- merge: D[row = ci][col = co]; lane holds col (lane & 31), rows (i&3) + 8 (i>>2) + 4 (lane>>5)
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < W3_TAPS_PER_WAVE; ++t) {
+        const int tap = wave + 4 * t;
+        if (tap < 27) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ci = ci0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    atomicAdd(&dwp[((int64_t)tap * Cin + ci) * Cout + co0 + nt * 32 + r], acc[t][nt][i]);
+                }
+        }
+    }
+    if (do_bias) atomicAdd(&dbias[co0 + tid % (32 * NT)], bsum);
+}
+
+int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
+                            int B, int X, int Y, int Z, int Cout, hipStream_t st) {
+    const int Cin = C1 + C2;
+    const int NT = (Cout % 64 == 0) ? 2 : 1;
+    const int nbx = ceil_div(X, W3_BX), nby = ceil_div(Y, W3_BY), nbz = ceil_div(Z, W3_BZ);
+    const int nbricks = B * nbx * nby * nbz;
+    const int n_ci = Cin / 32, n_co = Cout / (32 * NT);
+    const int ntiles = n_ci * n_co;
+    // one workgroup per CU-slot: aim at ~2 x 256 workgroups overall, at most one split per brick
+    int nsplit = (512 + ntiles - 1) / ntiles;
+    if (nsplit > nbricks) nsplit = nbricks;
+    if (nsplit < 1) nsplit = 1;
+    const size_t lds = W3_XBYTES + (size_t)NT * W3_GPLANE;
+    dim3 grid((unsigned)(ntiles * nsplit));
+#define W3_LAUNCH(NTV)                                                                                               \
+    do {                                                                                                             \
+        auto kern = conv3_wgrad_mfma_kernel<NTV>;                                                                    \
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return (int)e;                                                                          \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2, (const bf16*)dy, \
+                           dwp, dbias, B, X, Y, Z, Cout, nbx, nby, nbz, nsplit, n_ci);                               \
+    } while (0)
+    if (NT == 2) W3_LAUNCH(2); else W3_LAUNCH(1);
+#undef W3_LAUNCH
+    return tdx_launch_status();
+}

@@ -195,7 +195,9 @@ def test_graph_sampler_equals_eager_loop(golden, nb):
     out_eager = diff.p_sample_loop(x_bcs, C, cidx, noise_fn=lambda like: next(stream))
     assert rel_l2(out_graph, out_eager) < 1e-5
     # replaying gives the same trajectory again (offset / t reset on device)
-    assert torch.equal(gs.sample(), out_graph)
+    # (GroupNorm statistics merge per-block partials with f64 atomics, so runs agree to
+    # rounding, not bitwise)
+    assert rel_l2(gs.sample(), out_graph) < 1e-5
     # sharding invariance: trajectory 9 alone, on its own "rank", gives the same sample
     solo = GraphSampler(diff, x_bcs[1:], C, cidx, seed=42, trajectory_ids=[9], use_graph=False).sample()
     assert rel_l2(solo[0], out_graph[1]) < 1e-5
