@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the 3x3x3 conv kernels at the BASELINE config-2 shapes (B per GPU = 6).
+Usage (GPU box): python tools/conv_bench.py [--batch 6] [--impl auto]"""
+import argparse, os, sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "generative-turbulence_amd"))
+import torch
+from turbdiff_amd import _lib as L, ops
+
+LAYERS = [  # name, C1, C2, Cout, grid
+    ("down.0.b1", 64, 0, 64, (192, 64, 48)), ("down.1.b1", 64, 0, 128, (96, 32, 24)), ("down.1.b2", 128, 0, 128, (96, 32, 24)),
+    ("down.2.b1", 128, 0, 256, (48, 16, 12)), ("down.2.b2", 256, 0, 256, (48, 16, 12)), ("down.3.b1", 256, 0, 512, (24, 8, 6)),
+    ("down.3.b2", 512, 0, 512, (24, 8, 6)), ("center", 512, 0, 512, (12, 4, 3)), ("up.0.b1", 512, 512, 256, (24, 8, 6)),
+    ("up.0.b2", 256, 0, 256, (24, 8, 6)), ("up.1.b1", 256, 256, 128, (48, 16, 12)), ("up.1.b2", 128, 0, 128, (48, 16, 12)),
+    ("up.2.b1", 128, 128, 64, (96, 32, 24)), ("up.2.b2", 64, 0, 64, (96, 32, 24)), ("up.3.b1", 64, 64, 32, (192, 64, 48)),
+    ("up.3.b2", 32, 0, 32, (192, 64, 48)),
+]
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=6); ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0"); B = a.batch
+    tot = {"fwd": 0, "dgrad": 0, "wgrad": 0}; totf = 0
+    print(f"{'layer':12s} {'Cin':>5s} {'Cout':>5s} {'grid':>12s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
+    for name, C1, C2, Co, (X, Y, Z) in LAYERS:
+        if a.only and a.only not in name: continue
+        Ci = C1 + C2
+        x1 = torch.randn(B, X, Y, Z, C1, device=dev).bfloat16()
+        x2 = torch.randn(B, X, Y, Z, C2, device=dev).bfloat16() if C2 else None
+        w = (torch.randn(Co, Ci, 3, 3, 3, device=dev) * 0.02)
+        bias = torch.zeros(Co, device=dev)
+        gy = torch.randn(B, X, Y, Z, Co, device=dev).bfloat16()
+        wf, wb = ops._packed_conv3(w, torch.bfloat16)
+        y = torch.empty(B, X, Y, Z, Co, device=dev, dtype=torch.bfloat16)
+        st = L.stream()
+        f = lambda: L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Co, 1, 0, st)
+        gx1 = torch.empty_like(x1); gx2 = torch.empty_like(x2) if C2 else None
+        ws = torch.empty(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, Ci, 1, 0), dtype=torch.uint8, device=dev)
+        d = lambda: L.call("tdx_conv3_bwd_data", L.ptr(gy), L.ptr(wb), L.ptr(gx1), C1, L.ptr(gx2), C2, 0, B, X, Y, Z, Co, 1, 0, L.ptr(ws), st)
+        gw = torch.empty_like(w); gb = torch.empty(Co, device=dev)
+        ws2 = torch.empty(L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, 0), dtype=torch.uint8, device=dev)
+        wg = lambda: L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z, Co, 1, 0, L.ptr(ws2), st)
+        fl = 54.0 * Ci * Co * B * X * Y * Z
+        tf, td, tw = timeit(f), timeit(d), timeit(wg)
+        mult = 4 if name == "center" else (2 if name in ("down.0.b1",) else 1)  # center x4; down.0.b1 == down.0.b2
+        if name == "up.3.b2": mult = 3  # + decode.0.b1, decode.0.b2
+        for k, t in (("fwd", tf), ("dgrad", td), ("wgrad", tw)): tot[k] += t * mult
+        totf += fl * mult
+        print(f"{name:12s} {Ci:5d} {Co:5d} {X:4d}x{Y:3d}x{Z:3d} | {tf:8.3f} {fl/tf/1e9:6.0f} | {td:8.3f} {fl/td/1e9:6.0f} | {tw:8.3f} {fl/tw/1e9:6.0f}   x{mult}")
+    print(f"TOTAL per step (weighted): fwd {tot['fwd']:.2f} ms ({totf/tot['fwd']/1e9:.0f} TF/s)  dgrad {tot['dgrad']:.2f} ms ({totf/tot['dgrad']/1e9:.0f})  wgrad {tot['wgrad']:.2f} ms ({totf/tot['wgrad']/1e9:.0f})")
+
+if __name__ == "__main__":
+    main()
