@@ -40,7 +40,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define M3_HZ (M3_BZ + 2)
 #define M3_SZ 12                               // padded z stride of the LDS brick
 #define M3_NVOX_HALO (M3_HX * M3_HY * M3_HZ)   // 600
-#define M3_BRICK_BYTES (M3_HX * M3_HY * M3_SZ * 32)  // 23040
+#define M3_BRICK_BYTES (M3_HX * M3_HY * M3_SZ * 32 + 128)  // 23168
 #define M3_KC 16
 
 bool conv3_mfma_supported(int C1, int C2, int Cout) {
@@ -50,7 +50,7 @@ bool conv3_mfma_supported(int C1, int C2, int Cout) {
 // two half-planes (channels 0-7 / 8-15 of the slice), 16 B per voxel: with the z stride of 12
 // the 16 voxels of every ds_read_b128 lane group are distinct mod 16 -> conflict-free with
 // plain affine addresses (tap offsets become instruction immediates)
-#define M3_APLANE (M3_HX * M3_HY * M3_SZ * 16)
+#define M3_APLANE (M3_HX * M3_HY * M3_SZ * 16 + 64)  // +64 B: the two halves of a voxel land 4 slots apart
 __device__ __forceinline__ int brick_addr(int h, int half) { return half * M3_APLANE + h * 16; }
 // output tile rows of 64 B (BN = 32) or 128 B (BN = 64); 16-B chunk c of row v at c ^ swizzle(v)
 template <int BN>
@@ -97,7 +97,8 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         a_dst[i] = -1;
         a_src[i] = -1;
         if (p < A_PIECES) {
-            const int hv = p >> 1, half = p & 1;
+            // lanes 0-3 / 4-7 of every 8-lane group: 4 consecutive voxels x the two halves
+            const int hv = ((p >> 3) << 2) + (p & 3), half = (p >> 2) & 1;
             const int hx = hv / (M3_HY * M3_HZ), rem = hv - hx * (M3_HY * M3_HZ);
             const int hy = rem / M3_HZ, hz = rem - hy * M3_HZ;
             a_dst[i] = brick_addr((hx * M3_HY + hy) * M3_SZ + hz, half);
@@ -113,6 +114,13 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     }
     const int64_t batch_vox = (int64_t)b * g.Xi * g.Yi * g.Zi;
 
+    // weight staging role of this thread
+    constexpr int B_PLANE = 27 * BN * 16 + 64;
+    const int b_half = (tid >> 2) & 1;
+    const int b_row0 = ((tid >> 3) << 2) + (tid & 3);                       // 0..127
+    const int b_goff = ((b_row0 / BN) * Cout + (b_row0 % BN)) * 16 + b_half * 8;  // elements
+    const int b_dst = b_half * B_PLANE + b_row0 * 16;
+
     uint4 areg[A_PER_THREAD], breg[B_PER_THREAD];
     auto load_slice = [&](int c) {
         const int k0 = c * M3_KC;
@@ -126,16 +134,14 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             if (a_src[i] >= 0)
                 areg[i] = *reinterpret_cast<const uint4*>(xs + (int64_t)(a_src[i] >> 1) * Cs + (a_src[i] & 1) * 8);
         }
-        const bf16* wc = wp + (int64_t)c * 27 * Cout * 16 + (int64_t)n0 * 16;
+        // weights: thread -> (row = b_row0 + 128 i, half); 128 rows = 128/BN taps per step, so both
+        // the global and the LDS address advance by a constant per i
+        const bf16* wc = wp + (int64_t)c * 27 * Cout * 16 + (int64_t)n0 * 16 + b_goff;
 #pragma unroll
         for (int i = 0; i < B_PER_THREAD; ++i) {
-            const int p = tid + i * 256;
             breg[i] = make_uint4(0, 0, 0, 0);
-            if (p < B_PIECES) {
-                const int row = p >> 1;  // tap*BN + n
-                const int tap = row / BN, n = row - tap * BN;
-                breg[i] = *reinterpret_cast<const uint4*>(wc + ((int64_t)tap * Cout + n) * 16 + (p & 1) * 8);
-            }
+            if (b_row0 + 128 * i < 27 * BN)
+                breg[i] = *reinterpret_cast<const uint4*>(wc + (int64_t)i * (128 / BN) * Cout * 16);
         }
     };
     auto store_slice = [&]() {
@@ -143,13 +149,8 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         for (int i = 0; i < A_PER_THREAD; ++i)
             if (a_dst[i] >= 0) *reinterpret_cast<uint4*>(sA + a_dst[i]) = areg[i];
 #pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) {
-            const int p = tid + i * 256;
-            if (p < B_PIECES) {
-                const int row = p >> 1;
-                *reinterpret_cast<uint4*>(sB + (p & 1) * (27 * BN * 16) + row * 16) = breg[i];
-            }
-        }
+        for (int i = 0; i < B_PER_THREAD; ++i)
+            if (b_row0 + 128 * i < 27 * BN) *reinterpret_cast<uint4*>(sB + b_dst + i * 2048) = breg[i];
     };
 
     // ---- per-lane fragment bases
@@ -161,7 +162,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = nt * 32 + r;
-        b_off[nt] = hh * (27 * BN * 16) + n * 16;
+        b_off[nt] = hh * B_PLANE + n * 16;
     }
 
     f32x16 acc[NT][2];  // D[row = channel][col = voxel]
@@ -180,22 +181,38 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         __syncthreads();
         if (c + 1 < nchunks) load_slice(c + 1);  // in flight during the MFMAs below
 
-#pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
+        // fragments of tap t+1 are read while the MFMAs of tap t issue (two register sets)
+        bf16x8 xf[2][2], wf[2][NT];
+        auto read_frags = [&](int tap, int buf) {
             const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
             const int toff = (ex * M3_HY + ey) * M3_SZ + ez;
-            bf16x8 xf[2], wf[NT];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-                xf[mt] = *reinterpret_cast<const bf16x8*>(sA + brick_addr(a_h[mt] + toff, hh));
+                xf[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + brick_addr(a_h[mt] + toff, hh));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const bf16x8*>(sB + tap * (BN * 16) + b_off[nt]);
+                wf[buf][nt] = *reinterpret_cast<const bf16x8*>(sB + tap * (BN * 16) + b_off[nt]);
+        };
+        read_frags(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);  // DS_READ: tap 0's fragments
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            if (tap + 1 < 27) read_frags(tap + 1, (tap + 1) & 1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap & 1][nt], xf[tap & 1][mt], acc[nt][mt], 0, 0, 0);
+            // pin the interleave: one fragment read of tap+1 behind each MFMA of tap
+            if (tap + 1 < 27) {
+#pragma unroll
+                for (int k = 0; k < 2 * NT; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                    if (k < 2 + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS_READ
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+            }
         }
     }
 
@@ -245,7 +262,7 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
     const int BN = NT * 32;
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31)) return TDX_ESHAPE;  // a_src packs (voxel, half) in 31 bits
     dim3 grid((unsigned)((int64_t)g.B * nbx * nby * nbz), Cout / BN);
-    const size_t lds = M3_BRICK_BYTES + (size_t)27 * BN * 32;
+    const size_t lds = M3_BRICK_BYTES + (size_t)27 * BN * 32 + 128;  // two padded half-planes each
 #define M3_LAUNCH(NTV, ZP)                                                                                           \
     do {                                                                                                             \
         auto kern = conv3_mfma_kernel<NTV, ZP>;                                                                      \
