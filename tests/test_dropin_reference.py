@@ -1,0 +1,43 @@
+"""The drop-in claim, checked where the reference is available (the build container):
+with turbdiff_amd.dropin installed, the reference's own DiffusionTraining (diffusion.py:41-143)
+constructs OUR DenoisingModel / GaussianDiffusion and its state_dict has the reference schema.
+Skipped on machines without /root/reference (e.g. the GPU box)."""
+
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+
+SCRIPT = r'''
+import sys
+sys.path.insert(0, "{root}/tests/golden"); sys.path.insert(0, "{root}/generative-turbulence_amd")
+import make_golden
+make_golden.install_stubs()
+sys.path.insert(0, "/root/reference")
+import turbdiff_amd.dropin as dropin
+dropin.install()
+from pathlib import Path
+from turbdiff.models.diffusion import DiffusionTraining          # the reference's Lightning task
+from turbdiff.data.ofles import Variable as V
+import turbdiff.models.ddpm as D
+assert D.__name__ == "turbdiff_amd.models.ddpm", D.__name__
+task = DiffusionTraining(Path("/tmp/none"), Path("/tmp/none"), dim=32, variables=(V.U, V.P),
+                         beta_schedule="log-snr-linear", timesteps=500, loss="l2", noise_bcs=True,
+                         optimizer="radam", norm_type="group", with_geometry_embedding=False)
+assert type(task.model).__module__ == "turbdiff_amd.models.ddpm"
+assert type(task.model.model).__module__ == "turbdiff_amd.models.ddpm"
+want = [l.split("\t")[0] for l in open("{root}/tests/golden/state_dict_manifest.txt") if not l.startswith("#")]
+have = list(task.state_dict().keys())
+assert have == want, (len(have), len(want), set(have) ^ set(want))
+print("DROPIN_OK", len(have))
+'''
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference checkout not present")
+def test_reference_task_builds_our_model():
+    out = subprocess.run([sys.executable, "-c", SCRIPT.format(root=ROOT)], capture_output=True, text=True, timeout=300)
+    assert "DROPIN_OK 149" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
