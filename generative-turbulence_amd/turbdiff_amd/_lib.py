@@ -36,6 +36,10 @@ SIGNATURES = {
     "tdx_conv3_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "tdx_conv1_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "tdx_conv1_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i64, _i, _vp]),
+    "tdx_encode_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "tdx_encode_bwd": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
+    "tdx_decode_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
+    "tdx_decode_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "tdx_gn_workspace_bytes": (_sz, [_i, _i]),
     "tdx_gn_stats": (_i, [_vp, _vp, _i, _i64, _i, _i, _f, _i, _vp, _vp]),
     "tdx_gn_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),

@@ -297,12 +297,21 @@ class DenoisingModel(nn.Module):
     def forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
         B = x.shape[0]
         c = self.conditioning_vector(t, C, B)
-        h = ops.conv1(ops.to_nvc(x, self.compute_dtype), self.encode_x.weight, self.encode_x.bias)
-        e = encoded_local if encoded_local is not None else self.encode_local(C)
-        if e is not None:
-            h = torch.cat((h, e.expand(B, -1, -1, -1, -1)), dim=-1)
+        c_local = local_conditioning(C) if self.c_local_features > 0 else None
+        if ops.encode_supported(x, c_local, self.encode_x.weight):
+            # both encoders + NCDHW->NDHWC + concat in one kernel
+            wc = self.encode_c_local.weight if c_local is not None else None
+            bc = self.encode_c_local.bias if c_local is not None else None
+            h = ops.encode(x, c_local, self.encode_x.weight, self.encode_x.bias, wc, bc, self.compute_dtype)
+        else:
+            h = ops.conv1(ops.to_nvc(x, self.compute_dtype), self.encode_x.weight, self.encode_x.bias)
+            e = encoded_local if encoded_local is not None else self.encode_local(C)
+            if e is not None:
+                h = torch.cat((h, e.expand(B, -1, -1, -1, -1)), dim=-1)
         h = self.u_net(h, c)
         h = self.decode[0](h, c)
+        if ops.decode_supported(h, self.decode[1].weight):
+            return ops.decode(h, self.decode[1].weight, self.decode[1].bias)
         y = ops.conv1(h, self.decode[1].weight, self.decode[1].bias)
         return ops.to_ncv(y, torch.float32)
 

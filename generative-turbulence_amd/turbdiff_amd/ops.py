@@ -88,6 +88,102 @@ def to_ncv(x: torch.Tensor, dtype: torch.dtype = torch.float32) -> torch.Tensor:
     return _ToNCV.apply(x, dtype)
 
 
+# --------------------------------------------------------------------------- model boundary
+
+
+class _Encode(torch.autograd.Function):
+    """(B,4,X,Y,Z) f32 [+ (4,X,Y,Z) conditioning] -> (B,X,Y,Z,D or 2D): both 1x1 encoders, the
+    layout change and the channel concat in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, c_local, wx, bx, wc, bc, dtype):
+        B, Fx, X, Y, Z = x.shape
+        V, D = X * Y * Z, wx.shape[0]
+        x = x.contiguous().float()
+        has_c = c_local is not None
+        c = c_local.contiguous().float() if has_c else None
+        wx2, bx2 = wx.detach().reshape(D, Fx).contiguous(), bx.detach().contiguous()
+        wc2 = wc.detach().reshape(D, -1).contiguous() if has_c else None
+        bc2 = bc.detach().contiguous() if has_c else None
+        y = torch.empty((B, X, Y, Z, 2 * D if has_c else D), dtype=dtype, device=x.device)
+        L.call("tdx_encode_fwd", L.ptr(x), Fx, L.ptr(wx2), L.ptr(bx2), L.ptr(c), c.shape[0] if has_c else 0, L.ptr(wc2),
+               L.ptr(bc2), L.ptr(y), B, V, D, L.dtype_code(dtype), L.stream())
+        ctx.save_for_backward(x, c, wc2)
+        ctx.shapes = (tuple(wx.shape), tuple(wc.shape) if has_c else None, tuple(c_local.shape) if has_c else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, c, wc2 = ctx.saved_tensors
+        wx_shape, wc_shape, c_shape = ctx.shapes
+        B, Fx = x.shape[:2]
+        V = x[0, 0].numel()
+        D = wx_shape[0]
+        gy = gy.contiguous()
+        dev = gy.device
+        dwx = torch.empty(wx_shape, dtype=torch.float32, device=dev)
+        dbx = torch.empty(D, dtype=torch.float32, device=dev)
+        has_c = c is not None
+        dwc = torch.empty(wc_shape, dtype=torch.float32, device=dev) if has_c else None
+        dbc = torch.empty(D, dtype=torch.float32, device=dev) if has_c else None
+        dc = torch.empty(c_shape, dtype=torch.float32, device=dev) if (has_c and ctx.needs_input_grad[1]) else None
+        L.call("tdx_encode_bwd", L.ptr(gy), L.ptr(x), Fx, L.ptr(c), c.shape[0] if has_c else 0, L.ptr(wc2), L.ptr(dwx),
+               L.ptr(dbx), L.ptr(dwc), L.ptr(dbc), L.ptr(dc), B, V, D, L.dtype_code(gy.dtype), L.stream())
+        return None, dc, dwx, dbx, dwc, dbc, None
+
+
+def encode_supported(x, c_local, wx):
+    D = wx.shape[0]
+    n = (2 * D if c_local is not None else D) // 8
+    return (x.shape[1] == 4 and (c_local is None or c_local.shape[0] == 4) and D % 8 == 0 and n & (n - 1) == 0
+            and n <= 64 and not x.requires_grad)
+
+
+def encode(x, c_local, wx, bx, wc, bc, dtype):
+    return _Encode.apply(x, c_local, wx, bx, wc, bc, dtype)
+
+
+class _Decode(torch.autograd.Function):
+    """(B,X,Y,Z,D) -> (B,4,X,Y,Z) f32: decode.1's 1x1 conv fused with the layout change."""
+
+    @staticmethod
+    def forward(ctx, h, w, bias):
+        B, X, Y, Z, D = h.shape
+        F = w.shape[0]
+        h = h.contiguous()
+        w2 = w.detach().reshape(F, D).contiguous()
+        y = torch.empty((B, F, X, Y, Z), dtype=torch.float32, device=h.device)
+        L.call("tdx_decode_fwd", L.ptr(h), L.ptr(w2), L.ptr(bias.detach().contiguous()), L.ptr(y), B, X * Y * Z, D, F,
+               L.dtype_code(h.dtype), L.stream())
+        ctx.save_for_backward(h, w2)
+        ctx.wshape = tuple(w.shape)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        h, w2 = ctx.saved_tensors
+        B, X, Y, Z, D = h.shape
+        F = w2.shape[0]
+        gy = gy.contiguous().float()
+        dh = torch.empty_like(h)
+        dw = torch.empty(ctx.wshape, dtype=torch.float32, device=h.device)
+        db = torch.empty(F, dtype=torch.float32, device=h.device)
+        L.call("tdx_decode_bwd", L.ptr(gy), L.ptr(h), L.ptr(w2), L.ptr(dh), L.ptr(dw), L.ptr(db), B, X * Y * Z, D, F,
+               L.dtype_code(h.dtype), L.stream())
+        return dh, dw, db
+
+
+def decode_supported(h, w):
+    n = h.shape[-1] // 8
+    return w.shape[0] == 4 and h.shape[-1] % 8 == 0 and n & (n - 1) == 0 and n <= 64
+
+
+def decode(h, w, bias):
+    return _Decode.apply(h, w, bias)
+
+
 # --------------------------------------------------------------------------- conv 3x3x3
 
 # packed operands are cached per (parameter, version, dtype): repacked once per optimiser

@@ -60,9 +60,11 @@ int tdx_cast(const void* x, void* y, int64_t n, int dtype_in, int dtype_out, voi
 /* nn.Conv3d(k=3, padding=1, padding_mode="replicate"), ddpm.py:164.
  *
  * Weight packing: w (Cout, Cin, 3, 3, 3) f32 as stored in the reference's state_dict ->
- *   wf [27][Cin][Cout]  tap-major forward operand  (tap = (dx+1)*9 + (dy+1)*3 + (dz+1))
- *   wb [27][Cout][Cin]  flipped + transposed operand of the data-gradient conv
- * either output may be NULL.  Elements are `dtype`. */
+ *   wf  forward operand          (K = Cin,  N = Cout, tap = (dx+1)*9 + (dy+1)*3 + (dz+1))
+ *   wb  data-gradient operand    (K = Cout, N = Cin, taps flipped, weights transposed)
+ * each 27*Cin*Cout elements of `dtype`; either may be NULL.  The element order is an
+ * implementation detail shared by pack and the consumers, a function of (dtype, K, N) only:
+ * [K/16][27][N][16] for the bf16 MFMA kernels (K % 16 == 0, N % 32 == 0), else [27][K][N]. */
 int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream);
 
 /* y[b,v,:] = bias + sum_tap sum_ci x[b, clamp(v+tap), ci] * wf[tap][ci][:]
@@ -99,6 +101,24 @@ int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, const float* w
  * Overwrites (buffers are zeroed inside).  x has Cin channels (call twice for a concat). */
 int tdx_conv1_bwd_weight(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
                          int64_t rows, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ model boundary ------ */
+/* encode_x / encode_c_local (ddpm.py:433,436,495-501) fused with NCDHW -> NDHWC and the
+ * channel concatenation:  y[b,v,0:D] = wx x[b,:,v] + bx,  y[b,v,D:2D] = wc c[:,v] + bc.
+ * x (B, Fx, V) f32; c (Fc, V) f32 shared by the batch, or NULL (then y has D channels);
+ * wx [D][Fx], wc [D][Fc] are the reference's (D, F, 1, 1, 1) parameters.  Fx = Fc = 4. */
+int tdx_encode_fwd(const float* x, int Fx, const float* wx, const float* bx, const float* c, int Fc, const float* wc,
+                   const float* bc, void* y, int B, int64_t V, int D, int dtype, void* stream);
+/* parameter gradients (overwritten) and dc (Fc, V) = gradient w.r.t. the conditioning (may be
+ * NULL).  x is data (the noised sample): no gradient is produced for it. */
+int tdx_encode_bwd(const void* dy, const float* x, int Fx, const float* c, int Fc, const float* wc, float* dwx,
+                   float* dbx, float* dwc, float* dbc, float* dc, int B, int64_t V, int D, int dtype, void* stream);
+/* decode.1 (ddpm.py:459,505) fused with NDHWC -> NCDHW: y[b,f,v] = w[f,:] . h[b,v,:] + bias[f],
+ * y (B, F, V) f32, F = 4. */
+int tdx_decode_fwd(const void* h, const float* w, const float* bias, float* y, int B, int64_t V, int D, int F, int dtype,
+                   void* stream);
+int tdx_decode_bwd(const float* dy, const void* h, const float* w, void* dh, float* dw, float* db, int B, int64_t V, int D,
+                   int F, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ GroupNorm+FiLM+SiLU - */
 /* nn.GroupNorm(G, C, eps) -> [x*(scale+1)+shift] -> [SiLU] (-> [+ residual]),

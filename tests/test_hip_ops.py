@@ -344,3 +344,51 @@ def test_philox_randn_moments_and_replay():
     assert torch.equal(a, b)  # same (seed, stream, offset) -> same numbers
     c = ops.randn_philox(torch.empty(1 << 20, device=d), 1234, 8, torch.zeros(1, dtype=torch.int64, device=d))
     assert abs((a * c).mean().item()) < 5e-3  # other trajectory stream: independent
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_c", [True, False])
+@pytest.mark.parametrize("D", [8, 32])
+def test_encode_decode_fused(dtype, with_c, D):
+    """encode_x / encode_c_local / decode.1 fused with the layout changes (ddpm.py:495-505)"""
+    from turbdiff_amd import ops
+
+    B, X, Y, Z = 2, 7, 5, 6
+    x = rnd(B, 4, X, Y, Z, seed=1)
+    c = rnd(4, X, Y, Z, seed=2)
+    wx, bx = rnd(D, 4, 1, 1, 1, seed=3, scale=0.5), rnd(D, seed=4)
+    wc, bc = rnd(D, 4, 1, 1, 1, seed=5, scale=0.5), rnd(D, seed=6)
+    Dt = 2 * D if with_c else D
+    gy = q(rnd(B, Dt, X, Y, Z, seed=7), dtype)
+    leaves = [t.double().requires_grad_() for t in (c, wx, bx, wc, bc)]
+    cr, wxr, bxr, wcr, bcr = leaves
+    yr = F.conv3d(x.double(), wxr, bxr)
+    if with_c:
+        yr = torch.cat((yr, F.conv3d(cr[None], wcr, bcr).expand(B, -1, -1, -1, -1)), dim=1)
+    yr.backward(gy.double())
+    d = dev()
+    cd = c.to(d).requires_grad_()
+    wxd, bxd, wcd, bcd = (t.to(d).requires_grad_() for t in (wx, bx, wc, bc))
+    assert ops.encode_supported(x.to(d), cd if with_c else None, wxd)
+    y = ops.encode(x.to(d), cd if with_c else None, wxd, bxd, wcd if with_c else None, bcd if with_c else None, dtype)
+    y.backward(nvc(gy).to(d).to(dtype))
+    tol = tol_for(dtype)
+    assert rel_l2(ncv(y.float().cpu()), yr) < tol
+    assert rel_l2(wxd.grad.cpu(), wxr.grad) < 1e-4 and rel_l2(bxd.grad.cpu(), bxr.grad) < 1e-4
+    if with_c:
+        assert rel_l2(wcd.grad.cpu(), wcr.grad) < 1e-4 and rel_l2(bcd.grad.cpu(), bcr.grad) < 1e-4
+        assert rel_l2(cd.grad.cpu(), cr.grad) < 1e-4
+    # decode
+    h = q(rnd(B, D, X, Y, Z, seed=8), dtype)
+    w, b = rnd(4, D, 1, 1, 1, seed=9, scale=0.3), rnd(4, seed=10)
+    g4 = rnd(B, 4, X, Y, Z, seed=11)
+    hr, wr, br = h.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    F.conv3d(hr, wr, br).backward(g4.double())
+    hd = nvc(h).to(d).to(dtype).requires_grad_()
+    wd, bd = w.to(d).requires_grad_(), b.to(d).requires_grad_()
+    out = ops.decode(hd, wd, bd)
+    assert out.shape == (B, 4, X, Y, Z) and out.dtype == torch.float32
+    out.backward(g4.to(d))
+    assert rel_l2(out.cpu(), F.conv3d(hr, wr, br)) < 1e-5
+    assert rel_l2(ncv(hd.grad.float().cpu()), hr.grad) < tol
+    assert rel_l2(wd.grad.cpu(), wr.grad) < 1e-4 and rel_l2(bd.grad.cpu(), br.grad) < 1e-4
