@@ -30,9 +30,11 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 #define W3_BZ 8
 #define W3_HY 10
 #define W3_HZ 10
-#define W3_NHALO 600
-#define W3_XBYTES (W3_NHALO * 64)   // 38400
-#define W3_GPLANE (256 * 64)        // one 32-channel dy plane
+#define W3_NVOX (W3_BX * W3_BY * W3_BZ)              // 512 voxels per brick
+#define W3_NSTEPS (W3_NVOX / 16)                     // K-steps of 16 voxels
+#define W3_NHALO ((W3_BX + 2) * W3_HY * W3_HZ)        // 1000
+#define W3_XBYTES (W3_NHALO * 64)   // 64000
+#define W3_GPLANE (W3_NVOX * 64)    // one 32-channel dy plane
 #define W3_TAPS_PER_WAVE 7
 
 bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout) {
@@ -49,7 +51,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_lo, const un
 }
 
 template <int NT>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, NT == 2 ? 1 : 2)
 conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                         const bf16* __restrict__ dy, float* __restrict__ dwp, float* __restrict__ dbias, int B, int X,
                         int Y, int Z, int Cout, int nbx, int nby, int nbz, int nsplit, int n_ci_tiles) {
@@ -94,8 +96,14 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
         toff[t] = (ex * W3_HY + ey) * W3_HZ + ez;
     }
 
-    constexpr int XP = (W3_NHALO * 4 + 255) / 256;  // 10 pieces of 16 B per thread
-    constexpr int GP = (256 * 4 * NT) / 256;         // 4*NT pieces per thread
+    // per-tap fragment base address of this lane at step 0: halo voxel (1, kh + 1, q + 1) + tap
+    const unsigned char* a_base[W3_TAPS_PER_WAVE];
+#pragma unroll
+    for (int t = 0; t < W3_TAPS_PER_WAVE; ++t)
+        a_base[t] = sX + ((W3_HY + kh + 1) * W3_HZ + (q + 1) + toff[t]) * 64 + col_off;
+
+    constexpr int XP = (W3_NHALO * 4 + 255) / 256;  // 16 pieces of 16 B per thread
+    constexpr int GP = (W3_NVOX * 4 * NT) / 256;     // 8*NT pieces per thread
     uint4 xreg[XP], greg[GP];
 
     auto load_brick = [&](int brick) {
@@ -159,28 +167,73 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
             const int co = tid % NCO, part = tid / NCO, nparts = 256 / NCO;
             const unsigned char* gp = sG + (co >> 5) * W3_GPLANE + (co & 31) * 2;
             float s = 0.f;
-            for (int v = part; v < 256; v += nparts) s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(gp + v * 64));
+            for (int v = part; v < W3_NVOX; v += nparts) s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(gp + v * 64));
             bsum += s;
         }
 
-#pragma unroll 2
-        for (int s = 0; s < 16; ++s) {
-            // K-step s: voxels (x = s >> 2, y = 2 (s & 3) + kh, z = q (+4))
-            const int vrow = 16 * s + 8 * kh + q;                                  // dy row
-            const int hrow = (((s >> 2) + 1) * W3_HY + (2 * (s & 3) + kh + 1)) * W3_HZ + (q + 1);  // x halo row, tap (0,0,0)
-            bf16x8 bfrag[NT];
+        // K-step s: voxels (x = s >> 2, y = 2 (s & 3) + kh, z = q (+4)).  One wave per SIMD, so the
+        // LDS latency has to be hidden inside the wave: while step s issues its 7 x NT MFMAs from
+        // one register set, the 7 x-fragments and the dy fragments of step s+1 are read into the
+        // other set (a whole step, ~450 cycles, of cover).  Two steps per loop trip keep every
+        // register index static.
+        auto read_b = [&](int s, bf16x8 (&bf)[NT]) {
+            const unsigned char* bp = sG + (16 * s + 8 * kh + q) * 64 + col_off;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const unsigned char* bp = sG + nt * W3_GPLANE + vrow * 64 + col_off;
-                bfrag[nt] = tr_frag(bp, bp + 4 * 64);
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = tr_frag(bp + nt * W3_GPLANE, bp + nt * W3_GPLANE + 4 * 64);
+        };
+        // byte offset of step s inside the halo brick (x = s >> 2, y = 2 (s & 3))
+        auto step_off = [&](int s) { return ((s >> 2) * W3_HY + 2 * (s & 3)) * W3_HZ * 64; };
+        auto read_a = [&](int soff, int t) {
+            const unsigned char* ap = a_base[t] + soff;
+            return tr_frag(ap, ap + 4 * 64);
+        };
+        if constexpr (NT == 2) {
+            bf16x8 A0[W3_TAPS_PER_WAVE], A1[W3_TAPS_PER_WAVE], B0[NT], B1[NT];
+    #pragma unroll
+            for (int t = 0; t < W3_TAPS_PER_WAVE; ++t) A0[t] = read_a(0, t);
+            read_b(0, B0);
+    #pragma unroll 1
+            for (int s2 = 0; s2 < W3_NSTEPS / 2; ++s2) {
+                const int so = 2 * s2 + 1, sn = min(2 * s2 + 2, W3_NSTEPS - 1);
+                const int off_o = step_off(so), off_n = step_off(sn);
+    #pragma unroll
+                for (int t = 0; t < W3_TAPS_PER_WAVE; ++t) {  // even step: compute set 0, fetch set 1
+                    A1[t] = read_a(off_o, t);
+                    if (t == 0) read_b(so, B1);
+    #pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[t], B0[nt], acc[t][nt], 0, 0, 0);
+                    if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NT, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                }
+    #pragma unroll
+                for (int t = 0; t < W3_TAPS_PER_WAVE; ++t) {  // odd step: compute set 1, fetch set 0
+                    A0[t] = read_a(off_n, t);
+                    if (t == 0) read_b(sn, B0);
+    #pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[t], B1[nt], acc[t][nt], 0, 0, 0);
+                    if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NT, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                }
             }
+        } else {
+            // NT = 1: 112 accumulator registers -> two workgroups per CU cover each other's LDS
+            // latency and staging; keep the register count under 256 with a plain loop.
+#pragma unroll 2
+            for (int s = 0; s < W3_NSTEPS; ++s) {
+                bf16x8 bf[NT];
+                read_b(s, bf);
+                const int soff = step_off(s);
 #pragma unroll
-            for (int t = 0; t < W3_TAPS_PER_WAVE; ++t) {
-                const unsigned char* ap = sX + (hrow + toff[t]) * 64 + col_off;
-                const bf16x8 afrag = tr_frag(ap, ap + 4 * 64);
+                for (int t = 0; t < W3_TAPS_PER_WAVE; ++t) {
+                    const bf16x8 af = read_a(soff, t);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[nt], acc[t][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nt], acc[t][nt], 0, 0, 0);
+                }
             }
         }
     }
@@ -211,8 +264,10 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
     const int nbricks = B * nbx * nby * nbz;
     const int n_ci = Cin / 32, n_co = Cout / (32 * NT);
     const int ntiles = n_ci * n_co;
-    // one workgroup per CU-slot: aim at ~2 x 256 workgroups overall, at most one split per brick
-    int nsplit = (512 + ntiles - 1) / ntiles;
+    // one workgroup per CU (224 accumulator registers -> one wave per SIMD): aim at 256
+    // workgroups overall, at most one split per brick.  Fewer, longer workgroups also mean fewer
+    // bytes of f32 atomics at the end (221 KB per workgroup).
+    int nsplit = ((NT == 2 ? 256 : 512) + ntiles - 1) / ntiles;
     if (nsplit > nbricks) nsplit = nbricks;
     if (nsplit < 1) nsplit = 1;
     const size_t lds = W3_XBYTES + (size_t)NT * W3_GPLANE;

@@ -63,29 +63,28 @@ resize_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, AxisMap ax, AxisMa
     o.store(y + ((((int64_t)b * ax.out + ox) * ay.out + oy) * az.out + oz) * C + lc * 8);
 }
 
-#define RS_MAXC 10
-// outputs o that read input index i, with their weights (adjoint of axis_taps)
-__device__ __forceinline__ int axis_adjoint(const AxisMap& a, int i, int (&oo)[RS_MAXC], float (&ww)[RS_MAXC]) {
-    int n = 0;
-    int lo, hi;
+// range [lo, hi] of outputs that can read input index i (a superset; weights decide)
+__device__ __forceinline__ void axis_range(const AxisMap& a, int i, int& lo, int& hi) {
     if (a.scale > 0.f) {
         lo = max(0, (int)floorf((float)(i - 1) / a.scale) - 1);
         hi = min(a.out - 1, (int)ceilf((float)(i + 1) / a.scale) + 1);
     } else {
         lo = 0; hi = a.out - 1;  // out == 1 or in == 1: every output reads input 0
     }
-    for (int o = lo; o <= hi && n < RS_MAXC; ++o) {
-        int i0, i1;
-        float w1;
-        axis_taps(a, o, i0, i1, w1);
-        float w = 0.f;
-        if (i0 == i) w += 1.0f - w1;
-        if (i1 == i) w += w1;
-        if (i0 == i || i1 == i) { oo[n] = o; ww[n] = w; ++n; }
-    }
-    return n;
+}
+// weight with which output o reads input i (adjoint of axis_taps); 0 if it does not
+__device__ __forceinline__ float axis_weight(const AxisMap& a, int o, int i) {
+    int i0, i1;
+    float w1;
+    axis_taps(a, o, i0, i1, w1);
+    float w = 0.f;
+    if (i0 == i) w += 1.0f - w1;
+    if (i1 == i) w += w1;
+    return w;
 }
 
+// adjoint gather: dx[i] = sum over outputs o of w(o, i) dy[o]; weights are recomputed on the
+// fly (a handful of VALU ops) instead of being tabulated, so nothing lives in scratch
 template <typename T>
 __global__ void __launch_bounds__(256)
 resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, AxisMap ay, AxisMap az, int C, int64_t total) {
@@ -98,27 +97,31 @@ resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, Axis
     const int iy = (int)(v % ay.in); v /= ay.in;
     const int ix = (int)(v % ax.in);
     const int b = (int)(v / ax.in);
-    int oxs[RS_MAXC], oys[RS_MAXC], ozs[RS_MAXC];
-    float wxs[RS_MAXC], wys[RS_MAXC], wzs[RS_MAXC];
-    const int nx = axis_adjoint(ax, ix, oxs, wxs);
-    const int ny = axis_adjoint(ay, iy, oys, wys);
-    const int nz = axis_adjoint(az, iz, ozs, wzs);
+    int x0, x1, y0, y1, z0, z1;
+    axis_range(ax, ix, x0, x1);
+    axis_range(ay, iy, y0, y1);
+    axis_range(az, iz, z0, z1);
     const T* gb = dy + ((int64_t)b * ax.out * ay.out * az.out) * C + lc * 8;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int a = 0; a < nx; ++a)
-        for (int bb = 0; bb < ny; ++bb) {
-            const float wxy = wxs[a] * wys[bb];
-            const T* row = gb + (((int64_t)oxs[a] * ay.out + oys[bb]) * az.out) * C;
-            for (int c = 0; c < nz; ++c) {
-                const float w = wxy * wzs[c];
+    for (int ox = x0; ox <= x1; ++ox) {
+        const float wx = axis_weight(ax, ox, ix);
+        if (wx == 0.f) continue;
+        for (int oy = y0; oy <= y1; ++oy) {
+            const float wxy = wx * axis_weight(ay, oy, iy);
+            if (wxy == 0.f) continue;
+            const T* row = gb + (((int64_t)ox * ay.out + oy) * az.out) * C;
+            for (int oz = z0; oz <= z1; ++oz) {
+                const float w = wxy * axis_weight(az, oz, iz);
+                if (w == 0.f) continue;
                 Vec8<T> t;
-                t.load(row + (int64_t)ozs[c] * C);
+                t.load(row + (int64_t)oz * C);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += w * t.v[j];
             }
         }
+    }
     Vec8<T> o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
@@ -128,12 +131,6 @@ resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, Axis
 static int resize_args_ok(int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C) {
     return B > 0 && Xi > 0 && Yi > 0 && Zi > 0 && Xo > 0 && Yo > 0 && Zo > 0 && C > 0;
 }
-static int adjoint_fits(int in, int out) {
-    if (out <= 1 || in <= 1) return out <= RS_MAXC;
-    const float scale = (float)(in - 1) / (float)(out - 1);
-    return (int)(2.0f / scale) + 5 <= RS_MAXC || out <= RS_MAXC;
-}
-
 extern "C" int tdx_resize_fwd(const void* x, void* y, int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C,
                               int dtype, void* stream) {
     TDX_CHECK_ARG(x && y && resize_args_ok(B, Xi, Yi, Zi, Xo, Yo, Zo, C));
@@ -149,7 +146,6 @@ extern "C" int tdx_resize_bwd(const void* dy, void* dx, int B, int Xi, int Yi, i
                               int dtype, void* stream) {
     TDX_CHECK_ARG(dy && dx && resize_args_ok(B, Xi, Yi, Zi, Xo, Yo, Zo, C));
     if (C % 8) return TDX_ESHAPE;
-    if (!adjoint_fits(Xi, Xo) || !adjoint_fits(Yi, Yo) || !adjoint_fits(Zi, Zo)) return TDX_ESHAPE;
     const int64_t total = (int64_t)B * Xi * Yi * Zi * (C / 8);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_bwd_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0,
                                                   as_stream(stream), (const T*)dy, (T*)dx, make_axis(Xi, Xo),
