@@ -21,7 +21,7 @@ bool conv3_mfma_supported(int C1, int C2, int Cout);
 static inline bool conv3_uses_mfma_layout(int dtype, int K, int N) { return dtype == 1 && conv3_mfma_supported(K, 0, N); }
 
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
-                      const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st);
+                      const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr);
 
 bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout);
 int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
@@ -29,3 +29,8 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
 
 int conv3_direct_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                         const Conv3Geom& g, int Cout, int dtype, bool zero_pad, hipStream_t st);
+
+// tdx_groupnorm.hip: (mean, rstd) per (b, group) from per-channel f64 (sum, sumsq)
+#define TDX_GN_REPLICAS 32  // == GN_REPLICAS in tdx_groupnorm.hip (sizes tdx_gn_workspace_bytes)
+int gn_finalize_launch(const double* acc, float* stats, int B, int C, int G, int64_t V, float eps, int replicas,
+                       hipStream_t st);

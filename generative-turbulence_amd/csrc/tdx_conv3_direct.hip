@@ -318,6 +318,28 @@ extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, con
     return conv3_direct_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, dtype, false, as_stream(stream));
 }
 
+extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, const void* wf, const float* bias,
+                                void* y, float* stats, int G, float eps, void* gn_workspace, int B, int X, int Y, int Z,
+                                int Cout, int dtype, int impl, void* stream) {
+    TDX_CHECK_ARG(x1 && wf && y && stats && gn_workspace && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && C2 >= 0);
+    TDX_CHECK_ARG(Cout > 0 && G > 0 && (Cout % G) == 0 && (C2 == 0 || x2));
+    const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout));
+    if (!use_mfma) {  // unfused: conv, then the streaming statistics pass
+        int rc = tdx_conv3_fwd(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, dtype, impl, stream);
+        if (rc != TDX_OK) return rc;
+        return tdx_gn_stats(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, stream);
+    }
+    if (!mfma_ok(dtype, C1, C2, Cout)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
+    hipStream_t st = as_stream(stream);
+    double* acc = (double*)gn_workspace;
+    hipError_t e = hipMemsetAsync(acc, 0, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
+    if (e != hipSuccess) return (int)e;
+    Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
+    int rc = conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, st, acc);
+    if (rc != TDX_OK) return rc;
+    return gn_finalize_launch(acc, stats, B, Cout, G, (int64_t)X * Y * Z, eps, TDX_GN_REPLICAS, st);
+}
+
 extern "C" size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z, int Cin, int dtype, int impl) {
     (void)impl;
     return (size_t)B * (X + 2) * (Y + 2) * (Z + 2) * Cin * (dtype == TDX_BF16 ? 2 : 4) + 256;

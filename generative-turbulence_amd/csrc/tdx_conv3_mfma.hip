@@ -63,7 +63,7 @@ template <int NT, bool ZERO_PAD>
 __global__ void __launch_bounds__(256, 2)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                   const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, Conv3Geom g,
-                  int Cout, int nbx, int nby, int nbz) {
+                  int Cout, int nbx, int nby, int nbz, double* __restrict__ gn_acc) {
     constexpr int BN = NT * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;
@@ -242,7 +242,14 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             }
         }
     __syncthreads();
+    // store loop: thread -> 16-B chunk (tid % CHUNKS) of voxels tid / CHUNKS + (256 / CHUNKS) i.
+    // The same registers feed the fused GroupNorm statistics (forward only): per-channel sum and
+    // sum of squares of the (bf16-rounded) tile, reduced over the brick through LDS and merged
+    // across bricks with one f64 atomic per (channel, moment) -- saves the read pass over y.
     constexpr int CHUNKS = BN / 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
 #pragma unroll
     for (int i = 0; i < CHUNKS; ++i) {
         const int p = tid + i * 256;
@@ -251,12 +258,41 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         if (ox < g.Xo && oy < g.Yo && oz < g.Zo) {
             const uint4 val = *reinterpret_cast<const uint4*>(sO + out_addr<BN>(v, cidx));
             *reinterpret_cast<uint4*>(y + ((((int64_t)b * g.Xo + ox) * g.Yo + oy) * g.Zo + oz) * Cout + n0 + cidx * 8) = val;
+            if (gn_acc != nullptr) {
+                const unsigned wds[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(wds[e] << 16), hi = __uint_as_float(wds[e] & 0xffff0000u);
+                    s1[2 * e] += lo; s2[2 * e] += lo * lo;
+                    s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
+                }
+            }
+        }
+    }
+    if (gn_acc != nullptr) {
+        constexpr int NP = 256 / CHUNKS;  // threads per chunk column
+        float* red = reinterpret_cast<float*>(smem + 256 * BN * 2);  // [NP][BN][2], behind the output tile
+        const int cidx = tid % CHUNKS, part = tid / CHUNKS;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(part * BN + cidx * 8 + e) * 2] = s1[e];
+            red[(part * BN + cidx * 8 + e) * 2 + 1] = s2[e];
+        }
+        __syncthreads();
+        if (tid < BN * 2) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int pp = 0; pp < NP; ++pp) t += red[pp * BN * 2 + tid];
+            // 32 replicas of the [B][Cout][2] table, picked by brick index: all workgroups of a
+            // sample would otherwise hammer the same 2*Cout addresses
+            const int rep = blockIdx.x & (TDX_GN_REPLICAS - 1);
+            atomicAdd(&gn_acc[(((size_t)rep * g.B + b) * Cout + n0) * 2 + tid], (double)t);
         }
     }
 }
 
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
-                      const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st) {
+                      const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc) {
     const int nbx = ceil_div(g.Xo, M3_BX), nby = ceil_div(g.Yo, M3_BY), nbz = ceil_div(g.Zo, M3_BZ);
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const int BN = NT * 32;
@@ -273,7 +309,7 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
             attr_set = true;                                                                                         \
         }                                                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2,                 \
-                           (const bf16*)wp, bias, (bf16*)y, g, Cout, nbx, nby, nbz);                                 \
+                           (const bf16*)wp, bias, (bf16*)y, g, Cout, nbx, nby, nbz, gn_acc);                         \
     } while (0)
     if (NT == 2) { if (zero_pad) M3_LAUNCH(2, true); else M3_LAUNCH(2, false); }
     else         { if (zero_pad) M3_LAUNCH(1, true); else M3_LAUNCH(1, false); }

@@ -62,30 +62,46 @@ gn_stats_kernel(const T* __restrict__ x, double* __restrict__ acc, int64_t V, in
 }
 
 // per (b, g): mean / rstd from per-channel (sum, sumsq)
-__global__ void gn_stats_finalize(const double* __restrict__ acc, float* __restrict__ stats, int B, int C, int G,
-                                  int64_t V, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * G) return;
+// acc holds R replicas of [B][C][2] (replicas spread the atomics of the fused conv epilogue).
+// One wave per (b, group): lanes split the R * cpg (replica, channel) pairs.
+__global__ void __launch_bounds__(64)
+gn_stats_finalize(const double* __restrict__ acc, float* __restrict__ stats, int B, int C, int G, int64_t V, float eps,
+                  int R) {
+    const int i = blockIdx.x;  // b * G + g
     const int b = i / G, g = i - b * G;
     const int cpg = C / G;
     double s = 0.0, ss = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        s += acc[((size_t)b * C + c) * 2];
-        ss += acc[((size_t)b * C + c) * 2 + 1];
+    for (int k = threadIdx.x; k < R * cpg; k += 64) {
+        const int r = k / cpg, c = g * cpg + (k - r * cpg);
+        const double* a = acc + (((size_t)r * B + b) * C + c) * 2;
+        s += a[0];
+        ss += a[1];
     }
-    const double n = (double)cpg * (double)V;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[2 * i] = (float)mean;
-    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (threadIdx.x == 0) {
+        const double n = (double)cpg * (double)V;
+        const double mean = s / n;
+        double var = ss / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * i] = (float)mean;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
+#define GN_REPLICAS 32
 extern "C" size_t tdx_gn_workspace_bytes(int B, int C) {
-    return (size_t)B * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + 64;
+    return (size_t)GN_REPLICAS * B * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + 64;
 }
 
 static int gn_shape_ok(int C, int G) { return C > 0 && G > 0 && C % 8 == 0 && C % G == 0 && (C / 8) <= GN_THREADS; }
+
+// used by tdx_conv3_fwd_gn (statistics accumulated in the conv epilogue)
+int gn_finalize_launch(const double* acc, float* stats, int B, int C, int G, int64_t V, float eps, int replicas,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(gn_stats_finalize, dim3(B * G), dim3(64), 0, st, acc, stats, B, C, G, V, eps, replicas);
+    return tdx_launch_status();
+}
 
 extern "C" int tdx_gn_stats(const void* x, float* stats, int B, int64_t V, int C, int G, float eps, int dtype,
                             void* workspace, void* stream) {
@@ -97,8 +113,7 @@ extern "C" int tdx_gn_stats(const void* x, float* stats, int B, int64_t V, int C
     dim3 grid(ceil_div(V, GN_VOX_PER_BLOCK), B);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(GN_THREADS), 0, as_stream(stream),
                                                   (const T*)x, acc, V, C));
-    hipLaunchKernelGGL(gn_stats_finalize, dim3(ceil_div(B * G, 64)), dim3(64), 0, as_stream(stream), acc, stats, B, C, G,
-                       V, eps);
+    hipLaunchKernelGGL(gn_stats_finalize, dim3(B * G), dim3(64), 0, as_stream(stream), acc, stats, B, C, G, V, eps, 1);
     return tdx_launch_status();
 }
 

@@ -90,13 +90,14 @@ class Block(nn.Module):
         self._fused_act = isinstance(self.act, nn.SiLU)
 
     def forward(self, x, scale_shift=None, x2=None, res=None):
-        h = ops.conv3(x, self.conv.weight, self.conv.bias, x2=x2)
+        G = _norm_groups(self.norm)
+        h, stats = ops.conv3_gn_stats(x, self.conv.weight, self.conv.bias, G, self.norm.eps, x2=x2)
         scale, shift = scale_shift if scale_shift is not None else (None, None)
         if self._fused_act:
-            return ops.gn_film_silu(h, self.norm.weight, self.norm.bias, _norm_groups(self.norm), scale, shift,
-                                    res=res, act=True, eps=self.norm.eps)
-        h = ops.gn_film_silu(h, self.norm.weight, self.norm.bias, _norm_groups(self.norm), scale, shift, act=False,
-                             eps=self.norm.eps)
+            return ops.gn_film_silu(h, self.norm.weight, self.norm.bias, G, scale, shift, res=res, act=True,
+                                    eps=self.norm.eps, stats=stats)
+        h = ops.gn_film_silu(h, self.norm.weight, self.norm.bias, G, scale, shift, act=False, eps=self.norm.eps,
+                             stats=stats)
         h = self.act(h)
         return h if res is None else h + res
 

@@ -209,7 +209,7 @@ def _packed_conv3(weight: torch.Tensor, dtype: torch.dtype):
 
 class _Conv3(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias):
+    def forward(ctx, x1, x2, weight, bias, gn_groups=0, gn_eps=1e-5):
         B, X, Y, Z, C1 = _grid(x1)
         C2 = 0 if x2 is None else x2.shape[-1]
         Cout = weight.shape[0]
@@ -219,16 +219,25 @@ class _Conv3(torch.autograd.Function):
         dt = x1.dtype
         wf, wb = _packed_conv3(weight, dt)
         y = torch.empty((B, X, Y, Z, Cout), dtype=dt, device=x1.device)
-        L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Cout,
-               L.dtype_code(dt), L.conv_impl(), L.stream(), work=54.0 * (C1 + C2) * Cout * B * X * Y * Z)
+        flops = 54.0 * (C1 + C2) * Cout * B * X * Y * Z
         ctx.save_for_backward(x1, x2, wb)
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
+        if gn_groups:
+            stats = torch.empty((B, gn_groups, 2), dtype=torch.float32, device=x1.device)
+            ws = _ws(L.query("tdx_gn_workspace_bytes", B, Cout), x1.device)
+            L.call("tdx_conv3_fwd_gn", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats),
+                   gn_groups, float(gn_eps), L.ptr(ws), B, X, Y, Z, Cout, L.dtype_code(dt), L.conv_impl(), L.stream(),
+                   work=flops)
+            ctx.mark_non_differentiable(stats)
+            return y, stats
+        L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Cout,
+               L.dtype_code(dt), L.conv_impl(), L.stream(), work=flops)
         return y
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gstats=None):
         x1, x2, wb = ctx.saved_tensors
         B, X, Y, Z, C1 = _grid(x1)
         C2 = 0 if x2 is None else x2.shape[-1]
@@ -249,12 +258,18 @@ class _Conv3(torch.autograd.Function):
             ws = _ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cin, Cout, impl), dev)
             L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z,
                    Cout, code, impl, L.ptr(ws), st, work=54.0 * Cin * Cout * B * X * Y * Z)
-        return gx1, gx2, gw, gb
+        return gx1, gx2, gw, gb, None, None
 
 
 def conv3(x1, weight, bias=None, x2=None):
     """Replicate-padded 3x3x3 convolution of the channel concatenation [x1 | x2]."""
     return _Conv3.apply(x1, x2, weight, bias)
+
+
+def conv3_gn_stats(x1, weight, bias, groups, eps=1e-5, x2=None):
+    """conv3 plus the GroupNorm(groups) statistics (B, groups, 2) of its output, accumulated in
+    the conv epilogue.  Returns (y, stats); feed stats to gn_film_silu(..., stats=stats)."""
+    return _Conv3.apply(x1, x2, weight, bias, groups, eps)
 
 
 # --------------------------------------------------------------------------- conv 1x1x1
@@ -319,7 +334,7 @@ def conv1(x1, weight, bias=None, x2=None, add=None):
 
 class _GnFilmSilu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, scale, shift, res, groups, act, eps):
+    def forward(ctx, x, gamma, beta, scale, shift, res, groups, act, eps, stats=None):
         B, X, Y, Z, Cc = _grid(x)
         V = X * Y * Z
         x = x.contiguous()
@@ -329,9 +344,10 @@ class _GnFilmSilu(torch.autograd.Function):
         if scale is not None:
             scale = scale.detach().reshape(B, Cc).float().contiguous()
             shift = shift.detach().reshape(B, Cc).float().contiguous()
-        stats = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
-        ws = _ws(L.query("tdx_gn_workspace_bytes", B, Cc), dev)
-        L.call("tdx_gn_stats", L.ptr(x), L.ptr(stats), B, V, Cc, groups, float(eps), code, L.ptr(ws), st)
+        if stats is None:
+            stats = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
+            ws = _ws(L.query("tdx_gn_workspace_bytes", B, Cc), dev)
+            L.call("tdx_gn_stats", L.ptr(x), L.ptr(stats), B, V, Cc, groups, float(eps), code, L.ptr(ws), st)
         y = torch.empty_like(x)
         L.call("tdx_gn_apply", L.ptr(x), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), L.ptr(res),
                L.ptr(y), B, V, Cc, groups, int(act), code, st)
@@ -359,12 +375,13 @@ class _GnFilmSilu(torch.autograd.Function):
         L.call("tdx_gn_bwd", L.ptr(x), L.ptr(gy), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift),
                L.ptr(gx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dscale), L.ptr(dshift), B, V, Cc, groups, act, code,
                L.ptr(ws), st)
-        return gx, dgamma, dbeta, dscale, dshift, (gy if has_res else None), None, None, None
+        return gx, dgamma, dbeta, dscale, dshift, (gy if has_res else None), None, None, None, None
 
 
-def gn_film_silu(x, gamma, beta, groups, scale=None, shift=None, res=None, act=True, eps=1e-5):
-    """y = [silu]( GN(x) * (1 + scale) + shift ) + res;  scale/shift are (B, C) or None."""
-    return _GnFilmSilu.apply(x, gamma, beta, scale, shift, res, groups, act, eps)
+def gn_film_silu(x, gamma, beta, groups, scale=None, shift=None, res=None, act=True, eps=1e-5, stats=None):
+    """y = [silu]( GN(x) * (1 + scale) + shift ) + res;  scale/shift are (B, C) or None.
+    `stats` (B, groups, 2) may come from conv3_gn_stats (else a statistics pass is run)."""
+    return _GnFilmSilu.apply(x, gamma, beta, scale, shift, res, groups, act, eps, stats)
 
 
 # --------------------------------------------------------------------------- trilinear resize

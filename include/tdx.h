@@ -74,6 +74,14 @@ int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout,
 int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, const void* wf, const float* bias, void* y,
                   int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* stream);
 
+/* Same convolution, additionally producing the GroupNorm(G, Cout, eps) statistics of its own
+ * output -- stats [B][G][2] = (mean, rstd), as tdx_gn_stats would -- from per-channel moments
+ * accumulated in the conv epilogue (Block.conv -> Block.norm, ddpm.py:169-170), which saves the
+ * separate read pass over y.  gn_workspace: tdx_gn_workspace_bytes(B, Cout). */
+int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, const void* wf, const float* bias, void* y,
+                     float* stats, int G, float eps, void* gn_workspace, int B, int X, int Y, int Z, int Cout,
+                     int dtype, int impl, void* stream);
+
 /* Data gradient of the above: dx[b,u,:] = sum over (v,tap) with clamp(v+tap) == u of
  * wf[tap][:, :] dy[b,v,:]  (adjoint of the replicate-padded conv, halo folded back onto
  * the boundary).  The result has C1 + C2 channels and is split into dx1 / dx2 (dx2 may be

@@ -392,3 +392,29 @@ def test_encode_decode_fused(dtype, with_c, D):
     assert rel_l2(out.cpu(), F.conv3d(hr, wr, br)) < 1e-5
     assert rel_l2(ncv(hd.grad.float().cpu()), hr.grad) < tol
     assert rel_l2(wd.grad.cpu(), wr.grad) < 1e-4 and rel_l2(bd.grad.cpu(), br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("case", [(2, 64, 0, 64, 9, 10, 7, 8), (1, 32, 32, 32, 8, 8, 8, 8), (2, 16, 0, 96, 5, 4, 3, 1), (1, 8, 0, 16, 6, 5, 4, 8)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3_with_fused_gn_statistics(case, dtype):
+    """tdx_conv3_fwd_gn: statistics accumulated in the conv epilogue == the streaming
+    statistics pass over the stored conv output (ragged bricks included)."""
+    from turbdiff_amd import ops
+
+    B, C1, C2, Cout, X, Y, Z, G = case
+    d = dev()
+    x1 = rnd(B, X, Y, Z, C1, seed=1).to(d).to(dtype)
+    x2 = rnd(B, X, Y, Z, C2, seed=2).to(d).to(dtype) if C2 else None
+    w = rnd(Cout, C1 + C2, 3, 3, 3, seed=3, scale=0.05).to(d)
+    b = rnd(Cout, seed=4).to(d)
+    gamma, beta = (1 + 0.2 * rnd(Cout, seed=5)).to(d), (0.1 * rnd(Cout, seed=6)).to(d)
+    y, stats = ops.conv3_gn_stats(x1, w, b, G, 1e-5, x2=x2)
+    y_ref = ops.conv3(x1, w, b, x2=x2)
+    assert torch.equal(y, y_ref)
+    yr = ncv(y.float().cpu()).double().reshape(B, G, -1)
+    mean, var = yr.mean(-1), yr.var(-1, unbiased=False)
+    assert torch.allclose(stats[..., 0].cpu().double(), mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(stats[..., 1].cpu().double(), (var + 1e-5).rsqrt(), rtol=1e-4)
+    a = ops.gn_film_silu(y, gamma, beta, G, stats=stats)
+    a_ref = ops.gn_film_silu(y, gamma, beta, G)
+    assert rel_l2(a.float(), a_ref.float()) < 1e-5
