@@ -28,11 +28,12 @@
 //   weights: [half][tap*BN + n], 16 B each
 #include "tdx_common.h"
 #include "tdx_conv3.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-#define M3_BX 4
+#define M3_BX 4                                // x extent of the brick at MT = 2 (2*MT in general)
 #define M3_BY 8
 #define M3_BZ 8
 #define M3_HX (M3_BX + 2)
@@ -59,15 +60,22 @@ __device__ __forceinline__ int out_addr(int v, int c) {
     return v * 64 + ((c ^ ((v >> 1) & 3)) << 4);
 }
 
-template <int NT, bool ZERO_PAD>
-__global__ void __launch_bounds__(256, 2)
+// MT = 32-voxel M tiles per wave: 2 (4x8x8 brick, 2 workgroups/CU) or 4 (8x8x8 brick, one
+// workgroup/CU with twice the register tile -> 25 % fewer LDS fragment bytes per MFMA).
+template <int NT, int MT, bool ZERO_PAD>
+__global__ void __launch_bounds__(256, MT == 2 ? 2 : 1)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                   const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, Conv3Geom g,
                   int Cout, int nbx, int nby, int nbz, double* __restrict__ gn_acc) {
     constexpr int BN = NT * 32;
+    constexpr int BX = 2 * MT, HX = BX + 2;
+    constexpr int NVOX = BX * M3_BY * M3_BZ;                 // 256 / 512 output voxels
+    constexpr int NHALO = HX * M3_HY * M3_HZ;                // 600 / 1000 staged voxels
+    constexpr int APLANE = HX * M3_HY * M3_SZ * 16 + 64;     // one half-plane of the brick image
+    constexpr int BRICK_BYTES = 2 * APLANE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;
-    unsigned char* sB = smem + M3_BRICK_BYTES;
+    unsigned char* sB = smem + BRICK_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -80,13 +88,13 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     const int bx = bid % nbx; bid /= nbx;
     const int b = bid;
     const int n0 = blockIdx.y * BN;
-    const int ox0 = bx * M3_BX, oy0 = by * M3_BY, oz0 = bz * M3_BZ;
+    const int ox0 = bx * BX, oy0 = by * M3_BY, oz0 = bz * M3_BZ;
     const int Cin = C1 + C2;
 
     // ---- staging plan for the input brick: 1200 16-B pieces, <= 5 per thread.
     // a_src: (voxel index in the input grid) * 2 + half, or -1 for zero fill / no piece
-    constexpr int A_PIECES = M3_NVOX_HALO * 2;
-    constexpr int A_PER_THREAD = (A_PIECES + 255) / 256;  // 5
+    constexpr int A_PIECES = NHALO * 2;
+    constexpr int A_PER_THREAD = (A_PIECES + 255) / 256;  // 5 / 8
     constexpr int B_PIECES = 27 * BN * 2;
     constexpr int B_PER_THREAD = (B_PIECES + 255) / 256;  // 14 (NT=2) / 7 (NT=1)
     int a_src[A_PER_THREAD];
@@ -101,7 +109,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             const int hv = ((p >> 3) << 2) + (p & 3), half = (p >> 2) & 1;
             const int hx = hv / (M3_HY * M3_HZ), rem = hv - hx * (M3_HY * M3_HZ);
             const int hy = rem / M3_HZ, hz = rem - hy * M3_HZ;
-            a_dst[i] = brick_addr((hx * M3_HY + hy) * M3_SZ + hz, half);
+            a_dst[i] = half * APLANE + ((hx * M3_HY + hy) * M3_SZ + hz) * 16;
             int sx = ox0 + hx - 1 + g.off, sy = oy0 + hy - 1 + g.off, sz = oz0 + hz - 1 + g.off;
             bool ok = true;
             if (ZERO_PAD) {
@@ -154,10 +162,11 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     };
 
     // ---- per-lane fragment bases
-    int a_h[2];
+    // M tile mt of wave w: x = w*(MT/2) + (mt >> 1), y = 4*(mt & 1) + (r & 3), z = r >> 2
+    int a_h[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-        a_h[mt] = ((wave + 1) * M3_HY + (4 * mt + (r & 3) + 1)) * M3_SZ + ((r >> 2) + 1);
+    for (int mt = 0; mt < MT; ++mt)
+        a_h[mt] = ((wave * (MT / 2) + (mt >> 1) + 1) * M3_HY + (4 * (mt & 1) + (r & 3) + 1)) * M3_SZ + ((r >> 2) + 1);
     int b_off[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -165,11 +174,11 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         b_off[nt] = hh * B_PLANE + n * 16;
     }
 
-    f32x16 acc[NT][2];  // D[row = channel][col = voxel]
+    f32x16 acc[NT][MT];  // D[row = channel][col = voxel]
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
 
@@ -182,36 +191,36 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         if (c + 1 < nchunks) load_slice(c + 1);  // in flight during the MFMAs below
 
         // fragments of tap t+1 are read while the MFMAs of tap t issue (two register sets)
-        bf16x8 xf[2][2], wf[2][NT];
+        bf16x8 xf[2][MT], wf[2][NT];
         auto read_frags = [&](int tap, int buf) {
             const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
             const int toff = (ex * M3_HY + ey) * M3_SZ + ez;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-                xf[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + brick_addr(a_h[mt] + toff, hh));
+            for (int mt = 0; mt < MT; ++mt)
+                xf[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + hh * APLANE + (a_h[mt] + toff) * 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 wf[buf][nt] = *reinterpret_cast<const bf16x8*>(sB + tap * (BN * 16) + b_off[nt]);
         };
         read_frags(0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);  // DS_READ: tap 0's fragments
+        __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // DS_READ: tap 0's fragments
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
             if (tap + 1 < 27) read_frags(tap + 1, (tap + 1) & 1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap & 1][nt], xf[tap & 1][mt], acc[nt][mt], 0, 0, 0);
             // pin the interleave: one fragment read of tap+1 behind each MFMA of tap
             if (tap + 1 < 27) {
 #pragma unroll
-                for (int k = 0; k < 2 * NT; ++k) {
+                for (int k = 0; k < MT * NT; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                    if (k < 2 + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS_READ
+                    if (k < MT + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS_READ
                 }
             } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
             }
         }
     }
@@ -220,7 +229,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     // (x = w, y = 4 mt + (r & 3), z = r >> 2) and channels nt*32 + 8 j + 4 hh + (0..3) in
     // accumulator registers 4 j .. 4 j + 3.
     __syncthreads();
-    unsigned char* sO = smem;  // [256 voxels][BN] bf16, voxel v = (x*8 + y)*8 + z
+    unsigned char* sO = smem;  // [NVOX voxels][BN] bf16, voxel v = (x*8 + y)*8 + z
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -232,8 +241,8 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
                 for (int e = 0; e < 4; ++e) bv[e] = bias[n0 + ch + e];
             }
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int v = (wave * 8 + 4 * mt + (r & 3)) * 8 + (r >> 2);
+            for (int mt = 0; mt < MT; ++mt) {
+                const int v = ((wave * (MT / 2) + (mt >> 1)) * 8 + 4 * (mt & 1) + (r & 3)) * 8 + (r >> 2);
                 const unsigned lo = (unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j] + bv[0]) |
                                     ((unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 1] + bv[1]) << 16);
                 const unsigned hi = (unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 2] + bv[2]) |
@@ -251,7 +260,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < CHUNKS; ++i) {
+    for (int i = 0; i < CHUNKS * NVOX / 256; ++i) {
         const int p = tid + i * 256;
         const int v = p / CHUNKS, cidx = p % CHUNKS;
         const int ox = ox0 + (v >> 6), oy = oy0 + ((v >> 3) & 7), oz = oz0 + (v & 7);
@@ -271,7 +280,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     }
     if (gn_acc != nullptr) {
         constexpr int NP = 256 / CHUNKS;  // threads per chunk column
-        float* red = reinterpret_cast<float*>(smem + 256 * BN * 2);  // [NP][BN][2], behind the output tile
+        float* red = reinterpret_cast<float*>(smem + NVOX * BN * 2);  // [NP][BN][2], behind the output tile
         const int cidx = tid % CHUNKS, part = tid / CHUNKS;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -293,15 +302,21 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                       const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc) {
-    const int nbx = ceil_div(g.Xo, M3_BX), nby = ceil_div(g.Yo, M3_BY), nbz = ceil_div(g.Zo, M3_BZ);
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const int BN = NT * 32;
+    // big register tile (8x8x8 bricks) where the grid has room for it and there is enough K to amortise
+    // its longer prologue/epilogue; the env switch is for A/B measurements
+    static const int force_mt = getenv("TDX_CONV3_MT") ? atoi(getenv("TDX_CONV3_MT")) : 0;
+    int MT = 2;  // measured: MT = 4 (one workgroup/CU) is 5-30 % slower on every layer of the U-Net
+    if (force_mt == 2 || force_mt == 4) MT = force_mt;
+    const int BX = 2 * MT;
+    const int nbx = ceil_div(g.Xo, BX), nby = ceil_div(g.Yo, M3_BY), nbz = ceil_div(g.Zo, M3_BZ);
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31)) return TDX_ESHAPE;  // a_src packs (voxel, half) in 31 bits
     dim3 grid((unsigned)((int64_t)g.B * nbx * nby * nbz), Cout / BN);
-    const size_t lds = M3_BRICK_BYTES + (size_t)27 * BN * 32 + 128;  // two padded half-planes each
-#define M3_LAUNCH(NTV, ZP)                                                                                           \
+    const size_t lds = (size_t)2 * ((BX + 2) * M3_HY * M3_SZ * 16 + 64) + (size_t)27 * BN * 32 + 128;
+#define M3_LAUNCH(NTV, MTV, ZP)                                                                                      \
     do {                                                                                                             \
-        auto kern = conv3_mfma_kernel<NTV, ZP>;                                                                      \
+        auto kern = conv3_mfma_kernel<NTV, MTV, ZP>;                                                                 \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -311,8 +326,10 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2,                 \
                            (const bf16*)wp, bias, (bf16*)y, g, Cout, nbx, nby, nbz, gn_acc);                         \
     } while (0)
-    if (NT == 2) { if (zero_pad) M3_LAUNCH(2, true); else M3_LAUNCH(2, false); }
-    else         { if (zero_pad) M3_LAUNCH(1, true); else M3_LAUNCH(1, false); }
+    if (NT == 2 && MT == 4) { if (zero_pad) M3_LAUNCH(2, 4, true); else M3_LAUNCH(2, 4, false); }
+    else if (NT == 2)       { if (zero_pad) M3_LAUNCH(2, 2, true); else M3_LAUNCH(2, 2, false); }
+    else if (MT == 4)       { if (zero_pad) M3_LAUNCH(1, 4, true); else M3_LAUNCH(1, 4, false); }
+    else                    { if (zero_pad) M3_LAUNCH(1, 2, true); else M3_LAUNCH(1, 2, false); }
 #undef M3_LAUNCH
     return tdx_launch_status();
 }
