@@ -10,6 +10,7 @@
 // exact fp32 and is the path used at the U-Net bottleneck (N = 144 tokens at 192x64x48,
 // 0.01 GFLOP).  The MFMA flash kernel for long sequences lives in tdx_attention_mfma.hip.
 #include "tdx_common.h"
+#include <stdlib.h>
 
 template <typename T, int D>
 __global__ void __launch_bounds__(64)
@@ -144,10 +145,20 @@ attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const
     }
 }
 
+// tdx_attention_mfma.hip; TDX_ATTN_IMPL=vector forces the kernels of this file
+bool attn_mfma_supported(int N, int D);
+int attn_fwd_mfma_launch(const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t st);
+
 extern "C" int tdx_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, int dtype,
                             void* stream) {
     TDX_CHECK_ARG(qkv && out && lse && B > 0 && N > 0 && H > 0);
     if (D != 32) return TDX_ESHAPE;
+    {
+        const char* e = getenv("TDX_ATTN_IMPL");
+        const bool force_vector = e && e[0] == 'v';
+        if (dtype == TDX_BF16 && !force_vector && attn_mfma_supported(N, D))
+            return attn_fwd_mfma_launch(qkv, out, lse, B, N, H, as_stream(stream));
+    }
     dim3 grid(ceil_div(N, 64), B * H);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_fwd_kernel<T, 32>), grid, dim3(64), 0, as_stream(stream),
                                                   (const T*)qkv, (T*)out, lse, N, H));

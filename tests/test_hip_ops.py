@@ -418,3 +418,59 @@ def test_conv3_with_fused_gn_statistics(case, dtype):
     a = ops.gn_film_silu(y, gamma, beta, G, stats=stats)
     a_ref = ops.gn_film_silu(y, gamma, beta, G)
     assert rel_l2(a.float(), a_ref.float()) < 1e-5
+
+
+@pytest.mark.parametrize("N", [256, 1000, 4096])
+def test_attention_mfma_forward(N, monkeypatch):
+    """bf16 MFMA flash attention (used for N >= 256) vs the oracle on the same bf16 inputs"""
+    from turbdiff_amd import ops
+
+    B, H, D = 2, 4, 32
+    qkv = q(rnd(B, N, 3 * H * D, seed=1), torch.bfloat16)
+    qq, kk, vv = (p.reshape(B, N, H, D).transpose(1, 2).double() for p in qkv.chunk(3, dim=-1))
+    ref = O.sdpa(qq, kk, vv).transpose(1, 2).reshape(B, N, H * D)
+    qd = qkv.to(dev()).bfloat16()
+    out = ops.attention(qd, H)
+    assert rel_l2(out.float().cpu(), ref) < 1e-2
+    # the vector-ALU kernel on the same input (exact fp32 softmax): agree to bf16 rounding
+    monkeypatch.setenv("TDX_ATTN_IMPL", "vector")
+    out_v = ops.attention(qd, H)
+    assert rel_l2(out.float(), out_v.float()) < 1e-2
+    # backward (vector-ALU kernels, driven by the MFMA forward's out / lse)
+    monkeypatch.delenv("TDX_ATTN_IMPL")
+    if N <= 1000:
+        refq = qkv.double().requires_grad_()
+        q2, k2, v2 = (p.reshape(B, N, H, D).transpose(1, 2) for p in refq.chunk(3, dim=-1))
+        go = q(rnd(B, N, H * D, seed=2), torch.bfloat16)
+        O.sdpa(q2, k2, v2).transpose(1, 2).reshape(B, N, H * D).backward(go.double())
+        qg = qd.clone().requires_grad_()
+        ops.attention(qg, H).backward(go.to(dev()).bfloat16())
+        assert rel_l2(qg.grad.float().cpu(), refq.grad) < 3e-2
+
+
+def test_attention_full_config5_size(monkeypatch):
+    """BASELINE config 5: N = 96*32*24 = 73 728 tokens, 4 heads x 32 (too large for the CPU
+    oracle's N x N matrix): MFMA kernel vs the exact vector-ALU kernel on a query subset is
+    replaced by two size-independent properties -- softmax rows sum to one (V = const gives
+    O = const) and permuting the keys/values together leaves the output unchanged."""
+    from turbdiff_amd import ops
+
+    B, H, D, N = 1, 4, 32, 96 * 32 * 24
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(0)
+    qkv = torch.randn(B, N, 3 * H * D, device=d, generator=g).bfloat16()
+    out = ops.attention(qkv, H)
+    assert torch.isfinite(out.float()).all()
+    # (1) constant V -> output equals that constant
+    qc = qkv.clone()
+    qc[..., 2 * H * D:] = 0.75
+    oc = ops.attention(qc, H)
+    assert (oc.float() - 0.75).abs().max().item() < 8e-3
+    # (2) key/value permutation invariance
+    perm = torch.randperm(N, device=d, generator=g)
+    qp = qkv.clone()
+    qp[:, :, H * D:] = qkv[:, perm, H * D:]
+    op = ops.attention(qp, H)
+    assert rel_l2(op.float(), out.float()) < 5e-3
+    # (3) exact vector kernel on the same input, first 4096 queries only would need a sliced API;
+    #     instead compare full outputs at a reduced size inside test_attention_mfma_forward
