@@ -219,6 +219,70 @@ conv3_fold_kernel(const T* __restrict__ dpad, T* __restrict__ dx1, int C1, T* __
     o.store(dst);
 }
 
+// Face fix-up of the MFMA data gradient: the conv kernel has already written the interior term
+// dpad[u + 1] into dx; boundary voxels additionally receive the halo-shell positions that clamp
+// onto them.  One thread per (boundary voxel, 8-channel vector); the boundary set is enumerated
+// without duplicates as  x-faces | y-faces minus x-faces | z-faces minus x- and y-faces.
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv3_fold_faces_kernel(const T* __restrict__ dpad, T* __restrict__ dx1, int C1, T* __restrict__ dx2, int C2, int B,
+                        int X, int Y, int Z, int64_t nface, int64_t total) {
+    const int C = C1 + C2;
+    const int L = C >> 3;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lc = (int)(i % L);
+    int64_t f = i / L;
+    const int b = (int)(f / nface);
+    f -= (int64_t)b * nface;
+    // decode boundary voxel index f
+    const int nx = (X > 1) ? 2 : 1, ny = (Y > 1) ? 2 : 1, nz = (Z > 1) ? 2 : 1;
+    const int Xi = X - nx, Yi = Y - ny;  // interior extents along x / y (voxels not on those faces)
+    int ux, uy, uz;
+    const int64_t n_xf = (int64_t)nx * Y * Z;
+    const int64_t n_yf = (int64_t)ny * Xi * Z;
+    if (f < n_xf) {
+        const int s = (int)(f / ((int64_t)Y * Z));
+        const int rem = (int)(f - (int64_t)s * Y * Z);
+        ux = s == 0 ? 0 : X - 1; uy = rem / Z; uz = rem % Z;
+    } else if (f < n_xf + n_yf) {
+        f -= n_xf;
+        const int s = (int)(f / ((int64_t)Xi * Z));
+        const int rem = (int)(f - (int64_t)s * Xi * Z);
+        uy = s == 0 ? 0 : Y - 1; ux = 1 + rem / Z; uz = rem % Z;
+    } else {
+        f -= n_xf + n_yf;
+        const int s = (int)(f / ((int64_t)Xi * Yi));
+        const int rem = (int)(f - (int64_t)s * Xi * Yi);
+        uz = s == 0 ? 0 : Z - 1; ux = 1 + rem / Yi; uy = 1 + rem % Yi;
+    }
+    int x0, x1, y0, y1, z0, z1;
+    fold_range(ux, X, x0, x1);
+    fold_range(uy, Y, y0, y1);
+    fold_range(uz, Z, z0, z1);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const int Xp = X + 2, Yp = Y + 2, Zp = Z + 2;
+    for (int px = x0; px <= x1; ++px)
+        for (int py = y0; py <= y1; ++py)
+            for (int pz = z0; pz <= z1; ++pz) {
+                if (px == ux + 1 && py == uy + 1 && pz == uz + 1) continue;  // interior term is already in dx
+                Vec8<T> t;
+                t.load(dpad + ((((int64_t)b * Xp + px) * Yp + py) * Zp + pz) * C + lc * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += t.v[j];
+            }
+    const int64_t vox = (((int64_t)b * X + ux) * Y + uy) * Z + uz;
+    const int c = lc * 8;
+    T* dst = (c < C1) ? dx1 + vox * C1 + c : dx2 + vox * C2 + (c - C1);
+    Vec8<T> o;
+    o.load(dst);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] += acc[j];
+    o.store(dst);
+}
+
 // ------------------------------------------------------------------ direct weight grad ---
 // dwp[tap][ci][co] += sum over a chunk of voxels of x[clamp(v+tap), ci] * dy[v, co]
 #define D3W_VOX 8192
@@ -358,6 +422,21 @@ extern "C" int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int
     int rc;
     if (use_mfma) {
         if (!mfma_ok(dtype, Cout, 0, Cin)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
+        const bool direct_ok = !accumulate && (C1 % 64 == 0 || C2 == 0 || (C1 % 32 == 0 && Cin % 64 != 0));
+        if (direct_ok) {
+            // interior of dx written by the conv epilogue, halo shell into the workspace, then faces
+            rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream), nullptr,
+                                   dx1, C1, dx2);
+            if (rc != TDX_OK) return rc;
+            const int nx = (X > 1) ? 2 : 1, ny = (Y > 1) ? 2 : 1, nz = (Z > 1) ? 2 : 1;
+            const int64_t nface = (int64_t)nx * Y * Z + (int64_t)ny * (X - nx) * Z + (int64_t)nz * (X - nx) * (Y - ny);
+            const int64_t total = (int64_t)B * nface * (Cin / 8);
+            if (total > 0)
+                hipLaunchKernelGGL((conv3_fold_faces_kernel<bf16>), dim3(ceil_div(total, 256)), dim3(256), 0,
+                                   as_stream(stream), (const bf16*)workspace, (bf16*)dx1, C1, (bf16*)dx2, C2, B, X, Y, Z,
+                                   nface, total);
+            return tdx_launch_status();
+        }
         rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream));
     } else {
         rc = conv3_direct_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, dtype, true, as_stream(stream));

@@ -66,7 +66,8 @@ template <int NT, int MT, bool ZERO_PAD>
 __global__ void __launch_bounds__(256, MT == 2 ? 2 : 1)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                   const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, Conv3Geom g,
-                  int Cout, int nbx, int nby, int nbz, double* __restrict__ gn_acc) {
+                  int Cout, int nbx, int nby, int nbz, double* __restrict__ gn_acc, bf16* __restrict__ d1, int D1,
+                  bf16* __restrict__ d2) {
     constexpr int BN = NT * 32;
     constexpr int BX = 2 * MT, HX = BX + 2;
     constexpr int NVOX = BX * M3_BY * M3_BZ;                 // 256 / 512 output voxels
@@ -266,7 +267,22 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         const int ox = ox0 + (v >> 6), oy = oy0 + ((v >> 3) & 7), oz = oz0 + (v & 7);
         if (ox < g.Xo && oy < g.Yo && oz < g.Zo) {
             const uint4 val = *reinterpret_cast<const uint4*>(sO + out_addr<BN>(v, cidx));
-            *reinterpret_cast<uint4*>(y + ((((int64_t)b * g.Xo + ox) * g.Yo + oy) * g.Zo + oz) * Cout + n0 + cidx * 8) = val;
+            bool direct = false;
+            if (ZERO_PAD && d1 != nullptr) {
+                // data gradient: padded position (ox,oy,oz) = original voxel + 1.  Interior positions
+                // go straight to dx (split over the two inputs of a concatenated conv); only the
+                // halo shell is written to the padded workspace for the face fix-up.
+                const int ux = ox - 1, uy = oy - 1, uz = oz - 1;
+                if (ux >= 0 && ux < g.Xi && uy >= 0 && uy < g.Yi && uz >= 0 && uz < g.Zi) {
+                    const int64_t u = (((int64_t)b * g.Xi + ux) * g.Yi + uy) * g.Zi + uz;
+                    const int n = n0 + cidx * 8;
+                    if (n < D1) *reinterpret_cast<uint4*>(d1 + u * D1 + n) = val;
+                    else *reinterpret_cast<uint4*>(d2 + u * (Cout - D1) + (n - D1)) = val;
+                    direct = true;
+                }
+            }
+            if (!direct)
+                *reinterpret_cast<uint4*>(y + ((((int64_t)b * g.Xo + ox) * g.Yo + oy) * g.Zo + oz) * Cout + n0 + cidx * 8) = val;
             if (gn_acc != nullptr) {
                 const unsigned wds[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
@@ -301,7 +317,8 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 }
 
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
-                      const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc) {
+                      const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1,
+                      void* d2) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const int BN = NT * 32;
     // big register tile (8x8x8 bricks) where the grid has room for it and there is enough K to amortise
@@ -324,7 +341,8 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
             attr_set = true;                                                                                         \
         }                                                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2,                 \
-                           (const bf16*)wp, bias, (bf16*)y, g, Cout, nbx, nby, nbz, gn_acc);                         \
+                           (const bf16*)wp, bias, (bf16*)y, g, Cout, nbx, nby, nbz, gn_acc, (bf16*)d1, D1,           \
+                           (bf16*)d2);                                                                               \
     } while (0)
     if (NT == 2 && MT == 4) { if (zero_pad) M3_LAUNCH(2, 4, true); else M3_LAUNCH(2, 4, false); }
     else if (NT == 2)       { if (zero_pad) M3_LAUNCH(2, 2, true); else M3_LAUNCH(2, 2, false); }
