@@ -96,6 +96,22 @@ def cpu_baseline(budget_s=25.0):
             "sample": f"B=1 fwd+bwd of the same 192x64x48 step, fp32, median of {len(times)} after 1 warm-up ({med:.2f} s each)"}
 
 
+def measured_traffic():
+    """HBM bytes per launch of the forward conv kernel from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, produced by tools/collect_profiles.sh at B = 6); None if absent."""
+    files = sorted((ROOT / "profiles").glob("*_traffic.json"))
+    if not files:
+        return None, None
+    data = json.loads(files[-1].read_text())
+    num = den = 0.0
+    for name, k in data["kernels"].items():
+        if "conv3_mfma_kernel" in name and "false>" in name:  # forward instantiations
+            n = k["launches_sampled"]
+            num += n * (k["read_bytes_per_launch"] + k["write_bytes_per_launch"])
+            den += n
+    return (num / den if den else None), f"profiles/{files[-1].name}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,8 +201,11 @@ def main():
         kf = kern.get("tdx_conv3_fwd")
         if kf and kf["ms"] > 0:
             ach = kf["work"] / (kf["ms"] * 1e-3) / 1e12
+            traffic, tsrc = measured_traffic()
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                               "traffic": None, "kernel": "conv3_mfma_kernel (all tdx_conv3_fwd launches)",
+                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                               "traffic_source": tsrc, "algorithmic_bytes_per_launch": 1417.6e6 * B / 22,
+                               "kernel": "conv3_mfma_kernel (all tdx_conv3_fwd launches)",
                                "launches": kf["launches"], "avg_launch_ms": kf["ms"] / kf["launches"],
                                "conv_bandwidth_roofline_frac": (1417.6e6 * B * K / (kf["ms"] * 1e-3)) / 8e12
                                if dtype == torch.bfloat16 else (2835.2e6 * B * K / (kf["ms"] * 1e-3)) / 8e12}

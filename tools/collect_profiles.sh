@@ -1,0 +1,21 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): collects the rocprofv3 evidence that bench.py's roofline
+# object refers to.  Output goes to gpurun_out/prof_<tag>/ ; summarise with
+# tools/summarize_profiles.py and commit the summaries under profiles/.
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
+# (1) per-kernel time
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
+# (2)+(3) HBM traffic counters, one pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH > $OUT/write.log 2>&1
+# (4) SQ counters for the matrix-core kernels
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- $BENCH > $OUT/sq.log 2>&1
+# (5) an un-profiled reference run of the same command
+$BENCH > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
+ls -R $OUT | head -40

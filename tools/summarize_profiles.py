@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into profiles/<tag>_*.
+  <tag>_kernel_stats.csv   rocprofv3 --stats table (per-kernel calls / total / average)
+  <tag>_summary.md         human-readable per-step table + counters of the conv kernels
+  <tag>_traffic.json       per-launch HBM bytes of the dominant kernel (read by bench.py)
+FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3; on gfx950 FETCH_SIZE counts 64 B per
+128-B request for wide coalesced reads, so it is doubled (MI355X_MICROARCH.md, HBM section)."""
+import csv, glob, json, shutil, sys, collections
+from pathlib import Path
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4  # 1 warm-up + 3 timed
+root = Path(__file__).resolve().parent.parent
+src = root / "gpurun_out" / f"prof_{tag}"
+dst = root / "profiles"
+dst.mkdir(exist_ok=True)
+
+def one(pattern):
+    f = glob.glob(str(src / pattern))
+    return f[0] if f else None
+
+stats = one("stats/*/*kernel_stats.csv")
+rows = list(csv.DictReader(open(stats)))
+shutil.copy(stats, dst / f"{tag}_kernel_stats.csv")
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+
+def counter_avgs(pattern):
+    f = one(pattern)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not f:
+        return agg
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+fetch, write, sq = counter_avgs("fetch/*/*counter_collection.csv"), counter_avgs("write/*/*counter_collection.csv"), counter_avgs("sq/*/*counter_collection.csv")
+mean = lambda v: sum(v) / max(len(v), 1)
+lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra` (B = 6, bf16, 192x64x48)", "",
+         f"Total kernel time {tot/1e6/steps:.2f} ms per step ({steps} steps incl. warm-up in the trace).", "",
+         "| kernel | calls/step | ms/step | avg µs | % |", "|---|---|---|---|---|"]
+for r in rows[:28]:
+    lines.append(f"| `{r['Name'][:80]}` | {int(r['Calls'])/steps:.1f} | {float(r['TotalDurationNs'])/1e6/steps:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
+lines += ["", "## HBM traffic and SQ counters of the matrix-core conv kernels (averages per launch)", "",
+          "| kernel | FETCH_SIZE KB (raw) | read MB (x2 gfx950 correction) | WRITE_SIZE KB -> MB | MFMA insts | MFMA busy cyc | LDS conflict / active | clock GHz (GRBM/8/dur) |", "|---|---|---|---|---|---|---|---|"]
+traffic = {}
+durs = {r["Name"]: float(r["AverageNs"]) for r in rows}
+for k in sorted(set(list(fetch) + list(write))):
+    if "conv3_mfma_kernel" not in k and "wgrad_mfma" not in k:
+        continue
+    f_kb = mean(fetch[k].get("FETCH_SIZE", [0])); w_kb = mean(write[k].get("WRITE_SIZE", [0]))
+    rd, wr = 2 * f_kb * 1024, w_kb * 1024
+    s = sq.get(k, {})
+    dur = durs.get(k, 0)
+    clk = mean(s.get("GRBM_GUI_ACTIVE", [0])) / 8 / dur if dur else 0
+    conf, act = mean(s.get("SQ_LDS_BANK_CONFLICT", [0])), mean(s.get("SQ_LDS_IDX_ACTIVE", [1]))
+    lines.append(f"| `{k[:60]}` | {f_kb:.0f} | {rd/1e6:.1f} | {w_kb:.0f} -> {wr/1e6:.1f} | {mean(s.get('SQ_INSTS_MFMA',[0])):.3g} | {mean(s.get('SQ_VALU_MFMA_BUSY_CYCLES',[0])):.3g} | {conf/act:.3f} | {clk:.2f} |")
+    traffic[k] = {"read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "launches_sampled": len(fetch[k].get("FETCH_SIZE", []))}
+fw = {k: v for k, v in traffic.items() if "conv3_mfma_kernel" in k and "false" in k.lower().replace("lb0", "false")}
+(dst / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
+json.dump({"source": f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)",
+           "kernels": traffic}, open(dst / f"{tag}_traffic.json", "w"), indent=1)
+print("\n".join(lines[:40]))
