@@ -162,7 +162,7 @@ def main():
 
     for _ in range(Wm):
         train_step()
-    timer = _lib.KernelTimer({"tdx_conv3_fwd", "tdx_conv3_bwd_data", "tdx_conv3_bwd_weight"})
+    timer = _lib.KernelTimer({"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_bwd_data", "tdx_conv3_bwd_weight"})
     _lib.TIMER = timer
     barrier()
     t0 = time.perf_counter()
@@ -172,6 +172,13 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.TIMER = None
     kern = timer.summary()
+    # tdx_conv3_fwd_gn = the same conv kernel with the GroupNorm statistics in its epilogue
+    # (+ a memset and an 8 us finalize kernel inside the bracket): count it as a forward launch
+    if "tdx_conv3_fwd_gn" in kern:
+        f = kern.setdefault("tdx_conv3_fwd", {"launches": 0, "ms": 0.0, "work": 0.0})
+        g = kern.pop("tdx_conv3_fwd_gn")
+        for k in f:
+            f[k] += g[k]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
