@@ -162,7 +162,8 @@ def main():
 
     for _ in range(Wm):
         train_step()
-    timer = _lib.KernelTimer({"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_bwd_data", "tdx_conv3_bwd_weight"})
+    timer = _lib.KernelTimer({"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add",
+                               "tdx_conv3_bwd_weight"})
     _lib.TIMER = timer
     barrier()
     t0 = time.perf_counter()
@@ -174,11 +175,12 @@ def main():
     kern = timer.summary()
     # tdx_conv3_fwd_gn = the same conv kernel with the GroupNorm statistics in its epilogue
     # (+ a memset and an 8 us finalize kernel inside the bracket): count it as a forward launch
-    if "tdx_conv3_fwd_gn" in kern:
-        f = kern.setdefault("tdx_conv3_fwd", {"launches": 0, "ms": 0.0, "work": 0.0})
-        g = kern.pop("tdx_conv3_fwd_gn")
-        for k in f:
-            f[k] += g[k]
+    for alias, name in (("tdx_conv3_fwd_gn", "tdx_conv3_fwd"), ("tdx_conv3_bwd_data_add", "tdx_conv3_bwd_data")):
+        if alias in kern:
+            f = kern.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+            g = kern.pop(alias)
+            for k in f:
+                f[k] += g[k]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)

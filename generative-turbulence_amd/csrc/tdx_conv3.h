@@ -22,7 +22,8 @@ static inline bool conv3_uses_mfma_layout(int dtype, int K, int N) { return dtyp
 
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                       const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr,
-                      void* d1 = nullptr, int D1 = 0, void* d2 = nullptr);
+                      void* d1 = nullptr, int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr,
+                      const void* a2 = nullptr);
 
 bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout);
 int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,

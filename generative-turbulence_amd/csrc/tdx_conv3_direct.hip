@@ -176,7 +176,8 @@ __device__ __forceinline__ void fold_range(int u, int n, int& lo, int& hi) {
 }
 template <typename T>
 __global__ void __launch_bounds__(256)
-conv3_fold_kernel(const T* __restrict__ dpad, T* __restrict__ dx1, int C1, T* __restrict__ dx2, int C2, int accumulate,
+conv3_fold_kernel(const T* __restrict__ dpad, T* __restrict__ dx1, int C1, T* __restrict__ dx2, int C2,
+                  const T* __restrict__ add1, const T* __restrict__ add2,
                   int B, int X, int Y, int Z, int64_t total) {
     const int C = C1 + C2;
     const int L = C >> 3;
@@ -208,8 +209,9 @@ conv3_fold_kernel(const T* __restrict__ dpad, T* __restrict__ dx1, int C1, T* __
     const int c = lc * 8;
     T* dst = (c < C1) ? dx1 + vox * C1 + c : dx2 + vox * C2 + (c - C1);
     Vec8<T> o;
-    if (accumulate) {
-        o.load(dst);
+    const T* asrc = (c < C1) ? (add1 ? add1 + vox * C1 + c : nullptr) : (add2 ? add2 + vox * C2 + (c - C1) : nullptr);
+    if (asrc) {
+        o.load(asrc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.v[j] += acc[j];
     } else {
@@ -409,9 +411,9 @@ extern "C" size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z,
     return (size_t)B * (X + 2) * (Y + 2) * (Z + 2) * Cin * (dtype == TDX_BF16 ? 2 : 4) + 256;
 }
 
-extern "C" int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2,
-                                  int accumulate, int B, int X, int Y, int Z, int Cout, int dtype, int impl,
-                                  void* workspace, void* stream) {
+static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2, const void* add1,
+                               const void* add2, int B, int X, int Y, int Z, int Cout, int dtype, int impl,
+                               void* workspace, void* stream) {
     TDX_CHECK_ARG(dy && wb && dx1 && workspace && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && C2 >= 0 && Cout > 0);
     TDX_CHECK_ARG(C2 == 0 || dx2);
     const int Cin = C1 + C2;
@@ -422,11 +424,10 @@ extern "C" int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int
     int rc;
     if (use_mfma) {
         if (!mfma_ok(dtype, Cout, 0, Cin)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
-        const bool direct_ok = !accumulate && (C1 % 64 == 0 || C2 == 0 || (C1 % 32 == 0 && Cin % 64 != 0));
-        if (direct_ok) {
+        {
             // interior of dx written by the conv epilogue, halo shell into the workspace, then faces
             rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream), nullptr,
-                                   dx1, C1, dx2);
+                                   dx1, C1, dx2, add1, add2);
             if (rc != TDX_OK) return rc;
             const int nx = (X > 1) ? 2 : 1, ny = (Y > 1) ? 2 : 1, nz = (Z > 1) ? 2 : 1;
             const int64_t nface = (int64_t)nx * Y * Z + (int64_t)ny * (X - nx) * Z + (int64_t)nz * (X - nx) * (Y - ny);
@@ -437,7 +438,6 @@ extern "C" int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int
                                    nface, total);
             return tdx_launch_status();
         }
-        rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream));
     } else {
         rc = conv3_direct_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, dtype, true, as_stream(stream));
     }
@@ -445,8 +445,21 @@ extern "C" int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int
     const int64_t total = (int64_t)B * X * Y * Z * (Cin / 8);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv3_fold_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0,
                                                   as_stream(stream), (const T*)workspace, (T*)dx1, C1, (T*)dx2, C2,
-                                                  accumulate, B, X, Y, Z, total));
+                                                  (const T*)add1, (const T*)add2, B, X, Y, Z, total));
     return tdx_launch_status();
+}
+
+extern "C" int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2,
+                                  int accumulate, int B, int X, int Y, int Z, int Cout, int dtype, int impl,
+                                  void* workspace, void* stream) {
+    return conv3_bwd_data_impl(dy, wb, dx1, C1, dx2, C2, accumulate ? dx1 : nullptr, accumulate ? dx2 : nullptr, B, X, Y, Z,
+                               Cout, dtype, impl, workspace, stream);
+}
+
+extern "C" int tdx_conv3_bwd_data_add(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2,
+                                      const void* add1, const void* add2, int B, int X, int Y, int Z, int Cout, int dtype,
+                                      int impl, void* workspace, void* stream) {
+    return conv3_bwd_data_impl(dy, wb, dx1, C1, dx2, C2, add1, add2, B, X, Y, Z, Cout, dtype, impl, workspace, stream);
 }
 
 extern "C" size_t tdx_conv3_bwd_weight_workspace_bytes(int Cin, int Cout, int impl) {

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256, MT == 2 ? 2 : 1)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                   const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, Conv3Geom g,
                   int Cout, int nbx, int nby, int nbz, double* __restrict__ gn_acc, bf16* __restrict__ d1, int D1,
-                  bf16* __restrict__ d2) {
+                  bf16* __restrict__ d2, const bf16* __restrict__ a1, const bf16* __restrict__ a2) {
     constexpr int BN = NT * 32;
     constexpr int BX = 2 * MT, HX = BX + 2;
     constexpr int NVOX = BX * M3_BY * M3_BZ;                 // 256 / 512 output voxels
@@ -276,8 +276,20 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
                 if (ux >= 0 && ux < g.Xi && uy >= 0 && uy < g.Yi && uz >= 0 && uz < g.Zi) {
                     const int64_t u = (((int64_t)b * g.Xi + ux) * g.Yi + uy) * g.Zi + uz;
                     const int n = n0 + cidx * 8;
-                    if (n < D1) *reinterpret_cast<uint4*>(d1 + u * D1 + n) = val;
-                    else *reinterpret_cast<uint4*>(d2 + u * (Cout - D1) + (n - D1)) = val;
+                    // optional fused addend (the gradient arriving over the block's residual path)
+                    const bool lo = n < D1;
+                    bf16* dst = lo ? d1 + u * D1 + n : d2 + u * (Cout - D1) + (n - D1);
+                    const bf16* asrc = lo ? (a1 ? a1 + u * D1 + n : nullptr) : (a2 ? a2 + u * (Cout - D1) + (n - D1) : nullptr);
+                    if (asrc) {
+                        Vec8<bf16> va, vb;
+                        va.load(reinterpret_cast<const bf16*>(&val));
+                        vb.load(asrc);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) va.v[e] += vb.v[e];
+                        va.store(dst);
+                    } else {
+                        *reinterpret_cast<uint4*>(dst) = val;
+                    }
                     direct = true;
                 }
             }
@@ -318,7 +330,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                       const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1,
-                      void* d2) {
+                      void* d2, const void* a1, const void* a2) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const int BN = NT * 32;
     // big register tile (8x8x8 bricks) where the grid has room for it and there is enough K to amortise
@@ -342,7 +354,7 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
         }                                                                                                            \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2,                 \
                            (const bf16*)wp, bias, (bf16*)y, g, Cout, nbx, nby, nbz, gn_acc, (bf16*)d1, D1,           \
-                           (bf16*)d2);                                                                               \
+                           (bf16*)d2, (const bf16*)a1, (const bf16*)a2);                                             \
     } while (0)
     if (NT == 2 && MT == 4) { if (zero_pad) M3_LAUNCH(2, 4, true); else M3_LAUNCH(2, 4, false); }
     else if (NT == 2)       { if (zero_pad) M3_LAUNCH(2, 2, true); else M3_LAUNCH(2, 2, false); }

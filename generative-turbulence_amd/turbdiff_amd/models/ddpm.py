@@ -72,6 +72,13 @@ class SinusoidalPosEmb(nn.Module):
 # --------------------------------------------------------------------------- blocks (NDHWC)
 
 
+# one autograd node per ResnetBlock (hand-written backward) instead of one per operator;
+# TDX_FUSE_BLOCKS=0 selects the per-operator composition (same kernels, used as a cross-check)
+import os as _os
+
+FUSE_BLOCKS = _os.environ.get("TDX_FUSE_BLOCKS", "1") != "0"
+
+
 def _norm_groups(norm: nn.GroupNorm) -> int:
     return norm.num_groups
 
@@ -118,6 +125,13 @@ class ResnetBlock(nn.Module):
     def forward(self, x, c, x2=None):
         film = self.project_onto_scale_shift(c)  # (B, 2*dim_out): [scale | shift]
         scale, shift = film[:, : self.dim_out], film[:, self.dim_out :]
+        identity = isinstance(self.conv, nn.Identity)
+        if self.block1._fused_act and self.block2._fused_act and not (identity and x2 is not None) and FUSE_BLOCKS:
+            b1, b2 = self.block1, self.block2
+            return ops.resnet_block(x, x2, scale, shift, (b1.conv.weight, b1.conv.bias), (b1.norm.weight, b1.norm.bias),
+                                    (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias),
+                                    None if identity else (self.conv.weight, self.conv.bias), _norm_groups(b1.norm),
+                                    b1.norm.eps)
         h = self.block1(x, scale_shift=(scale, shift), x2=x2)
         if isinstance(self.conv, nn.Identity):
             skip = x if x2 is None else torch.cat((x, x2), dim=-1)

@@ -522,3 +522,135 @@ def randn_philox_batched(out: torch.Tensor, seed: int, stream_ids: torch.Tensor,
     B = out.shape[0]
     L.call("tdx_randn_batched", L.ptr(out), B, out[0].numel(), seed, L.ptr(stream_ids), L.ptr(offset_dev), L.stream())
     return out
+
+
+# --------------------------------------------------------------------------- fused ResnetBlock
+
+
+class _ResnetBlock(torch.autograd.Function):
+    """ResnetBlock (reference ddpm.py:180-197) as ONE autograd node:
+
+        h1 = conv3([x1|x2]; w1) ; a1 = silu(GN(h1) * (1 + scale) + shift)
+        h2 = conv3(a1; w2)      ; y  = silu(GN(h2)) + res,   res = [x1|x2] (identity) or conv1x1([x1|x2]; wr)
+
+    Doing the backward by hand (instead of chaining the per-op Functions) lets the gradient that
+    arrives over the residual path be added inside the data-gradient conv's epilogue / the 1x1
+    conv's epilogue, so autograd never runs a separate three-pass add on the block input, and it
+    cuts the number of autograd nodes per block from 6-7 to 1."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, scale, shift, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps):
+        B, X, Y, Z, C1 = _grid(x1)
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Cin, Cout = C1 + C2, w1.shape[0]
+        V = X * Y * Z
+        dev, dt = x1.device, x1.dtype
+        code, impl, st = L.dtype_code(dt), L.conv_impl(), L.stream()
+        x1 = x1.contiguous()
+        x2 = None if x2 is None else x2.contiguous()
+        wf1, wb1 = _packed_conv3(w1, dt)
+        wf2, wb2 = _packed_conv3(w2, dt)
+        f32c = lambda t: t.detach().float().contiguous()
+        g1, be1, g2, be2 = f32c(g1), f32c(be1), f32c(g2), f32c(be2)
+        scale, shift = f32c(scale.reshape(B, Cout)), f32c(shift.reshape(B, Cout))
+        gws = _ws(L.query("tdx_gn_workspace_bytes", B, Cout), dev)
+
+        def conv_gn(xa, Ca, xb, Cb, wf, bias):
+            y = torch.empty((B, X, Y, Z, Cout), dtype=dt, device=dev)
+            stats = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
+            L.call("tdx_conv3_fwd_gn", L.ptr(xa), Ca, L.ptr(xb), Cb, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats), groups,
+                   float(eps), L.ptr(gws), B, X, Y, Z, Cout, code, impl, st, work=54.0 * (Ca + Cb) * Cout * B * V)
+            return y, stats
+
+        h1, st1 = conv_gn(x1, C1, x2, C2, wf1, b1)
+        a1 = torch.empty_like(h1)
+        L.call("tdx_gn_apply", L.ptr(h1), L.ptr(st1), L.ptr(g1), L.ptr(be1), L.ptr(scale), L.ptr(shift), None, L.ptr(a1),
+               B, V, Cout, groups, 1, code, st)
+        h2, st2 = conv_gn(a1, Cout, None, 0, wf2, b2)
+        wr2 = None
+        if wr is None:
+            assert x2 is None and Cin == Cout
+            res = x1
+        else:
+            wr2 = wr.detach().reshape(Cout, Cin).contiguous()
+            res = torch.empty_like(h1)
+            L.call("tdx_conv1_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wr2.t().contiguous()), Cout, L.ptr(br), None,
+                   L.ptr(res), B * V, Cout, code, st)
+        y = torch.empty_like(h1)
+        L.call("tdx_gn_apply", L.ptr(h2), L.ptr(st2), L.ptr(g2), L.ptr(be2), None, None, L.ptr(res), L.ptr(y), B, V, Cout,
+               groups, 1, code, st)
+        ctx.save_for_backward(x1, x2, h1, st1, a1, h2, st2, scale, shift, g1, be1, g2, be2, wb1, wb2, wr2)
+        ctx.cfg = (groups, tuple(w1.shape), tuple(w2.shape), None if wr is None else tuple(wr.shape),
+                   b1 is not None, b2 is not None, br is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x1, x2, h1, st1, a1, h2, st2, scale, shift, g1, be1, g2, be2, wb1, wb2, wr2 = ctx.saved_tensors
+        groups, w1s, w2s, wrs, hb1, hb2, hbr = ctx.cfg
+        B, X, Y, Z, C1 = _grid(x1)
+        C2 = 0 if x2 is None else x2.shape[-1]
+        Cin, Cout = C1 + C2, w1s[0]
+        V = X * Y * Z
+        gy = gy.contiguous()
+        dev, dt = gy.device, gy.dtype
+        code, impl, st = L.dtype_code(dt), L.conv_impl(), L.stream()
+        f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        gws = _ws(L.query("tdx_gn_workspace_bytes", B, Cout), dev)
+        flops = lambda ci: 54.0 * ci * Cout * B * V
+
+        # ---- block2: GroupNorm + SiLU (+ residual: its gradient is gy itself)
+        dh2, dg2, dbe2 = torch.empty_like(h2), f32(Cout), f32(Cout)
+        L.call("tdx_gn_bwd", L.ptr(h2), L.ptr(gy), L.ptr(st2), L.ptr(g2), L.ptr(be2), None, None, L.ptr(dh2), L.ptr(dg2),
+               L.ptr(dbe2), None, None, B, V, Cout, groups, 1, code, L.ptr(gws), st)
+        dw2, db2 = f32(*w2s), (f32(Cout) if hb2 else None)
+        wws = _ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", max(Cin, Cout), Cout, impl), dev)
+        L.call("tdx_conv3_bwd_weight", L.ptr(a1), Cout, None, 0, L.ptr(dh2), L.ptr(dw2), L.ptr(db2), B, X, Y, Z, Cout, code,
+               impl, L.ptr(wws), st, work=flops(Cout))
+        da1 = torch.empty_like(a1)
+        dws = _ws(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, max(Cin, Cout), code, impl), dev)
+        L.call("tdx_conv3_bwd_data", L.ptr(dh2), L.ptr(wb2), L.ptr(da1), Cout, None, 0, 0, B, X, Y, Z, Cout, code, impl,
+               L.ptr(dws), st, work=flops(Cout))
+        del dh2
+        # ---- block1: GroupNorm + FiLM + SiLU
+        dh1, dg1, dbe1, dscale, dshift = torch.empty_like(h1), f32(Cout), f32(Cout), f32(B, Cout), f32(B, Cout)
+        L.call("tdx_gn_bwd", L.ptr(h1), L.ptr(da1), L.ptr(st1), L.ptr(g1), L.ptr(be1), L.ptr(scale), L.ptr(shift), L.ptr(dh1),
+               L.ptr(dg1), L.ptr(dbe1), L.ptr(dscale), L.ptr(dshift), B, V, Cout, groups, 1, code, L.ptr(gws), st)
+        del da1
+        dw1, db1 = f32(*w1s), (f32(Cout) if hb1 else None)
+        L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
+               impl, L.ptr(wws), st, work=flops(Cin))
+        # ---- input gradient = conv1 data gradient + residual-path gradient
+        gx1 = torch.empty_like(x1)
+        gx2 = None if x2 is None else torch.empty_like(x2)
+        dwr = dbr = None
+        if wr2 is None:  # identity skip: add gy inside the data-gradient epilogue
+            L.call("tdx_conv3_bwd_data_add", L.ptr(dh1), L.ptr(wb1), L.ptr(gx1), C1, None, 0, L.ptr(gy), None, B, X, Y, Z, Cout,
+                   code, impl, L.ptr(dws), st, work=flops(Cin))
+        else:
+            t1 = torch.empty_like(x1)
+            t2 = None if x2 is None else torch.empty_like(x2)
+            L.call("tdx_conv3_bwd_data", L.ptr(dh1), L.ptr(wb1), L.ptr(t1), C1, L.ptr(t2), C2, 0, B, X, Y, Z, Cout, code, impl,
+                   L.ptr(dws), st, work=flops(Cin))
+            # 1x1 skip: dx = gy @ wr (+ t) -- the add rides in the 1x1 kernel's epilogue
+            L.call("tdx_conv1_fwd", L.ptr(gy), Cout, None, 0, wr2.data_ptr(), Cin, None, L.ptr(t1), L.ptr(gx1), B * V, C1, code, st)
+            if x2 is not None:
+                L.call("tdx_conv1_fwd", L.ptr(gy), Cout, None, 0, wr2.data_ptr() + 4 * C1, Cin, None, L.ptr(t2), L.ptr(gx2),
+                       B * V, C2, code, st)
+            dwt = f32(Cin, Cout)
+            dbr = f32(Cout) if hbr else None
+            L.call("tdx_conv1_bwd_weight", L.ptr(x1), C1, L.ptr(gy), Cout, dwt.data_ptr(), Cout, L.ptr(dbr), B * V, code, st)
+            if x2 is not None:
+                L.call("tdx_conv1_bwd_weight", L.ptr(x2), C2, L.ptr(gy), Cout, dwt.data_ptr() + 4 * C1 * Cout, Cout, None,
+                       B * V, code, st)
+            dwr = dwt.t().reshape(wrs)
+        return (gx1, gx2, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None)
+
+
+def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, skip_wb, groups, eps=1e-5):
+    """Fused ResnetBlock; *_wb are (weight, bias) pairs, skip_wb is None for an identity skip.
+    Requires SiLU activations and bf16/f32 NDHWC inputs; scale/shift are (B, Cout)."""
+    wr, br = skip_wb if skip_wb is not None else (None, None)
+    return _ResnetBlock.apply(x1, x2, scale, shift, conv1_wb[0], conv1_wb[1], norm1_wb[0], norm1_wb[1], conv2_wb[0],
+                              conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps)

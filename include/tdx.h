@@ -91,6 +91,13 @@ size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z, int Cin, i
 int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2, int accumulate,
                        int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* workspace, void* stream);
 
+/* Same, with a fused addend: dx1 = adjoint[:, 0:C1] + add1, dx2 = adjoint[:, C1:] + add2 (either
+ * addend may be NULL).  Used by the ResnetBlock backward, where the gradient arriving over the
+ * residual path (ddpm.py:197) would otherwise cost a separate three-pass add. */
+int tdx_conv3_bwd_data_add(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2, const void* add1,
+                           const void* add2, int B, int X, int Y, int Z, int Cout, int dtype, int impl,
+                           void* workspace, void* stream);
+
 /* Weight + bias gradient.  dw is written in the reference's parameter layout
  * (Cout, Cin, 3, 3, 3) f32, dbias (Cout) f32 (may be NULL).  Overwrites.
  * workspace: tdx_conv3_bwd_weight_workspace_bytes(). */
