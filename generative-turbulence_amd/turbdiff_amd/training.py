@@ -1,0 +1,166 @@
+"""The callers of the hot path, without Lightning / hydra / h5py.
+
+``DiffusionTrainer`` reproduces what the reference's ``DiffusionTraining`` task
+(turbdiff/models/diffusion.py:41-243) does around ``GaussianDiffusion``:
+
+* construction from the keys of ``config/model/diffusion.yaml`` (dim, timesteps, beta_schedule,
+  loss, noise_bcs, learned_variances, clip_denoised, norm_type, actfn, optimizer, learning_rate,
+  min_learning_rate, lr_decay, cell_type_embedding_dim, ...) -- u_net_levels = 4 is hard-coded
+  there (diffusion.py:120) and here;
+* ``_model_input``: per-feature normalisation ``addcmul(-mean/std, 1/std, x)``
+  (normalization.py:20-24) and the learned cell-type embedding as local conditioning
+  (cell_type_embeddings.py:72-79, conditioning.py:48-51);
+* ``training_step`` = ``GaussianDiffusion.forward``; ``sample`` = ``p_sample_loop`` + denormalise
+  (diffusion.py:152-165); ``configure_optimizers`` = RAdam + per-step exponential LambdaLR
+  (diffusion.py:210-235); ``fit_step`` adds the trainer's clip-by-norm 0.1 (train.yaml:30-31);
+* ``measure_sample_time``: the reference's only timing harness (scripts/evaluate-runtime.py:54-96:
+  synchronize, perf_counter_ns around ``task.sample`` at batch size 1).
+
+The ``state_dict`` has the reference task's 149 keys (``model.model.*``, the two aliases of the
+cell-type embedding, and the 8 metric buffers as placeholders), so the reference's checkpoints load
+with ``strict=True``.  A batch is any object with ``x`` (B, F, X, Y, Z) in physical units,
+``cell_idx`` (flat in-domain cell indices), ``cell_types`` (X, Y, Z) int64 in [0, 6), and the
+per-feature ``mean`` / ``std`` of the active normalisation mode.
+"""
+
+from __future__ import annotations
+
+import math
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch import nn
+
+from .models.conditioning import Conditioning
+from .models.ddpm import DenoisingModel, GaussianDiffusion
+
+ACTFNS = {"silu": nn.SiLU, "gelu": nn.GELU, "relu": nn.ReLU, "softplus": nn.Softplus, "tanh": nn.Tanh}
+N_CELL_TYPES = 6  # inside, outside, walls, inlets, outlets, empties (cell_type_embeddings.py:30-38)
+
+
+class _CellTypeEmbedding(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.embedding = nn.Embedding(N_CELL_TYPES, embedding_dim=dim)
+
+    def forward(self, cell_types):
+        return torch.movedim(self.embedding(cell_types), -1, 0)
+
+
+class _Holder(nn.Module):
+    """Empty module used to reproduce nested state_dict paths."""
+
+
+def _metric_placeholders():
+    """`{val,test}_sample_metrics.metrics.0.distance.*` buffers of the reference task
+    (models/metrics.py); evaluation metrics are out of scope, the buffers only keep checkpoints
+    strict-loadable (legendre_* hold the real Gauss-Legendre rule, the Lebedev grid is zero-filled
+    and overwritten by a checkpoint)."""
+    nodes, weights = np.polynomial.legendre.leggauss(64)
+    coll = _Holder()
+    coll.metrics = nn.ModuleList([_Holder()])
+    dist = _Holder()
+    dist.register_buffer("legendre_nodes", torch.tensor(nodes, dtype=torch.float32))
+    dist.register_buffer("legendre_weights", torch.tensor(weights, dtype=torch.float32))
+    dist.tke_spectrum = _Holder()
+    dist.tke_spectrum.register_buffer("p", torch.zeros(5810, 3))
+    dist.tke_spectrum.register_buffer("w", torch.zeros(5810))
+    coll.metrics[0].distance = dist
+    return coll
+
+
+class DiffusionTrainer(nn.Module):
+    def __init__(self, dim: int = 32, cell_type_embedding_dim: int = 4, n_features: int = 4,
+                 beta_schedule: str = "log-snr-linear", timesteps: int = 500, learning_rate: float = 1e-4,
+                 min_learning_rate: float = 1e-6, lr_decay: str | None = "exp", max_train_steps: int = 1000,
+                 loss: str = "l2", clip_denoised: bool = False, noise_bcs: bool = True, learned_variances: bool = False,
+                 elbo_weight: float | None = None, detach_elbo_mean: bool = True, actfn: str = "silu",
+                 optimizer: str = "radam", norm_type: str = "group", with_geometry_embedding: bool = False,
+                 gradient_clip_val: float = 0.1, u_net_levels: int = 4, compute_dtype: torch.dtype = torch.float32):
+        super().__init__()
+        self.cell_type_embedding = _CellTypeEmbedding(cell_type_embedding_dim)
+        self.conditioning = _Holder()
+        self.conditioning.cell_type_embedding = self.cell_type_embedding  # alias, as in the reference
+        net = DenoisingModel(in_features=n_features, out_features=n_features * (2 if learned_variances else 1),
+                             c_local_features=cell_type_embedding_dim, c_global_features=0, timesteps=timesteps, dim=dim,
+                             u_net_levels=u_net_levels, actfn=ACTFNS[actfn], norm_type=norm_type,
+                             with_geometry_embedding=with_geometry_embedding)
+        net.set_compute_dtype(compute_dtype)
+        self.model = GaussianDiffusion(net, timesteps=timesteps, beta_schedule=beta_schedule, loss_type=loss,
+                                       clip_denoised=clip_denoised, noise_bcs=noise_bcs,
+                                       learned_variances=learned_variances, elbo_weight=elbo_weight,
+                                       detach_elbo_mean=detach_elbo_mean)
+        self.val_sample_metrics = _metric_placeholders()
+        self.test_sample_metrics = _metric_placeholders()
+        self.learning_rate, self.min_learning_rate = learning_rate, min_learning_rate
+        self.lr_decay, self.max_train_steps, self.optimizer = lr_decay, max_train_steps, optimizer
+        self.gradient_clip_val = gradient_clip_val
+        self._opt = self._sched = None
+        self.ddp = None  # set to a parallel.BucketedDataParallel(self) for multi-GPU training
+
+    # ---- the glue around the hot path ------------------------------------------------------
+    @staticmethod
+    def normalize_grid(x, mean, std):
+        m, s = mean.view(-1, 1, 1, 1), std.view(-1, 1, 1, 1)
+        return torch.addcmul(-m / s, torch.reciprocal(s), x)
+
+    @staticmethod
+    def denormalize_grid(x, mean, std):
+        return torch.addcmul(mean.view(-1, 1, 1, 1), std.view(-1, 1, 1, 1), x)
+
+    def _model_input(self, batch):
+        x = self.normalize_grid(batch.x, batch.mean, batch.std)
+        C = {Conditioning.Type.CELL_TYPE: self.cell_type_embedding(batch.cell_types)}
+        return x, C
+
+    def training_step(self, batch):
+        x, C = self._model_input(batch)
+        loss, _ = self.model(x, C, SimpleNamespace(cell_idx=batch.cell_idx), None)
+        return loss
+
+    @torch.no_grad()
+    def sample(self, batch, start_from=None, noise_fn=None):
+        x, C = self._model_input(batch)
+        x = self.model.p_sample_loop(x, C, batch.cell_idx, pbar=False, start_from=start_from, noise_fn=noise_fn)
+        return self.denormalize_grid(x, batch.mean, batch.std)
+
+    def configure_optimizers(self):
+        klass = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "radam": torch.optim.RAdam}.get(self.optimizer)
+        if klass is None:
+            raise RuntimeError(f"Unknown optimizer {self.optimizer}")
+        opt = klass(self.parameters(), lr=self.learning_rate)
+        sched = None
+        if self.lr_decay == "exp":
+            rate = math.log(self.min_learning_rate / self.learning_rate) / self.max_train_steps
+            sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: math.exp(rate * min(step, self.max_train_steps)))
+        return opt, sched
+
+    def fit_step(self, batch):
+        """zero_grad -> training_step -> backward -> [grad all-reduce] -> clip -> optimizer -> LR schedule."""
+        if self._opt is None:
+            self._opt, self._sched = self.configure_optimizers()
+        self._opt.zero_grad(set_to_none=True)
+        loss = self.training_step(batch)
+        loss.backward()
+        if self.ddp is not None:
+            self.ddp.finish()
+        if self.gradient_clip_val:
+            torch.nn.utils.clip_grad_norm_(self.parameters(), self.gradient_clip_val)
+        self._opt.step()
+        if self._sched is not None:
+            self._sched.step()
+        return loss.detach()
+
+    @torch.no_grad()
+    def measure_sample_time(self, batch, repeats: int = 1):
+        """Seconds per `sample(batch)` with the reference's protocol (evaluate-runtime.py:63-84)."""
+        best = float("inf")
+        for _ in range(repeats):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter_ns()
+            self.sample(batch)
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter_ns() - t0) * 1e-9)
+        return best

@@ -130,3 +130,27 @@ def test_kwargs_sequential_filters_keywords():
 
     seq = KwargsSequential(A(), B(), K())
     assert seq(torch.tensor(1.0), c=torch.tensor(3.0)).item() == 11.0
+
+
+def test_trainer_state_dict_has_the_reference_tasks_149_keys():
+    """DiffusionTrainer (our Lightning-free counterpart of DiffusionTraining, diffusion.py:41-143)
+    exposes exactly the key / shape schema of the reference task, so eval_ckpt.py-style strict
+    loading (scripts/eval_ckpt.py:59) works."""
+    from turbdiff_amd.training import DiffusionTrainer
+
+    want = {}
+    for line in (ROOT / "tests" / "golden" / "state_dict_manifest.txt").read_text().splitlines():
+        if line and not line.startswith("#"):
+            k, shp = line.split("\t")
+            want[k] = eval(shp)
+    assert len(want) == 149
+    task = DiffusionTrainer(dim=32, timesteps=500)
+    have = {k: tuple(v.shape) for k, v in task.state_dict().items()}
+    assert have == want
+    task.load_state_dict({k: torch.zeros(s) for k, s in want.items()}, strict=True)
+    opt, sched = task.configure_optimizers()
+    assert isinstance(opt, torch.optim.RAdam) and sched is not None
+    # exponential decay from 1e-4 to 1e-6 over max_train_steps (diffusion.py:221-233)
+    for _ in range(task.max_train_steps):
+        opt.step(); sched.step()
+    assert abs(sched.get_last_lr()[0] - 1e-6) < 1e-12

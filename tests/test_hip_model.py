@@ -246,3 +246,45 @@ def test_fused_resnet_block_golden(golden, dtype):
         assert rel_l2(c.grad.cpu(), g[f"{tag}/gc"]) < gtol, tag
         for k, v in sd.items():
             assert_grad_close(f"{tag}/{k}", v.grad.cpu(), g[f"{tag}/grad/{k}"], gtol)
+
+
+def test_trainer_training_step_and_sample(golden):
+    """DiffusionTrainer: normalisation + learned cell-type embedding + GaussianDiffusion, checked
+    against the oracle fed with the same normalised input / embedded conditioning."""
+    from turbdiff_amd.training import DiffusionTrainer
+
+    g = golden("model_cfg1")
+    d = dev()
+    torch.manual_seed(3)
+    task = DiffusionTrainer(dim=8, timesteps=10, u_net_levels=2, max_train_steps=20).to(d)
+    task.model.model.load_state_dict(g.sub("sd/"))
+    X, Y, Z = g["x"].shape[-3:]
+    gen = torch.Generator().manual_seed(11)
+    cell_types = torch.randint(0, 6, (X, Y, Z), generator=gen)
+    mean, std = torch.tensor([0.3, -0.1, 0.2, 1.0]), torch.tensor([2.0, 1.5, 0.7, 3.0])
+    raw = g["x"] * std.view(4, 1, 1, 1) + mean.view(4, 1, 1, 1)
+    batch = SimpleNamespace(x=raw.to(d), cell_idx=g["cell_idx"].to(d), cell_types=cell_types.to(d), mean=mean.to(d), std=std.to(d))
+    x_n, C = task._model_input(batch)
+    assert rel_l2(x_n.cpu(), g["x"]) < 1e-6
+    emb = task.cell_type_embedding.embedding.weight.detach().cpu()
+    c_local = emb[cell_types].movedim(-1, 0)
+    # loss with injected (t, noise) equals the oracle's
+    noise = g["loss_nb1/noise"].to(d)
+    loss, _ = task.model.p_losses(x_n, g["t"].to(d), C, SimpleNamespace(cell_idx=batch.cell_idx), None, noise=noise)
+    buf = O.schedule_buffers("log-snr-linear", 10)
+    ref, _ = O.p_losses(g.sub("sd/"), buf, g["x"], g["t"], c_local, g["cell_idx"], g["loss_nb1/noise"], timesteps=10, noise_bcs=True)
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    loss.backward()
+    assert task.cell_type_embedding.embedding.weight.grad is not None  # conditioning is trained
+    # two optimiser steps run and change the parameters; loss stays finite
+    before = task.model.model.encode_x.weight.detach().clone()
+    for _ in range(2):
+        l = task.fit_step(batch)
+        assert torch.isfinite(l)
+    assert not torch.equal(before, task.model.model.encode_x.weight.detach())
+    # sample: denormalised output keeps the data values outside the domain (ddpm.py:814 + diffusion.py:157)
+    out = task.sample(batch)
+    inside = torch.zeros(X * Y * Z, dtype=torch.bool)
+    inside[g["cell_idx"]] = True
+    assert rel_l2(out.cpu().flatten(-3)[..., ~inside], raw.flatten(-3)[..., ~inside]) < 1e-5
+    assert task.measure_sample_time(batch) > 0
