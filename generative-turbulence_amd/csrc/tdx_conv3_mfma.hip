@@ -43,6 +43,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define M3_NVOX_HALO (M3_HX * M3_HY * M3_HZ)   // 600
 #define M3_BRICK_BYTES (M3_HX * M3_HY * M3_SZ * 32 + 128)  // 23168
 #define M3_KC 16
+#define M3_DEFAULT_PP false
 
 bool conv3_mfma_supported(int C1, int C2, int Cout) {
     return C1 > 0 && (C1 % M3_KC) == 0 && (C2 % M3_KC) == 0 && (Cout % 32) == 0;
@@ -62,8 +63,11 @@ __device__ __forceinline__ int out_addr(int v, int c) {
 
 // MT = 32-voxel M tiles per wave: 2 (4x8x8 brick, 2 workgroups/CU) or 4 (8x8x8 brick, one
 // workgroup/CU with twice the register tile -> 25 % fewer LDS fragment bytes per MFMA).
-template <int NT, int MT, bool ZERO_PAD>
-__global__ void __launch_bounds__(256, MT == 2 ? 2 : 1)
+// PP = ping-pong LDS: one workgroup per CU owns two stage buffers; slice c+1 is written into the
+// idle buffer at the top of slice c's MFMA phase (its global loads were issued a slice earlier),
+// so there is ONE barrier per slice and the staging costs only its issue slots.
+template <int NT, int MT, bool ZERO_PAD, bool PP>
+__global__ void __launch_bounds__(256, (MT == 2 && !PP) ? 2 : 1)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                   const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, Conv3Geom g,
                   int Cout, int nbx, int nby, int nbz, double* __restrict__ gn_acc, bf16* __restrict__ d1, int D1,
@@ -74,9 +78,9 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     constexpr int NHALO = HX * M3_HY * M3_HZ;                // 600 / 1000 staged voxels
     constexpr int APLANE = HX * M3_HY * M3_SZ * 16 + 64;     // one half-plane of the brick image
     constexpr int BRICK_BYTES = 2 * APLANE;
+    constexpr int B_PLANE = 27 * BN * 16 + 64;
+    constexpr int STAGE_BYTES = BRICK_BYTES + 2 * B_PLANE;   // one stage buffer (brick + weights)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + BRICK_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -124,7 +128,6 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     const int64_t batch_vox = (int64_t)b * g.Xi * g.Yi * g.Zi;
 
     // weight staging role of this thread
-    constexpr int B_PLANE = 27 * BN * 16 + 64;
     const int b_half = (tid >> 2) & 1;
     const int b_row0 = ((tid >> 3) << 2) + (tid & 3);                       // 0..127
     const int b_goff = ((b_row0 / BN) * Cout + (b_row0 % BN)) * 16 + b_half * 8;  // elements
@@ -153,7 +156,9 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
                 breg[i] = *reinterpret_cast<const uint4*>(wc + (int64_t)i * (128 / BN) * Cout * 16);
         }
     };
-    auto store_slice = [&]() {
+    auto store_slice = [&](int buf) {
+        unsigned char* sA = smem + buf * STAGE_BYTES;
+        unsigned char* sB = sA + BRICK_BYTES;
 #pragma unroll
         for (int i = 0; i < A_PER_THREAD; ++i)
             if (a_dst[i] >= 0) *reinterpret_cast<uint4*>(sA + a_dst[i]) = areg[i];
@@ -184,15 +189,14 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
 
     const int nchunks = Cin / M3_KC;
-    load_slice(0);
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();  // previous slice's fragment reads are done
-        store_slice();
-        __syncthreads();
-        if (c + 1 < nchunks) load_slice(c + 1);  // in flight during the MFMAs below
-
-        // fragments of tap t+1 are read while the MFMAs of tap t issue (two register sets)
-        bf16x8 xf[2][MT], wf[2][NT];
+    // the 27 x (MT x NT) MFMAs of one slice; fragments of tap t+1 are read while the MFMAs of tap t
+    // issue (two register sets)
+    auto compute_slice = [&](int buf) {
+        const unsigned char* sA = smem + buf * STAGE_BYTES;
+        const unsigned char* sB = sA + BRICK_BYTES;
+        constexpr int PD = PP ? 3 : 1;       // fragment prefetch distance in taps (ring of PD + 1 sets):
+        constexpr int RING = PD + 1;         // one wave per SIMD (PP) has to cover the LDS latency alone
+        bf16x8 xf[RING][MT], wf[RING][NT];
         auto read_frags = [&](int tap, int buf) {
             const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
             const int toff = (ex * M3_HY + ey) * M3_SZ + ez;
@@ -203,18 +207,19 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             for (int nt = 0; nt < NT; ++nt)
                 wf[buf][nt] = *reinterpret_cast<const bf16x8*>(sB + tap * (BN * 16) + b_off[nt]);
         };
-        read_frags(0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);  // DS_READ: tap 0's fragments
+#pragma unroll
+        for (int t = 0; t < PD; ++t) read_frags(t, t);
+        __builtin_amdgcn_sched_group_barrier(0x100, PD * (MT + NT), 0);  // DS_READ: the first PD taps
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
-            if (tap + 1 < 27) read_frags(tap + 1, (tap + 1) & 1);
+            if (tap + PD < 27) read_frags(tap + PD, (tap + PD) % RING);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap & 1][nt], xf[tap & 1][mt], acc[nt][mt], 0, 0, 0);
-            // pin the interleave: one fragment read of tap+1 behind each MFMA of tap
-            if (tap + 1 < 27) {
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap % RING][nt], xf[tap % RING][mt], acc[nt][mt], 0, 0, 0);
+            // pin the interleave: one fragment read of tap+PD behind each MFMA of tap
+            if (tap + PD < 27) {
 #pragma unroll
                 for (int k = 0; k < MT * NT; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
@@ -224,12 +229,35 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
                 __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
             }
         }
+    };
+
+    load_slice(0);
+    if constexpr (PP) {
+        store_slice(0);
+        __syncthreads();
+        if (nchunks > 1) load_slice(1);
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) {
+                store_slice((c + 1) & 1);                  // buffer last read during slice c-1
+                if (c + 2 < nchunks) load_slice(c + 2);    // in flight for a whole slice
+            }
+            compute_slice(c & 1);
+            __syncthreads();
+        }
+    } else {
+        for (int c = 0; c < nchunks; ++c) {
+            __syncthreads();  // previous slice's fragment reads are done
+            store_slice(0);
+            __syncthreads();
+            if (c + 1 < nchunks) load_slice(c + 1);  // in flight during the MFMAs below
+            compute_slice(0);
+        }
+        __syncthreads();
     }
 
     // ---------------- epilogue.  Lane (r, hh) of wave w holds, for M tile mt, voxel
     // (x = w, y = 4 mt + (r & 3), z = r >> 2) and channels nt*32 + 8 j + 4 hh + (0..3) in
     // accumulator registers 4 j .. 4 j + 3.
-    __syncthreads();
     unsigned char* sO = smem;  // [NVOX voxels][BN] bf16, voxel v = (x*8 + y)*8 + z
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -338,14 +366,18 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
     static const int force_mt = getenv("TDX_CONV3_MT") ? atoi(getenv("TDX_CONV3_MT")) : 0;
     int MT = 2;  // measured: MT = 4 (one workgroup/CU) is 5-30 % slower on every layer of the U-Net
     if (force_mt == 2 || force_mt == 4) MT = force_mt;
+    // ping-pong LDS variant (one workgroup per CU); TDX_CONV3_PP=0/1 overrides for A/B runs
+    static const int force_pp = getenv("TDX_CONV3_PP") ? atoi(getenv("TDX_CONV3_PP")) : -1;
+    const bool PPv = force_pp >= 0 ? (force_pp != 0) : M3_DEFAULT_PP;
     const int BX = 2 * MT;
     const int nbx = ceil_div(g.Xo, BX), nby = ceil_div(g.Yo, M3_BY), nbz = ceil_div(g.Zo, M3_BZ);
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31)) return TDX_ESHAPE;  // a_src packs (voxel, half) in 31 bits
     dim3 grid((unsigned)((int64_t)g.B * nbx * nby * nbz), Cout / BN);
-    const size_t lds = (size_t)2 * ((BX + 2) * M3_HY * M3_SZ * 16 + 64) + (size_t)27 * BN * 32 + 128;
-#define M3_LAUNCH(NTV, MTV, ZP)                                                                                      \
+    const size_t stage = (size_t)2 * ((BX + 2) * M3_HY * M3_SZ * 16 + 64) + (size_t)27 * BN * 32 + 128;
+    const size_t lds = PPv ? 2 * stage : stage;
+#define M3_LAUNCH_PP(NTV, MTV, ZP, PPV)                                                                              \
     do {                                                                                                             \
-        auto kern = conv3_mfma_kernel<NTV, MTV, ZP>;                                                                 \
+        auto kern = conv3_mfma_kernel<NTV, MTV, ZP, PPV>;                                                            \
         static bool attr_set = false;                                                                                \
         if (!attr_set) {                                                                                             \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -356,10 +388,16 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
                            (const bf16*)wp, bias, (bf16*)y, g, Cout, nbx, nby, nbz, gn_acc, (bf16*)d1, D1,           \
                            (bf16*)d2, (const bf16*)a1, (const bf16*)a2);                                             \
     } while (0)
+#define M3_LAUNCH(NTV, MTV, ZP)                                     \
+    do {                                                            \
+        if (PPv) M3_LAUNCH_PP(NTV, MTV, ZP, true);                  \
+        else M3_LAUNCH_PP(NTV, MTV, ZP, false);                     \
+    } while (0)
     if (NT == 2 && MT == 4) { if (zero_pad) M3_LAUNCH(2, 4, true); else M3_LAUNCH(2, 4, false); }
     else if (NT == 2)       { if (zero_pad) M3_LAUNCH(2, 2, true); else M3_LAUNCH(2, 2, false); }
     else if (MT == 4)       { if (zero_pad) M3_LAUNCH(1, 4, true); else M3_LAUNCH(1, 4, false); }
     else                    { if (zero_pad) M3_LAUNCH(1, 2, true); else M3_LAUNCH(1, 2, false); }
 #undef M3_LAUNCH
+#undef M3_LAUNCH_PP
     return tdx_launch_status();
 }
