@@ -1,31 +1,46 @@
 // bf16 MFMA implicit-GEMM 3x3x3 convolution for gfx950 (forward and, with zero padding on
 // the padded grid, the data gradient).
 //
-//   M = output voxels (a 4 x 8 x 8 brick per workgroup), N = output channels (BN = 32/64
-//   per workgroup), K = 27 taps x input channels, walked in 16-channel slices.
+//   M = output voxels (a 256-voxel brick per workgroup), N = output channels (BN = 32/64 per
+//   workgroup), K = 27 taps x input channels, walked in 16-channel slices.
 //
-// Per K slice the workgroup stages ONE halo'd input brick (6 x 10 x 10 voxels x 16 ch =
-// 19 KB) and the slice's weights for all 27 taps (27 x BN x 16 = 54 KB at BN = 64) into
-// LDS; every tap then re-reads the same brick at a shifted voxel offset, so the 27-fold
-// input reuse of the convolution is served from LDS, not from L2/HBM.  78 KB of LDS per
-// workgroup -> two workgroups per CU.
+// Per K slice the workgroup stages ONE halo'd input brick (6 x 10 x 10 voxels x 16 ch = 19 KB)
+// and the slice's weights for all 27 taps (27 x BN x 16 = 54 KB at BN = 64) into LDS; every tap
+// then re-reads the same brick at a shifted voxel offset, so the 27-fold input reuse of the
+// convolution is served from LDS, not from L2/HBM.  78 KB of LDS per workgroup -> two
+// workgroups per CU, one staging while the other issues MFMAs.
 //
-// Pipeline: the global loads of slice c+1 are issued into registers right after slice c has
-// been written to LDS and stay in flight during the 27 x 2 x NT MFMAs of slice c (the wait
-// lands at the next LDS write), so L2/HBM latency hides behind the matrix work; the second
-// workgroup on the CU covers the short LDS-write window.
+// Pipeline: the global loads of slice c+1 are issued into registers right after slice c has been
+// written to LDS and stay in flight during the 27 x 2 x NT MFMAs of slice c (the wait lands at
+// the next LDS write); inside a slice the fragments of tap t+1 are read while the MFMAs of tap t
+// issue (pinned with sched_group_barrier).
 //
-// Wave w owns the x = w slab of the brick: 8 x 8 voxels = two 32-voxel M tiles
-// (r <-> y = 4*mt + (r & 3), z = r >> 2) x NT 32-channel N tiles.  The MFMA is issued as
-// D^T = W^T X^T (weights as the A operand), so a lane owns ONE voxel and 4 consecutive
-// channels per accumulator quad: the epilogue packs them to 8-B writes of an LDS output
-// tile [256 voxels][BN] that is then stored to HBM in whole 16-B-per-lane voxel rows.
+// Wave w owns an 8 x 8 (y, z) slab of the brick = two 32-voxel M tiles (r <-> y = 4*mt + (r & 3),
+// z = r >> 2) x NT 32-channel N tiles.  The MFMA is issued as D^T = W^T X^T (weights as the A
+// operand), so a lane owns ONE voxel and 4 consecutive channels per accumulator quad: the
+// epilogue packs them to 8-B writes of an LDS output tile [256 voxels][BN] that is then stored to
+// HBM in whole 16-B-per-lane voxel rows (+ fused GroupNorm moments, + fused residual addend for
+// the data gradient).
 //
-// LDS images (conflict-free for ds_read_b128, checked by exhaustive enumeration of the
-// 16-lane read groups over all tap offsets), each split in two half-planes holding
-// channels 0-7 and 8-15 of the slice so that a lane's 16-B fragment is one plane entry:
-//   brick  : [half][voxel h = (hx*10 + hy)*12 + hz] (z stride padded 10 -> 12), 16 B each
-//   weights: [half][tap*BN + n], 16 B each
+// LDS images, each split in two half-planes (channels 0-7 / 8-15 of the slice) of 16-B entries:
+//   brick  : [half][voxel h = (hx*HY + hy)*SZ + hz]; with the main shape's z stride padded
+//            10 -> 12 the 16 voxels of every ds_read_b128 lane group are distinct mod 16, i.e.
+//            conflict-free with plain affine addresses (tap offsets are instruction immediates;
+//            found by exhaustive enumeration of lane groups x tap offsets)
+//   weights: [half][tap*BN + n]
+//
+// Brick shapes.  The main shape is 4 x 8 x 8 (wave = x plane).  Grids whose extent leaves a
+// remainder of 1-2 voxels along an axis -- every padded data-gradient grid (X+2 ...), and the
+// reference's real 194 x 50 x 50 grids -- would waste a whole row of mostly empty bricks per such
+// axis (+34 % bricks at 194 x 66 x 50), so those remainder slabs are tiled with a thin
+// 2 x 16 x 8 brick (XT: wave = (x plane, y half)), with the kernel's local axes permuted so that
+// its thin axis is the slab's thin axis.  All index arithmetic is therefore in "local axes" with
+// explicit voxel strides.
+//
+// Measured alternatives that lost (kept out of the build): an 8 x 8 x 8 brick with a 128 x 64
+// register tile per wave and one workgroup per CU (-5...-30 %), and a ping-pong-LDS single
+// workgroup per CU with one barrier per slice (700 vs 840 TFLOP/s): with this much LDS traffic
+// per MFMA, two co-resident workgroups hide more than a deeper pipeline in one.
 #include "tdx_common.h"
 #include "tdx_conv3.h"
 #include <stdlib.h>
@@ -33,27 +48,26 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-#define M3_BX 4                                // x extent of the brick at MT = 2 (2*MT in general)
-#define M3_BY 8
-#define M3_BZ 8
-#define M3_HX (M3_BX + 2)
-#define M3_HY (M3_BY + 2)
-#define M3_HZ (M3_BZ + 2)
-#define M3_SZ 12                               // padded z stride of the LDS brick
-#define M3_NVOX_HALO (M3_HX * M3_HY * M3_HZ)   // 600
-#define M3_BRICK_BYTES (M3_HX * M3_HY * M3_SZ * 32 + 128)  // 23168
 #define M3_KC 16
-#define M3_DEFAULT_PP false
 
 bool conv3_mfma_supported(int C1, int C2, int Cout) {
     return C1 > 0 && (C1 % M3_KC) == 0 && (C2 % M3_KC) == 0 && (Cout % 32) == 0;
 }
 
-// two half-planes (channels 0-7 / 8-15 of the slice), 16 B per voxel: with the z stride of 12
-// the 16 voxels of every ds_read_b128 lane group are distinct mod 16 -> conflict-free with
-// plain affine addresses (tap offsets become instruction immediates)
-#define M3_APLANE (M3_HX * M3_HY * M3_SZ * 16 + 64)  // +64 B: the two halves of a voxel land 4 slots apart
-__device__ __forceinline__ int brick_addr(int h, int half) { return half * M3_APLANE + h * 16; }
+// geometry of one launch, in the kernel's local axes (axis 0 = brick "x", axis 2 = brick "z")
+struct ConvView {
+    int B;
+    int Ei[3];   // input grid extents
+    int si[3];   // input voxel strides
+    int so[3];   // output voxel strides
+    int r0[3];   // first output coordinate of the region handled by this launch
+    int r1[3];   // end (exclusive)
+    int nb[3];   // bricks per axis
+    int off;     // output voxel o reads input voxel o + off + e
+    int ws[3];   // weight-tap strides of the local axes: tap index = sum_k (e_k + 1) * ws[k]  ({9,3,1} permuted)
+    int in_batch, out_batch;  // voxels per sample
+};
+
 // output tile rows of 64 B (BN = 32) or 128 B (BN = 64); 16-B chunk c of row v at c ^ swizzle(v)
 template <int BN>
 __device__ __forceinline__ int out_addr(int v, int c) {
@@ -61,26 +75,23 @@ __device__ __forceinline__ int out_addr(int v, int c) {
     return v * 64 + ((c ^ ((v >> 1) & 3)) << 4);
 }
 
-// MT = 32-voxel M tiles per wave: 2 (4x8x8 brick, 2 workgroups/CU) or 4 (8x8x8 brick, one
-// workgroup/CU with twice the register tile -> 25 % fewer LDS fragment bytes per MFMA).
-// PP = ping-pong LDS: one workgroup per CU owns two stage buffers; slice c+1 is written into the
-// idle buffer at the top of slice c's MFMA phase (its global loads were issued a slice earlier),
-// so there is ONE barrier per slice and the staging costs only its issue slots.
-template <int NT, int MT, bool ZERO_PAD, bool PP>
-__global__ void __launch_bounds__(256, (MT == 2 && !PP) ? 2 : 1)
+template <int NT, bool XT, bool ZERO_PAD>
+__global__ void __launch_bounds__(256, 2)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
-                  const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, Conv3Geom g,
-                  int Cout, int nbx, int nby, int nbz, double* __restrict__ gn_acc, bf16* __restrict__ d1, int D1,
-                  bf16* __restrict__ d2, const bf16* __restrict__ a1, const bf16* __restrict__ a2) {
+                  const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, ConvView g,
+                  int Cout, double* __restrict__ gn_acc, bf16* __restrict__ d1, int D1, bf16* __restrict__ d2,
+                  const bf16* __restrict__ a1, const bf16* __restrict__ a2) {
     constexpr int BN = NT * 32;
-    constexpr int BX = 2 * MT, HX = BX + 2;
-    constexpr int NVOX = BX * M3_BY * M3_BZ;                 // 256 / 512 output voxels
-    constexpr int NHALO = HX * M3_HY * M3_HZ;                // 600 / 1000 staged voxels
-    constexpr int APLANE = HX * M3_HY * M3_SZ * 16 + 64;     // one half-plane of the brick image
+    constexpr int BX = XT ? 2 : 4, BY = XT ? 16 : 8, BZ = 8;
+    constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
+    constexpr int SZ = XT ? 10 : 12;                    // z stride of the LDS brick (padded for the main shape)
+    constexpr int NHALO = HX * HY * HZ;                 // 600 / 720 staged voxels
+    constexpr int APLANE = HX * HY * SZ * 16 + 64;      // +64 B: the two halves of a voxel land 4 slots apart
     constexpr int BRICK_BYTES = 2 * APLANE;
     constexpr int B_PLANE = 27 * BN * 16 + 64;
-    constexpr int STAGE_BYTES = BRICK_BYTES + 2 * B_PLANE;   // one stage buffer (brick + weights)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + BRICK_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -88,18 +99,18 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 
     // block -> (n tile, b, brick)
     int bid = blockIdx.x;
-    const int bz = bid % nbz; bid /= nbz;
-    const int by = bid % nby; bid /= nby;
-    const int bx = bid % nbx; bid /= nbx;
+    const int b2 = bid % g.nb[2]; bid /= g.nb[2];
+    const int b1 = bid % g.nb[1]; bid /= g.nb[1];
+    const int b0 = bid % g.nb[0]; bid /= g.nb[0];
     const int b = bid;
     const int n0 = blockIdx.y * BN;
-    const int ox0 = bx * BX, oy0 = by * M3_BY, oz0 = bz * M3_BZ;
+    const int o0 = g.r0[0] + b0 * BX, o1 = g.r0[1] + b1 * BY, o2 = g.r0[2] + b2 * BZ;
     const int Cin = C1 + C2;
 
-    // ---- staging plan for the input brick: 1200 16-B pieces, <= 5 per thread.
-    // a_src: (voxel index in the input grid) * 2 + half, or -1 for zero fill / no piece
+    // ---- staging plan for the input brick: 2 * NHALO 16-B pieces, 5-6 per thread.
+    // a_src: (voxel index in the sample's input grid) * 2 + half, or -1 for zero fill / no piece
     constexpr int A_PIECES = NHALO * 2;
-    constexpr int A_PER_THREAD = (A_PIECES + 255) / 256;  // 5 / 8
+    constexpr int A_PER_THREAD = (A_PIECES + 255) / 256;
     constexpr int B_PIECES = 27 * BN * 2;
     constexpr int B_PER_THREAD = (B_PIECES + 255) / 256;  // 14 (NT=2) / 7 (NT=1)
     int a_src[A_PER_THREAD];
@@ -112,24 +123,25 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         if (p < A_PIECES) {
             // lanes 0-3 / 4-7 of every 8-lane group: 4 consecutive voxels x the two halves
             const int hv = ((p >> 3) << 2) + (p & 3), half = (p >> 2) & 1;
-            const int hx = hv / (M3_HY * M3_HZ), rem = hv - hx * (M3_HY * M3_HZ);
-            const int hy = rem / M3_HZ, hz = rem - hy * M3_HZ;
-            a_dst[i] = half * APLANE + ((hx * M3_HY + hy) * M3_SZ + hz) * 16;
-            int sx = ox0 + hx - 1 + g.off, sy = oy0 + hy - 1 + g.off, sz = oz0 + hz - 1 + g.off;
+            const int hx = hv / (HY * HZ), rem = hv - hx * (HY * HZ);
+            const int hy = rem / HZ, hz = rem - hy * HZ;
+            a_dst[i] = half * APLANE + ((hx * HY + hy) * SZ + hz) * 16;
+            int s0 = o0 + hx - 1 + g.off, s1 = o1 + hy - 1 + g.off, s2 = o2 + hz - 1 + g.off;
             bool ok = true;
             if (ZERO_PAD) {
-                ok = sx >= 0 && sx < g.Xi && sy >= 0 && sy < g.Yi && sz >= 0 && sz < g.Zi;
+                ok = s0 >= 0 && s0 < g.Ei[0] && s1 >= 0 && s1 < g.Ei[1] && s2 >= 0 && s2 < g.Ei[2];
             } else {
-                sx = min(max(sx, 0), g.Xi - 1); sy = min(max(sy, 0), g.Yi - 1); sz = min(max(sz, 0), g.Zi - 1);
+                s0 = min(max(s0, 0), g.Ei[0] - 1); s1 = min(max(s1, 0), g.Ei[1] - 1); s2 = min(max(s2, 0), g.Ei[2] - 1);
             }
-            if (ok) a_src[i] = ((sx * g.Yi + sy) * g.Zi + sz) * 2 + half;
+            if (ok) a_src[i] = (s0 * g.si[0] + s1 * g.si[1] + s2 * g.si[2]) * 2 + half;
         }
     }
-    const int64_t batch_vox = (int64_t)b * g.Xi * g.Yi * g.Zi;
+    const int64_t batch_vox = (int64_t)b * g.in_batch;
 
-    // weight staging role of this thread
+    // weight staging role of this thread: (row = b_row0 + 128 i, half); 128 rows = 128/BN taps per
+    // step, so both the global and the LDS address advance by a constant per i
     const int b_half = (tid >> 2) & 1;
-    const int b_row0 = ((tid >> 3) << 2) + (tid & 3);                       // 0..127
+    const int b_row0 = ((tid >> 3) << 2) + (tid & 3);                             // 0..127
     const int b_goff = ((b_row0 / BN) * Cout + (b_row0 % BN)) * 16 + b_half * 8;  // elements
     const int b_dst = b_half * B_PLANE + b_row0 * 16;
 
@@ -146,8 +158,6 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             if (a_src[i] >= 0)
                 areg[i] = *reinterpret_cast<const uint4*>(xs + (int64_t)(a_src[i] >> 1) * Cs + (a_src[i] & 1) * 8);
         }
-        // weights: thread -> (row = b_row0 + 128 i, half); 128 rows = 128/BN taps per step, so both
-        // the global and the LDS address advance by a constant per i
         const bf16* wc = wp + (int64_t)c * 27 * Cout * 16 + (int64_t)n0 * 16 + b_goff;
 #pragma unroll
         for (int i = 0; i < B_PER_THREAD; ++i) {
@@ -156,9 +166,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
                 breg[i] = *reinterpret_cast<const uint4*>(wc + (int64_t)i * (128 / BN) * Cout * 16);
         }
     };
-    auto store_slice = [&](int buf) {
-        unsigned char* sA = smem + buf * STAGE_BYTES;
-        unsigned char* sB = sA + BRICK_BYTES;
+    auto store_slice = [&]() {
 #pragma unroll
         for (int i = 0; i < A_PER_THREAD; ++i)
             if (a_dst[i] >= 0) *reinterpret_cast<uint4*>(sA + a_dst[i]) = areg[i];
@@ -167,98 +175,75 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             if (b_row0 + 128 * i < 27 * BN) *reinterpret_cast<uint4*>(sB + b_dst + i * 2048) = breg[i];
     };
 
-    // ---- per-lane fragment bases
-    // M tile mt of wave w: x = w*(MT/2) + (mt >> 1), y = 4*(mt & 1) + (r & 3), z = r >> 2
-    int a_h[MT];
+    // ---- per-lane fragment bases.  Wave w owns brick plane wx and the y rows [wy0, wy0 + 8):
+    // M tile mt: y = wy0 + 4*mt + (r & 3), z = r >> 2
+    const int wx = XT ? (wave >> 1) : wave, wy0 = XT ? 8 * (wave & 1) : 0;
+    int a_h[2];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        a_h[mt] = ((wave * (MT / 2) + (mt >> 1) + 1) * M3_HY + (4 * (mt & 1) + (r & 3) + 1)) * M3_SZ + ((r >> 2) + 1);
+    for (int mt = 0; mt < 2; ++mt)
+        a_h[mt] = ((wx + 1) * HY + (wy0 + 4 * mt + (r & 3) + 1)) * SZ + ((r >> 2) + 1);
     int b_off[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = nt * 32 + r;
-        b_off[nt] = hh * B_PLANE + n * 16;
-    }
+    for (int nt = 0; nt < NT; ++nt) b_off[nt] = hh * B_PLANE + (nt * 32 + r) * 16;
 
-    f32x16 acc[NT][MT];  // D[row = channel][col = voxel]
+    f32x16 acc[NT][2];  // D[row = channel][col = voxel]
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
 
     const int nchunks = Cin / M3_KC;
-    // the 27 x (MT x NT) MFMAs of one slice; fragments of tap t+1 are read while the MFMAs of tap t
-    // issue (two register sets)
-    auto compute_slice = [&](int buf) {
-        const unsigned char* sA = smem + buf * STAGE_BYTES;
-        const unsigned char* sB = sA + BRICK_BYTES;
-        constexpr int PD = PP ? 3 : 1;       // fragment prefetch distance in taps (ring of PD + 1 sets):
-        constexpr int RING = PD + 1;         // one wave per SIMD (PP) has to cover the LDS latency alone
-        bf16x8 xf[RING][MT], wf[RING][NT];
+    load_slice(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();  // previous slice's fragment reads are done
+        store_slice();
+        __syncthreads();
+        if (c + 1 < nchunks) load_slice(c + 1);  // in flight during the MFMAs below
+
+        // fragments of tap t+1 are read while the MFMAs of tap t issue (two register sets)
+        bf16x8 xf[2][2], wf[2][NT];
         auto read_frags = [&](int tap, int buf) {
             const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
-            const int toff = (ex * M3_HY + ey) * M3_SZ + ez;
+            const int toff = (ex * HY + ey) * SZ + ez;
+            // the weight tap is indexed in GLOBAL axes; thin bricks run on permuted local axes
+            const int wtap = XT ? (ex + 1) * g.ws[0] + (ey + 1) * g.ws[1] + (ez + 1) * g.ws[2] : tap;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
                 xf[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + hh * APLANE + (a_h[mt] + toff) * 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                wf[buf][nt] = *reinterpret_cast<const bf16x8*>(sB + tap * (BN * 16) + b_off[nt]);
+                wf[buf][nt] = *reinterpret_cast<const bf16x8*>(sB + wtap * (BN * 16) + b_off[nt]);
         };
-#pragma unroll
-        for (int t = 0; t < PD; ++t) read_frags(t, t);
-        __builtin_amdgcn_sched_group_barrier(0x100, PD * (MT + NT), 0);  // DS_READ: the first PD taps
+        read_frags(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);  // DS_READ: tap 0's fragments
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
-            if (tap + PD < 27) read_frags(tap + PD, (tap + PD) % RING);
+            if (tap + 1 < 27) read_frags(tap + 1, (tap + 1) & 1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap % RING][nt], xf[tap % RING][mt], acc[nt][mt], 0, 0, 0);
-            // pin the interleave: one fragment read of tap+PD behind each MFMA of tap
-            if (tap + PD < 27) {
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap & 1][nt], xf[tap & 1][mt], acc[nt][mt], 0, 0, 0);
+            // pin the interleave: one fragment read of tap+1 behind each MFMA of tap
+            if (tap + 1 < 27) {
 #pragma unroll
-                for (int k = 0; k < MT * NT; ++k) {
+                for (int k = 0; k < 2 * NT; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                    if (k < MT + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS_READ
+                    if (k < 2 + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS_READ
                 }
             } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
             }
         }
-    };
-
-    load_slice(0);
-    if constexpr (PP) {
-        store_slice(0);
-        __syncthreads();
-        if (nchunks > 1) load_slice(1);
-        for (int c = 0; c < nchunks; ++c) {
-            if (c + 1 < nchunks) {
-                store_slice((c + 1) & 1);                  // buffer last read during slice c-1
-                if (c + 2 < nchunks) load_slice(c + 2);    // in flight for a whole slice
-            }
-            compute_slice(c & 1);
-            __syncthreads();
-        }
-    } else {
-        for (int c = 0; c < nchunks; ++c) {
-            __syncthreads();  // previous slice's fragment reads are done
-            store_slice(0);
-            __syncthreads();
-            if (c + 1 < nchunks) load_slice(c + 1);  // in flight during the MFMAs below
-            compute_slice(0);
-        }
-        __syncthreads();
     }
 
     // ---------------- epilogue.  Lane (r, hh) of wave w holds, for M tile mt, voxel
-    // (x = w, y = 4 mt + (r & 3), z = r >> 2) and channels nt*32 + 8 j + 4 hh + (0..3) in
-    // accumulator registers 4 j .. 4 j + 3.
-    unsigned char* sO = smem;  // [NVOX voxels][BN] bf16, voxel v = (x*8 + y)*8 + z
+    // (wx, wy0 + 4 mt + (r & 3), r >> 2) and channels nt*32 + 8 j + 4 hh + (0..3) in accumulator
+    // registers 4 j .. 4 j + 3.  Tile voxel index v = (x*BY + y)*8 + z.
+    __syncthreads();
+    unsigned char* sO = smem;  // [256 voxels][BN] bf16
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -270,8 +255,8 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
                 for (int e = 0; e < 4; ++e) bv[e] = bias[n0 + ch + e];
             }
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int v = ((wave * (MT / 2) + (mt >> 1)) * 8 + 4 * (mt & 1) + (r & 3)) * 8 + (r >> 2);
+            for (int mt = 0; mt < 2; ++mt) {
+                const int v = (wx * BY + wy0 + 4 * mt + (r & 3)) * 8 + (r >> 2);
                 const unsigned lo = (unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j] + bv[0]) |
                                     ((unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 1] + bv[1]) << 16);
                 const unsigned hi = (unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 2] + bv[2]) |
@@ -289,22 +274,22 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < CHUNKS * NVOX / 256; ++i) {
+    for (int i = 0; i < CHUNKS; ++i) {
         const int p = tid + i * 256;
         const int v = p / CHUNKS, cidx = p % CHUNKS;
-        const int ox = ox0 + (v >> 6), oy = oy0 + ((v >> 3) & 7), oz = oz0 + (v & 7);
-        if (ox < g.Xo && oy < g.Yo && oz < g.Zo) {
+        const int c0 = o0 + (v >> 3) / BY, c1 = o1 + (v >> 3) % BY, c2 = o2 + (v & 7);
+        if (c0 < g.r1[0] && c1 < g.r1[1] && c2 < g.r1[2]) {
             const uint4 val = *reinterpret_cast<const uint4*>(sO + out_addr<BN>(v, cidx));
             bool direct = false;
             if (ZERO_PAD && d1 != nullptr) {
-                // data gradient: padded position (ox,oy,oz) = original voxel + 1.  Interior positions
-                // go straight to dx (split over the two inputs of a concatenated conv); only the
+                // data gradient: padded position = original voxel + 1.  Interior positions go
+                // straight to dx (split over the two inputs of a concatenated conv, plus the optional
+                // fused addend = the gradient arriving over the block's residual path); only the
                 // halo shell is written to the padded workspace for the face fix-up.
-                const int ux = ox - 1, uy = oy - 1, uz = oz - 1;
-                if (ux >= 0 && ux < g.Xi && uy >= 0 && uy < g.Yi && uz >= 0 && uz < g.Zi) {
-                    const int64_t u = (((int64_t)b * g.Xi + ux) * g.Yi + uy) * g.Zi + uz;
+                const int u0 = c0 - 1, u1 = c1 - 1, u2 = c2 - 1;
+                if (u0 >= 0 && u0 < g.Ei[0] && u1 >= 0 && u1 < g.Ei[1] && u2 >= 0 && u2 < g.Ei[2]) {
+                    const int64_t u = (int64_t)b * g.in_batch + u0 * g.si[0] + u1 * g.si[1] + u2 * g.si[2];
                     const int n = n0 + cidx * 8;
-                    // optional fused addend (the gradient arriving over the block's residual path)
                     const bool lo = n < D1;
                     bf16* dst = lo ? d1 + u * D1 + n : d2 + u * (Cout - D1) + (n - D1);
                     const bf16* asrc = lo ? (a1 ? a1 + u * D1 + n : nullptr) : (a2 ? a2 + u * (Cout - D1) + (n - D1) : nullptr);
@@ -321,8 +306,10 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
                     direct = true;
                 }
             }
-            if (!direct)
-                *reinterpret_cast<uint4*>(y + ((((int64_t)b * g.Xo + ox) * g.Yo + oy) * g.Zo + oz) * Cout + n0 + cidx * 8) = val;
+            if (!direct) {
+                const int64_t ov = (int64_t)b * g.out_batch + c0 * g.so[0] + c1 * g.so[1] + c2 * g.so[2];
+                *reinterpret_cast<uint4*>(y + ov * Cout + n0 + cidx * 8) = val;
+            }
             if (gn_acc != nullptr) {
                 const unsigned wds[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
@@ -336,7 +323,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     }
     if (gn_acc != nullptr) {
         constexpr int NP = 256 / CHUNKS;  // threads per chunk column
-        float* red = reinterpret_cast<float*>(smem + NVOX * BN * 2);  // [NP][BN][2], behind the output tile
+        float* red = reinterpret_cast<float*>(smem + 256 * BN * 2);  // [NP][BN][2], behind the output tile
         const int cidx = tid % CHUNKS, part = tid / CHUNKS;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -356,48 +343,90 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     }
 }
 
+template <int NT, bool XT, bool ZP>
+static int launch_view(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
+                       const ConvView& v, int Cout, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
+                       const void* a1, const void* a2) {
+    constexpr int BN = NT * 32;
+    constexpr int HXv = (XT ? 2 : 4) + 2, HYv = (XT ? 16 : 8) + 2, SZv = XT ? 10 : 12;
+    const size_t lds = (size_t)2 * (HXv * HYv * SZv * 16 + 64) + (size_t)27 * BN * 32 + 128;
+    auto kern = conv3_mfma_kernel<NT, XT, ZP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((int64_t)v.B * v.nb[0] * v.nb[1] * v.nb[2]), Cout / BN);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2, (const bf16*)wp, bias,
+                       (bf16*)y, v, Cout, gn_acc, (bf16*)d1, D1, (bf16*)d2, (const bf16*)a1, (const bf16*)a2);
+    return tdx_launch_status();
+}
+
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                       const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1,
                       void* d2, const void* a1, const void* a2) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
-    const int BN = NT * 32;
-    // big register tile (8x8x8 bricks) where the grid has room for it and there is enough K to amortise
-    // its longer prologue/epilogue; the env switch is for A/B measurements
-    static const int force_mt = getenv("TDX_CONV3_MT") ? atoi(getenv("TDX_CONV3_MT")) : 0;
-    int MT = 2;  // measured: MT = 4 (one workgroup/CU) is 5-30 % slower on every layer of the U-Net
-    if (force_mt == 2 || force_mt == 4) MT = force_mt;
-    // ping-pong LDS variant (one workgroup per CU); TDX_CONV3_PP=0/1 overrides for A/B runs
-    static const int force_pp = getenv("TDX_CONV3_PP") ? atoi(getenv("TDX_CONV3_PP")) : -1;
-    const bool PPv = force_pp >= 0 ? (force_pp != 0) : M3_DEFAULT_PP;
-    const int BX = 2 * MT;
-    const int nbx = ceil_div(g.Xo, BX), nby = ceil_div(g.Yo, M3_BY), nbz = ceil_div(g.Zo, M3_BZ);
-    if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31)) return TDX_ESHAPE;  // a_src packs (voxel, half) in 31 bits
-    dim3 grid((unsigned)((int64_t)g.B * nbx * nby * nbz), Cout / BN);
-    const size_t stage = (size_t)2 * ((BX + 2) * M3_HY * M3_SZ * 16 + 64) + (size_t)27 * BN * 32 + 128;
-    const size_t lds = PPv ? 2 * stage : stage;
-#define M3_LAUNCH_PP(NTV, MTV, ZP, PPV)                                                                              \
-    do {                                                                                                             \
-        auto kern = conv3_mfma_kernel<NTV, MTV, ZP, PPV>;                                                            \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set) {                                                                                             \
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return (int)e;                                                                      \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2,                 \
-                           (const bf16*)wp, bias, (bf16*)y, g, Cout, nbx, nby, nbz, gn_acc, (bf16*)d1, D1,           \
-                           (bf16*)d2, (const bf16*)a1, (const bf16*)a2);                                             \
-    } while (0)
-#define M3_LAUNCH(NTV, MTV, ZP)                                     \
-    do {                                                            \
-        if (PPv) M3_LAUNCH_PP(NTV, MTV, ZP, true);                  \
-        else M3_LAUNCH_PP(NTV, MTV, ZP, false);                     \
-    } while (0)
-    if (NT == 2 && MT == 4) { if (zero_pad) M3_LAUNCH(2, 4, true); else M3_LAUNCH(2, 4, false); }
-    else if (NT == 2)       { if (zero_pad) M3_LAUNCH(2, 2, true); else M3_LAUNCH(2, 2, false); }
-    else if (MT == 4)       { if (zero_pad) M3_LAUNCH(1, 4, true); else M3_LAUNCH(1, 4, false); }
-    else                    { if (zero_pad) M3_LAUNCH(1, 2, true); else M3_LAUNCH(1, 2, false); }
-#undef M3_LAUNCH
-#undef M3_LAUNCH_PP
-    return tdx_launch_status();
+    if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
+    static const bool no_thin = getenv("TDX_CONV3_THIN") && atoi(getenv("TDX_CONV3_THIN")) == 0;  // A/B switch
+
+    // global axes: 0 = x, 1 = y, 2 = z (z fastest in memory)
+    const int Ei[3] = {g.Xi, g.Yi, g.Zi}, Eo[3] = {g.Xo, g.Yo, g.Zo};
+    const int si[3] = {g.Yi * g.Zi, g.Zi, 1}, so[3] = {g.Yo * g.Zo, g.Zo, 1};
+    const int bdim[3] = {4, 8, 8};
+    // an axis whose extent leaves a remainder of 1-2 voxels gets a thin slab instead of a row of
+    // mostly empty main bricks
+    // (measured: pays on the two finest U-Net levels, loses to the extra launches below ~50k voxels)
+    static const bool force_thin = getenv("TDX_CONV3_THIN") && atoi(getenv("TDX_CONV3_THIN")) == 2;
+    const bool big = force_thin || (int64_t)g.Xo * g.Yo * g.Zo >= 60000;
+    int main_end[3];
+    bool thin[3];
+    for (int a = 0; a < 3; ++a) {
+        const int rem = Eo[a] % bdim[a];
+        thin[a] = !no_thin && rem >= 1 && rem <= 2 && Eo[a] > bdim[a] && big;
+        main_end[a] = thin[a] ? Eo[a] - rem : Eo[a];
+    }
+    auto launch = [&](const int perm[3], const int lo[3], const int hi[3], bool xt) -> int {
+        // local axis k = global axis perm[k]; region [lo, hi) in global output coordinates
+        ConvView v;
+        v.B = g.B; v.off = g.off;
+        v.in_batch = g.Xi * g.Yi * g.Zi; v.out_batch = g.Xo * g.Yo * g.Zo;
+        const int bl[3] = {xt ? 2 : 4, xt ? 16 : 8, 8};
+        for (int k = 0; k < 3; ++k) {
+            const int a = perm[k];
+            if (hi[a] <= lo[a]) return TDX_OK;  // empty region
+            v.Ei[k] = Ei[a]; v.si[k] = si[a]; v.so[k] = so[a];
+            v.ws[k] = (a == 0) ? 9 : (a == 1 ? 3 : 1);
+            v.r0[k] = lo[a]; v.r1[k] = hi[a];
+            v.nb[k] = ceil_div(hi[a] - lo[a], bl[k]);
+        }
+#define M3_GO(NTV, XTV)                                                                                               \
+    (zero_pad ? launch_view<NTV, XTV, true>(x1, C1, x2, C2, wp, bias, y, v, Cout, st, gn_acc, d1, D1, d2, a1, a2)     \
+              : launch_view<NTV, XTV, false>(x1, C1, x2, C2, wp, bias, y, v, Cout, st, gn_acc, d1, D1, d2, a1, a2))
+        if (NT == 2) return xt ? M3_GO(2, true) : M3_GO(2, false);
+        return xt ? M3_GO(1, true) : M3_GO(1, false);
+#undef M3_GO
+    };
+    const int id[3] = {0, 1, 2};
+    const int lo[3] = {0, 0, 0}, hi[3] = {main_end[0], main_end[1], main_end[2]};
+    int rc = launch(id, lo, hi, false);
+    if (rc != TDX_OK) return rc;
+    // x slab: [main_end_x, Xo) x all y x all z           (local axes x, y, z)
+    if (thin[0]) {
+        const int l[3] = {main_end[0], 0, 0}, h[3] = {Eo[0], Eo[1], Eo[2]};
+        if ((rc = launch(id, l, h, true)) != TDX_OK) return rc;
+    }
+    // y slab: main x range x [main_end_y, Yo) x all z    (local axes y, x, z)
+    if (thin[1]) {
+        const int pm[3] = {1, 0, 2};
+        const int l[3] = {0, main_end[1], 0}, h[3] = {main_end[0], Eo[1], Eo[2]};
+        if ((rc = launch(pm, l, h, true)) != TDX_OK) return rc;
+    }
+    // z slab: main x, y ranges x [main_end_z, Zo)         (local axes z, x, y)
+    if (thin[2]) {
+        const int pm[3] = {2, 0, 1};
+        const int l[3] = {0, 0, main_end[2]}, h[3] = {main_end[0], main_end[1], Eo[2]};
+        if ((rc = launch(pm, l, h, true)) != TDX_OK) return rc;
+    }
+    return TDX_OK;
 }

@@ -474,3 +474,35 @@ def test_attention_full_config5_size(monkeypatch):
     assert rel_l2(op.float(), out.float()) < 5e-3
     # (3) exact vector kernel on the same input, first 4096 queries only would need a sliced API;
     #     instead compare full outputs at a reduced size inside test_attention_mfma_forward
+
+
+@pytest.mark.parametrize("grid", [(18, 10, 10), (10, 18, 9), (9, 10, 18), (14, 18, 18), (6, 9, 10)])
+def test_conv3_thin_slab_bricks(grid, monkeypatch):
+    """grids with a 1-2 voxel remainder per axis (the reference's real 194x50x50 family and every
+    padded data-gradient grid) are tiled with thin 2x16x8 bricks on permuted axes: same numbers
+    as the all-main-brick tiling (TDX_CONV3_THIN=0 is read once per process, so compare with the
+    vector-ALU kernels instead) and as the oracle."""
+    from turbdiff_amd import ops
+
+    X, Y, Z = grid
+    B, Cin, Cout = 2, 32, 64
+    x = q(rnd(B, Cin, X, Y, Z, seed=1), torch.bfloat16)
+    w = q(rnd(Cout, Cin, 3, 3, 3, seed=2, scale=0.05), torch.bfloat16)
+    gy = q(rnd(B, Cout, X, Y, Z, seed=3), torch.bfloat16)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    yr = O.conv3_replicate(xr, wr)
+    yr.backward(gy.double())
+    outs = {}
+    for impl in ("mfma", "direct"):
+        monkeypatch.setenv("TDX_CONV_IMPL", impl)
+        xd = nvc(x).to(dev()).bfloat16().requires_grad_()
+        wd = w.to(dev()).requires_grad_()
+        y, stats = ops.conv3_gn_stats(xd, wd, None, 8)
+        y.backward(nvc(gy).to(dev()).bfloat16())
+        outs[impl] = (y.float(), xd.grad.float(), stats)
+        assert rel_l2(ncv(y.float().cpu()), yr) < BF16_TOL
+        assert rel_l2(ncv(xd.grad.float().cpu()), xr.grad) < BF16_TOL
+        assert rel_l2(wd.grad.cpu(), wr.grad) < BF16_TOL
+    assert rel_l2(outs["mfma"][0], outs["direct"][0]) < 3e-3
+    assert rel_l2(outs["mfma"][1], outs["direct"][1]) < 3e-3
+    assert torch.allclose(outs["mfma"][2], outs["direct"][2], rtol=2e-3, atol=2e-3)
