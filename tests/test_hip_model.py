@@ -288,3 +288,32 @@ def test_trainer_training_step_and_sample(golden):
     inside[g["cell_idx"]] = True
     assert rel_l2(out.cpu().flatten(-3)[..., ~inside], raw.flatten(-3)[..., ~inside]) < 1e-5
     assert task.measure_sample_time(batch) > 0
+
+
+@pytest.mark.parametrize("grid,levels", [((50, 26, 18), 3), ((13, 7, 6), 2), ((97, 25, 25), 2)])
+def test_odd_grids_forward_and_grads_vs_oracle(grid, levels):
+    """Grids that do not divide the brick sizes (the reference's real data is 194x50x50 -> 97x25x25
+    -> ...; resampling uses max(int(s/2), 3), ddpm.py:358): HIP model vs the CPU oracle, fp32 and
+    bf16, forward and parameter gradients."""
+    from turbdiff_amd.models.ddpm import DenoisingModel
+
+    torch.manual_seed(5)
+    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=50, dim=16,
+                         u_net_levels=levels, norm_type="group")
+    sd = {k: v.clone().requires_grad_() for k, v in net.state_dict().items()}
+    gx = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 4, *grid, generator=gx)
+    c_local = torch.randn(4, *grid, generator=gx)
+    t = torch.tensor([3, 41])
+    gy = torch.randn(2, 4, *grid, generator=gx)
+    ref = O.denoiser(sd, x, t, c_local, timesteps=50)
+    ref.backward(gy)
+    net.to(dev())
+    for dtype, tol, gtol in [(torch.float32, 1e-4, 2e-3), (torch.bfloat16, 3e-2, 0.15)]:
+        net.set_compute_dtype(dtype)
+        net.zero_grad(set_to_none=True)
+        y = net(x.to(dev()), t.to(dev()), cond(c_local))
+        y.backward(gy.to(dev()))
+        assert rel_l2(y.cpu(), ref) < tol, (dtype, rel_l2(y.cpu(), ref))
+        for name, p in net.named_parameters():
+            assert_grad_close(name, p.grad.cpu(), sd[name].grad, gtol, noise_floor=1e-5)
