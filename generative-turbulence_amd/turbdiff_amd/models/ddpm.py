@@ -520,3 +520,83 @@ class GaussianDiffusion(nn.Module):
     def forward(self, x, *args, **kwargs):
         t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=x.device, dtype=torch.long)
         return self.p_losses(x, t, *args, **kwargs)
+
+
+# --------------------------------------------------------------------------- rarely used surface
+# Symbols of the reference's ddpm.py that its shipped configuration never instantiates
+# (SURVEY.md §2b).  They are provided on stock torch ops over NCDHW tensors so that code importing
+# them keeps working; none of them is on the accelerated path.
+
+
+def pad_to_multiple_of(x: torch.Tensor, n: int, *, mode: str):
+    """Pad the three trailing dims up to the next multiple of n (reference ddpm.py:51-63; like the
+    reference, a dimension that already is a multiple still receives a full extra block)."""
+    pads = [n - s % n for s in x.shape[-3:]]
+    if min(pads) <= 0:
+        return x, (0, 0, 0)
+    h, w, d = pads
+    return F.pad(x, (0, d, 0, w, 0, h), mode=mode), (h, w, d)
+
+
+def unpad(x: torch.Tensor, padding):
+    if min(padding) <= 0:
+        return x
+    h, w, d = padding
+    return x[..., :-h, :-w, :-d]
+
+
+def expand_as(x: torch.Tensor, y: torch.Tensor, dim: int):
+    """Broadcast y to x's shape everywhere except along `dim` (reference ddpm.py:314-323)."""
+    assert x.ndim >= y.ndim
+    target = list(x.shape)
+    target[dim] = -1
+    return y.expand(target)
+
+
+class LinearAttention(nn.Module):
+    """Efficient attention with linear complexity (Shen et al.); reference ddpm.py:200-229."""
+
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        self.heads = heads
+        hidden = dim_head * heads
+        self.to_qkv = nn.Conv3d(dim, 3 * hidden, 1, bias=False)
+        self.combine_heads = nn.Sequential(nn.Conv3d(hidden, dim, 1))
+
+    def forward(self, x):
+        b, _, X, Y, Z = x.shape
+        qkv = self.to_qkv(x).reshape(b, 3, self.heads, -1, X * Y * Z)
+        q, k, v = qkv[:, 0].softmax(dim=-2), qkv[:, 1].softmax(dim=-1), qkv[:, 2]
+        context = torch.einsum("bhci,bhdi->bhcd", k, v)           # (c, d) summary of keys x values
+        out = torch.einsum("bhcd,bhck->bhdk", context, q)          # apply to every query position
+        return self.combine_heads(out.reshape(b, -1, X, Y, Z))
+
+
+class LocalAttention(nn.Module):
+    """Windowed self-attention over non-overlapping w^3 blocks (reference ddpm.py:232-283)."""
+
+    def __init__(self, dim: int, window_size: int, heads: int = 4, dim_head: int = 32):
+        super().__init__()
+        self.dim, self.window_size, self.heads, self.dim_head = dim, window_size, heads, dim_head
+        hidden = dim_head * heads
+        self.to_qkv = nn.Conv3d(dim, hidden * 3, 1, bias=False)
+        self.merge_heads = nn.Sequential(nn.Conv3d(hidden, dim, 1))
+
+    def forward(self, x):
+        from .attention import fused_attention
+
+        w = self.window_size
+        qkv = self.to_qkv(x)
+        padded = any(s % w != 0 for s in qkv.shape[-3:])
+        if padded:
+            qkv, padding = pad_to_multiple_of(qkv, w, mode="constant")
+        b, _, X, Y, Z = qkv.shape
+        nx, ny, nz = X // w, Y // w, Z // w
+        t = qkv.reshape(b, 3, self.heads, self.dim_head, nx, w, ny, w, nz, w)
+        t = t.permute(1, 0, 4, 6, 8, 2, 5, 7, 9, 3).reshape(3, b * nx * ny * nz, self.heads, w**3, self.dim_head)
+        out = fused_attention(t[0].contiguous(), t[1].contiguous(), t[2].contiguous())
+        out = out.reshape(b, nx, ny, nz, self.heads, w, w, w, self.dim_head)
+        out = out.permute(0, 4, 8, 1, 5, 2, 6, 3, 7).reshape(b, self.heads * self.dim_head, X, Y, Z)
+        if padded:
+            out = unpad(out, padding)
+        return self.merge_heads(out)

@@ -263,6 +263,15 @@ def main():
     gd = R.GaussianDiffusion(nn.Identity(), timesteps=10, beta_schedule="log-snr-linear")
     tt = torch.tensor([3, 9])
     ops.update({"qsample/t": to_np(tt), "qsample/y": to_np(gd.q_sample(a, tt, b))})
+    # LocalAttention (ddpm.py:232-283): windows of 2^3 on a grid that needs padding
+    torch.manual_seed(4)
+    la = R.LocalAttention(16, window_size=2, heads=4, dim_head=32)
+    xl = randn(1, 16, 5, 4, 6)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yl = la(xl)
+    save_mod("local_attn", la)
+    ops.update({"local_attn/x": to_np(xl), "local_attn/y": to_np(yl)})
     np.savez_compressed(OUT / "ops.npz", **ops)
 
     # ------------------------------------------------------------------ cfg1 model

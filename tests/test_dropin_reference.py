@@ -41,3 +41,39 @@ print("DROPIN_OK", len(have))
 def test_reference_task_builds_our_model():
     out = subprocess.run([sys.executable, "-c", SCRIPT.format(root=ROOT)], capture_output=True, text=True, timeout=300)
     assert "DROPIN_OK 149" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+SURFACE = r'''
+import sys, warnings
+sys.path.insert(0, "{root}/tests/golden"); sys.path.insert(0, "{root}/generative-turbulence_amd")
+import make_golden
+make_golden.install_stubs()
+sys.path.insert(0, "/root/reference")
+import torch
+import turbdiff.models.ddpm as R
+import turbdiff_amd.models.ddpm as M
+import inspect
+missing = [n for n, v in vars(R).items() if (inspect.isclass(v) or inspect.isfunction(v))
+           and getattr(v, "__module__", "") == R.__name__ and not hasattr(M, n)]
+assert not missing, missing
+torch.manual_seed(0)
+a, b = R.LinearAttention(8, heads=2, dim_head=4), M.LinearAttention(8, heads=2, dim_head=4)
+b.load_state_dict(a.state_dict(), strict=True)
+x = torch.randn(2, 8, 3, 4, 5)
+assert torch.allclose(a(x), b(x), atol=1e-6)
+for shape in [(1, 2, 5, 4, 6), (1, 2, 4, 4, 4)]:
+    x = torch.randn(*shape)
+    (pa, qa), (pb, qb) = R.pad_to_multiple_of(x, 2, mode="constant"), M.pad_to_multiple_of(x, 2, mode="constant")
+    assert tuple(qa) == tuple(qb) and torch.equal(pa, pb) and torch.equal(R.unpad(pa, qa), M.unpad(pb, qb))
+x, y = torch.randn(2, 3, 4), torch.randn(1, 5, 1)
+assert torch.equal(R.expand_as(x, y, 1), M.expand_as(x, y, 1))
+print("SURFACE_OK")
+'''
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference checkout not present")
+def test_module_surface_matches_reference():
+    """Every class / function the reference's ddpm.py defines exists here, and the torch-only ones
+    (LinearAttention, pad_to_multiple_of, unpad, expand_as) agree with it numerically."""
+    out = subprocess.run([sys.executable, "-c", SURFACE.format(root=ROOT)], capture_output=True, text=True, timeout=300)
+    assert "SURFACE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -317,3 +317,17 @@ def test_odd_grids_forward_and_grads_vs_oracle(grid, levels):
         assert rel_l2(y.cpu(), ref) < tol, (dtype, rel_l2(y.cpu(), ref))
         for name, p in net.named_parameters():
             assert_grad_close(name, p.grad.cpu(), sd[name].grad, gtol, noise_floor=1e-5)
+
+
+def test_local_attention_golden(golden):
+    """LocalAttention (reference ddpm.py:232-283) on a grid that needs padding: the windowed
+    batches go through the HIP attention kernel (N = 8 keys per window)."""
+    from turbdiff_amd.models.ddpm import LocalAttention
+
+    g = golden("ops")
+    la = LocalAttention(16, window_size=2, heads=4, dim_head=32)
+    la.load_state_dict(g.sub("local_attn/sd/"), strict=True)
+    la.to(dev())
+    with torch.no_grad():
+        y = la(g["local_attn/x"].to(dev()))
+    assert rel_l2(y.cpu(), g["local_attn/y"]) < 1e-5
