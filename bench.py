@@ -96,6 +96,49 @@ def cpu_baseline(budget_s=25.0):
             "sample": f"B=1 fwd+bwd of the same 192x64x48 step, fp32, median of {len(times)} after 1 warm-up ({med:.2f} s each)"}
 
 
+def torch_rocm_baseline(B, dev, amp, steps=2):
+    """The reference's arithmetic path as it runs on this GPU through stock PyTorch-ROCm ops
+    (MIOpen conv3d, ATen group_norm / interpolate / SDPA): the oracle's functional restatement on
+    `cuda`, fp32 weights, optionally under bf16 autocast, same step (fwd + bwd + clip + RAdam).
+    A reported baseline (--torch-baseline), never part of `value`."""
+    from oracle import turbdiff_oracle as O
+    from turbdiff_amd.models.ddpm import DenoisingModel
+
+    torch.manual_seed(0)
+    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=500, dim=32,
+                         u_net_levels=4, norm_type="group")
+    sd = {k: v.clone().to(dev).requires_grad_() for k, v in net.state_dict().items()}
+    del net
+    params = list(sd.values())
+    opt = torch.optim.RAdam(params, lr=1e-4)
+    x, c, cell_idx = synthetic_inputs(B, dev)
+    buf = {k: v.to(dev) for k, v in O.schedule_buffers("log-snr-linear", 500).items()}
+    noise = torch.randn(x.shape, device=dev)
+
+    def step():
+        t = torch.randint(0, 500, (B,), device=dev)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            loss, _ = O.p_losses(sd, buf, x, t, c, cell_idx, noise, timesteps=500, noise_bcs=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 0.1)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    V = GRID[0] * GRID[1] * GRID[2]
+    res = {"ms_per_step": ms, "voxels_per_s": B * V / (ms * 1e-3), "batch": B, "precision": "bf16 autocast" if amp else "fp32",
+           "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
+    del sd, params, opt
+    torch.cuda.empty_cache()
+    return res
+
+
 def measured_traffic():
     """HBM bytes per launch of the forward conv kernel from the committed rocprofv3 PMC passes
     (profiles/*_traffic.json, produced by tools/collect_profiles.sh at B = 6); None if absent."""
@@ -123,6 +166,8 @@ def main():
     ap.add_argument("--sample-batch", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--torch-baseline", action="store_true",
+                    help="also time the same step through stock PyTorch-ROCm ops (MIOpen); adds extra.torch_rocm_reference")
     args = ap.parse_args()
 
     from turbdiff_amd import _lib, parallel
@@ -251,6 +296,18 @@ def main():
             extra["ddpm_samples_per_s_T500_extrapolated"] = Bs / (per_step * 500)
             extra["ddpm_samples_per_s_T1000_extrapolated"] = Bs / (per_step * 1000)
         out["extra"] = extra
+
+    if args.torch_baseline and world == 1:
+        del diff, ddp, opt
+        torch.cuda.empty_cache()
+        ref = {}
+        for amp in (True, False):
+            torch.cuda.reset_peak_memory_stats()
+            try:
+                ref["bf16_autocast" if amp else "fp32"] = torch_rocm_baseline(B, dev, amp)
+            except Exception as e:  # noqa: BLE001 -- a baseline that cannot run is reported, not fatal
+                ref["bf16_autocast" if amp else "fp32"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        out.setdefault("extra", {})["torch_rocm_reference"] = ref
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

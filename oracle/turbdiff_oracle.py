@@ -104,8 +104,8 @@ def time_features(t: torch.Tensor, dim: int, T: int) -> torch.Tensor:
     k = dim // 2
     phi = (1 + np.sqrt(5)) / 2
     freq = np.geomspace(1 / 8, (T / 2) / (2 * phi), num=k)
-    scale = torch.tensor(np.repeat(2 * np.pi * freq / T, 2), dtype=torch.float32)
-    bias = torch.tensor(np.tile(np.array([0, np.pi / 2]), k), dtype=torch.float32)
+    scale = torch.tensor(np.repeat(2 * np.pi * freq / T, 2), dtype=torch.float32, device=t.device)
+    bias = torch.tensor(np.tile(np.array([0, np.pi / 2]), k), dtype=torch.float32, device=t.device)
     return torch.addcmul(bias, scale, t[..., None]).sin()
 
 
@@ -271,13 +271,13 @@ def p_sample_loop(sd, buf, x_bcs, c_local, cell_idx, noises, *, timesteps, noise
         x_t = next(noises)
         T = timesteps
     else:
-        tt = torch.full((B,), start_from - 1, dtype=torch.long)
+        tt = torch.full((B,), start_from - 1, dtype=torch.long, device=x_bcs.device)
         x_t = q_sample(buf, x_bcs, tt, next(noises))
         T = start_from
     if not noise_bcs:
         x_t = where_cells(cell_idx, x_t, x_bcs)
     for step in reversed(range(T)):
-        tt = torch.full((B,), step, dtype=torch.long)
+        tt = torch.full((B,), step, dtype=torch.long, device=x_bcs.device)
         _, mean = model_mean(buf, x_t, tt, denoise_fn(x_t, tt), cell_idx, noise_bcs)
         if step == 0:
             x_t = mean

@@ -25,9 +25,55 @@ def timeit(fn, n=5):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
 
+def miopen_layer(B, Ci, Co, grid, dtype, channels_last):
+    """The same layer through stock PyTorch-ROCm: F.pad(replicate) + F.conv3d (MIOpen), NCDHW or
+    channels_last_3d.  Returns (fwd ms, fwd+bwd ms)."""
+    import torch.nn.functional as F
+    X, Y, Z = grid
+    x = torch.randn(B, Ci, X, Y, Z, device="cuda", dtype=dtype)
+    w = (torch.randn(Co, Ci, 3, 3, 3, device="cuda") * 0.02).to(dtype)
+    b = torch.zeros(Co, device="cuda", dtype=dtype)
+    if channels_last:
+        x = x.contiguous(memory_format=torch.channels_last_3d); w = w.contiguous(memory_format=torch.channels_last_3d)
+    x.requires_grad_(); w.requires_grad_(); b.requires_grad_()
+    fwd = lambda: F.conv3d(F.pad(x, (1,) * 6, mode="replicate"), w, b)
+    with torch.no_grad():
+        tf = timeit(fwd, 3)
+    gy = torch.randn_like(fwd())
+    def both():
+        x.grad = w.grad = b.grad = None
+        fwd().backward(gy)
+    return tf, timeit(both, 3)
+
+def miopen_table(a):
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
+    print(f"stock PyTorch-ROCm conv3d (MIOpen, find={'on' if a.miopen_find else 'off'}), B={a.batch}; TF/s on 54*Cin*Cout*V (fwd) and 3x that (fwd+bwd)")
+    print(f"{'layer':12s} {'Cin':>5s} {'Cout':>5s} | " + " | ".join(f"{n:>24s}" for n in ("bf16 NCDHW fwd / f+b ms", "bf16 NDHWC fwd / f+b ms", "fp32 NCDHW fwd / f+b ms")))
+    tot = [[0.0, 0.0] for _ in range(3)]; totf = 0.0
+    for name, C1, C2, Co, grid in LAYERS:
+        if a.only and a.only not in name: continue
+        Ci = C1 + C2; fl = 54.0 * Ci * Co * a.batch * grid[0] * grid[1] * grid[2]
+        mult = 4 if name == "center" else (2 if name == "down.0.b1" else (3 if name == "up.3.b2" else 1))
+        cells = []
+        for k, (dt, cl) in enumerate([(torch.bfloat16, False), (torch.bfloat16, True), (torch.float32, False)]):
+            try:
+                tf, tb = miopen_layer(a.batch, Ci, Co, grid, dt, cl)
+            except Exception as e:  # noqa: BLE001 -- report and continue with the other layouts
+                cells.append(f"{'failed: ' + type(e).__name__:>24s}"); tot[k][0] = tot[k][1] = float("nan"); continue
+            tot[k][0] += tf * mult; tot[k][1] += tb * mult
+            cells.append(f"{tf:7.2f} {fl/tf/1e9:4.0f} /{tb:7.2f} {3*fl/tb/1e9:4.0f}")
+        totf += fl * mult
+        print(f"{name:12s} {Ci:5d} {Co:5d} | " + " | ".join(cells) + f"   x{mult}", flush=True)
+    for k, n in enumerate(("bf16 NCDHW", "bf16 NDHWC", "fp32 NCDHW")):
+        print(f"TOTAL {n}: fwd {tot[k][0]:.1f} ms ({totf/tot[k][0]/1e9:.0f} TF/s)  fwd+bwd {tot[k][1]:.1f} ms ({3*totf/tot[k][1]/1e9:.0f} TF/s)")
+
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=6); ap.add_argument("--only", default="")
+    ap.add_argument("--miopen", action="store_true", help="time the same layers through F.conv3d (MIOpen) instead")
+    ap.add_argument("--miopen-find", action="store_true", help="with --miopen: torch.backends.cudnn.benchmark = True")
     a = ap.parse_args()
+    if a.miopen:
+        return miopen_table(a)
     dev = torch.device("cuda:0"); B = a.batch
     tot = {"fwd": 0, "dgrad": 0, "wgrad": 0}; totf = 0
     print(f"{'layer':12s} {'Cin':>5s} {'Cout':>5s} {'grid':>12s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
