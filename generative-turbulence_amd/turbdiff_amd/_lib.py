@@ -14,7 +14,7 @@ from pathlib import Path
 import torch
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libtdx_hip.so"
+LIB_PATH = Path(os.environ.get("TDX_LIB", _HERE / "libtdx_hip.so"))  # TDX_LIB: kernel-development builds
 
 F32, BF16 = 0, 1
 CONV_AUTO, CONV_DIRECT, CONV_MFMA = 0, 1, 2
