@@ -257,10 +257,8 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int v = (wx * BY + wy0 + 4 * mt + (r & 3)) * 8 + (r >> 2);
-                const unsigned lo = (unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j] + bv[0]) |
-                                    ((unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 1] + bv[1]) << 16);
-                const unsigned hi = (unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 2] + bv[2]) |
-                                    ((unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 3] + bv[3]) << 16);
+                const unsigned lo = pack_bf16x2(acc[nt][mt][4 * j] + bv[0], acc[nt][mt][4 * j + 1] + bv[1]);
+                const unsigned hi = pack_bf16x2(acc[nt][mt][4 * j + 2] + bv[2], acc[nt][mt][4 * j + 3] + bv[3]);
                 *reinterpret_cast<uint2*>(sO + out_addr<BN>(v, ch >> 3) + (ch & 7) * 2) = make_uint2(lo, hi);
             }
         }

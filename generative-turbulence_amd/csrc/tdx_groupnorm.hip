@@ -90,8 +90,13 @@ gn_stats_finalize(const double* __restrict__ acc, float* __restrict__ stats, int
 }
 
 #define GN_REPLICAS 32
+// covers both uses: GN_REPLICAS f64 moment tables (+ stats) of the fused conv epilogue, and the
+// backward's [B][C][2] f64 sums + [B][C][2] group sums + GN_MAX_BLOCKS per-block partial tables
 extern "C" size_t tdx_gn_workspace_bytes(int B, int C) {
-    return (size_t)GN_REPLICAS * B * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + 64;
+    const size_t fwd = (size_t)GN_REPLICAS * B * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) + 64;
+    const size_t bwd = (size_t)B * C * 2 * sizeof(double) + (size_t)B * C * 2 * sizeof(float) +
+                       (size_t)512 * B * C * 2 * sizeof(float) + 64;
+    return fwd > bwd ? fwd : bwd;
 }
 
 static int gn_shape_ok(int C, int G) { return C > 0 && G > 0 && C % 8 == 0 && C % G == 0 && (C / 8) <= GN_THREADS; }
@@ -142,6 +147,22 @@ __device__ __forceinline__ void gn_load_coef(GnCoef& k, float (&mean)[8], float 
     }
 }
 
+// Streaming skeleton of the apply / backward passes: block (bx, b) walks the voxels of sample b
+// with stride gridDim.x * rows, GN_UNROLL voxels per thread per trip (independent 16-B loads in
+// flight); the grid is sized to about 8 resident blocks per CU so per-block set-up (coefficient
+// loads) is paid once per ~MB streamed.
+#define GN_UNROLL 4
+#define GN_MAX_BLOCKS 512  // per sample; bounds the backward partial-sum buffer
+
+static int gn_blocks_per_sample(int B, int64_t V, int C) {
+    const int rows = GN_THREADS / (C >> 3);
+    int64_t want = (2048 + B - 1) / B;
+    const int64_t most = (V + (int64_t)rows * GN_UNROLL - 1) / ((int64_t)rows * GN_UNROLL);
+    if (want > most) want = most;
+    if (want > GN_MAX_BLOCKS) want = GN_MAX_BLOCKS;
+    return want < 1 ? 1 : (int)want;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(GN_THREADS)
 gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -156,24 +177,35 @@ gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const 
     GnCoef k;
     float mean[8], rstd[8], gam[8], film[8];
     gn_load_coef(k, mean, rstd, gam, film, stats, gamma, beta, scale, shift, b, C, G, lc * 8);
-    const int64_t v0 = (int64_t)blockIdx.x * GN_VOX_PER_BLOCK;
-    const int64_t v1 = min(V, v0 + GN_VOX_PER_BLOCK);
     const int64_t base = ((int64_t)b * V) * C + lc * 8;
-    for (int64_t v = v0 + r; v < v1; v += rows) {
-        Vec8<T> a, o;
-        a.load(x + base + v * C);
+    const int64_t stride = (int64_t)gridDim.x * rows;
+    for (int64_t v = (int64_t)blockIdx.x * rows + r; v < V; v += stride * GN_UNROLL) {
+        Vec8<T> a[GN_UNROLL], rr[GN_UNROLL];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float n = a.v[j] * k.a[j] + k.c0[j];
-            o.v[j] = act ? silu_f(n) : n;
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            const int64_t vv = v + u * stride;
+            if (vv < V) {
+                a[u].load(x + base + vv * C);
+                if (res) rr[u].load(res + base + vv * C);
+            }
         }
-        if (res) {
-            Vec8<T> rr;
-            rr.load(res + base + v * C);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o.v[j] += rr.v[j];
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            const int64_t vv = v + u * stride;
+            if (vv < V) {
+                Vec8<T> o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float n = __builtin_fmaf(a[u].v[j], k.a[j], k.c0[j]);
+                    o.v[j] = act ? silu_f(n) : n;
+                }
+                if (res) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o.v[j] += rr[u].v[j];
+                }
+                o.store(y + base + vv * C);
+            }
         }
-        o.store(y + base + v * C);
     }
 }
 
@@ -183,7 +215,7 @@ extern "C" int tdx_gn_apply(const void* x, const float* stats, const float* gamm
     TDX_CHECK_ARG(x && stats && gamma && beta && y && B > 0 && V > 0);
     TDX_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     if (!gn_shape_ok(C, G)) return TDX_ESHAPE;
-    dim3 grid(ceil_div(V, GN_VOX_PER_BLOCK), B);
+    dim3 grid(gn_blocks_per_sample(B, V, C), B);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(GN_THREADS), 0, as_stream(stream),
                                                   (const T*)x, stats, gamma, beta, scale, shift, (const T*)res, (T*)y,
                                                   V, C, G, act));
@@ -191,12 +223,18 @@ extern "C" int tdx_gn_apply(const void* x, const float* stats, const float* gamm
 }
 
 // ------------------------------------------------------------------ backward -------------
-// reduce pass: P[b,c] = sum_v dn, Q[b,c] = sum_v dn * xhat, dn = dy * act'(n)
+// With n = a x + c0 (GroupNorm affine + FiLM folded), dn = dy act'(n), xhat = (x - mean) rstd:
+//   reduce pass : P[b,c] = sum_v dn, Q[b,c] = sum_v dn xhat     (per-block partials, no atomics)
+//   finalize    : per (b, group) A = mean_g(k P), Bq = mean_g(k Q), k = gamma (1 + scale); parameter grads
+//   apply pass  : dx = rstd (k dn - A - xhat Bq)
+// partial[(b * nblk + blk) * C + c][2] holds one block's sums; the finalize kernels add them in f64
+// in a fixed order, so the result is deterministic.
 template <typename T>
 __global__ void __launch_bounds__(GN_THREADS)
 gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
                      const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
-                     const float* __restrict__ shift, double* __restrict__ acc, int64_t V, int C, int G, int act) {
+                     const float* __restrict__ shift, float* __restrict__ partial, int64_t V, int C, int G, int act) {
+    __shared__ float red[GN_THREADS][17];
     const int b = blockIdx.y;
     const int L = C >> 3;
     const int rows = GN_THREADS / L;
@@ -208,26 +246,70 @@ gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const fl
     for (int j = 0; j < 8; ++j) s[0][j] = s[1][j] = 0.f;
     if (active) {
         GnCoef k;
-        float mean[8], rstd[8], gam[8], film[8];
+        float mean[8], rstd[8], gam[8], film[8], mr[8];
         gn_load_coef(k, mean, rstd, gam, film, stats, gamma, beta, scale, shift, b, C, G, lc * 8);
-        const int64_t v0 = (int64_t)blockIdx.x * GN_VOX_PER_BLOCK;
-        const int64_t v1 = min(V, v0 + GN_VOX_PER_BLOCK);
-        const int64_t base = ((int64_t)b * V) * C + lc * 8;
-        for (int64_t v = v0 + r; v < v1; v += rows) {
-            Vec8<T> a, g;
-            a.load(x + base + v * C);
-            g.load(dy + base + v * C);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float n = a.v[j] * k.a[j] + k.c0[j];
-                const float dn = act ? g.v[j] * dsilu_f(n) : g.v[j];
-                const float xh = (a.v[j] - mean[j]) * rstd[j];
-                s[0][j] += dn;
-                s[1][j] += dn * xh;
+        for (int j = 0; j < 8; ++j) mr[j] = -mean[j] * rstd[j];
+        const int64_t base = ((int64_t)b * V) * C + lc * 8;
+        const int64_t stride = (int64_t)gridDim.x * rows;
+        for (int64_t v = (int64_t)blockIdx.x * rows + r; v < V; v += stride * GN_UNROLL) {
+            Vec8<T> a[GN_UNROLL], g[GN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < GN_UNROLL; ++u) {
+                const int64_t vv = v + u * stride;
+                if (vv < V) {
+                    a[u].load(x + base + vv * C);
+                    g[u].load(dy + base + vv * C);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GN_UNROLL; ++u) {
+                if (v + u * stride < V) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float n = __builtin_fmaf(a[u].v[j], k.a[j], k.c0[j]);
+                        const float dn = act ? g[u].v[j] * dsilu_f(n) : g[u].v[j];
+                        const float xh = __builtin_fmaf(a[u].v[j], rstd[j], mr[j]);
+                        s[0][j] += dn;
+                        s[1][j] = __builtin_fmaf(dn, xh, s[1][j]);
+                    }
+                }
             }
         }
     }
-    block_channel_reduce<2>(s, L, lc, active, acc + (size_t)b * C * 2, C);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[tid][j] = s[0][j];
+        red[tid][8 + j] = s[1][j];
+    }
+    __syncthreads();
+    float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * C * 2;
+    for (int o = tid; o < C * 2; o += GN_THREADS) {
+        const int c = o >> 1, q = o & 1;
+        const int lcc = c >> 3, j = c & 7;
+        float t = 0.f;
+        for (int rr = 0; rr < rows; ++rr) t += red[rr * L + lcc][q * 8 + j];
+        out[o] = t;
+    }
+}
+
+// sums the per-block partials: acc[(b*C + c)*2 + q] (f64).  One wave per (b, c) pair of sums.
+__global__ void __launch_bounds__(64)
+gn_bwd_sum_partials(const float* __restrict__ partial, double* __restrict__ acc, int nblk, int C) {
+    const int bc = blockIdx.x;  // b * C + c
+    const int b = bc / C, c = bc - b * C;
+    double p = 0.0, q = 0.0;
+    for (int k = threadIdx.x; k < nblk; k += 64) {
+        const float2 t = *reinterpret_cast<const float2*>(partial + (((size_t)b * nblk + k) * C + c) * 2);
+        p += (double)t.x;
+        q += (double)t.y;
+    }
+    p = wave_sum(p);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) {
+        acc[(size_t)bc * 2] = p;
+        acc[(size_t)bc * 2 + 1] = q;
+    }
 }
 
 // finalize: one thread per (b, g) for the group sums, then per-channel parameter grads.
@@ -282,30 +364,46 @@ gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const flo
     const int lc = tid % L, r = tid / L;
     if (r >= rows) return;
     GnCoef k;
-    float mean[8], rstd[8], gam[8], film[8], ga[8], gb[8];
+    float mean[8], rstd[8], gam[8], film[8];
     gn_load_coef(k, mean, rstd, gam, film, stats, gamma, beta, scale, shift, b, C, G, lc * 8);
+    // dx = k1 dn - k2 - xhat k3,  xhat = x rstd + mr
+    float k1[8], k2[8], k3[8], mr[8];
     const int cpg = C / G;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int g = (lc * 8 + j) / cpg;
-        ga[j] = gsum[((size_t)b * G + g) * 2];
-        gb[j] = gsum[((size_t)b * G + g) * 2 + 1];
+        k1[j] = rstd[j] * gam[j] * film[j];
+        k2[j] = rstd[j] * gsum[((size_t)b * G + g) * 2];
+        k3[j] = rstd[j] * gsum[((size_t)b * G + g) * 2 + 1];
+        mr[j] = -mean[j] * rstd[j];
     }
-    const int64_t v0 = (int64_t)blockIdx.x * GN_VOX_PER_BLOCK;
-    const int64_t v1 = min(V, v0 + GN_VOX_PER_BLOCK);
     const int64_t base = ((int64_t)b * V) * C + lc * 8;
-    for (int64_t v = v0 + r; v < v1; v += rows) {
-        Vec8<T> a, g, o;
-        a.load(x + base + v * C);
-        g.load(dy + base + v * C);
+    const int64_t stride = (int64_t)gridDim.x * rows;
+    for (int64_t v = (int64_t)blockIdx.x * rows + r; v < V; v += stride * GN_UNROLL) {
+        Vec8<T> a[GN_UNROLL], g[GN_UNROLL];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float n = a.v[j] * k.a[j] + k.c0[j];
-            const float dn = act ? g.v[j] * dsilu_f(n) : g.v[j];
-            const float xh = (a.v[j] - mean[j]) * rstd[j];
-            o.v[j] = rstd[j] * (gam[j] * film[j] * dn - ga[j] - xh * gb[j]);
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            const int64_t vv = v + u * stride;
+            if (vv < V) {
+                a[u].load(x + base + vv * C);
+                g[u].load(dy + base + vv * C);
+            }
         }
-        o.store(dx + base + v * C);
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            const int64_t vv = v + u * stride;
+            if (vv < V) {
+                Vec8<T> o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float n = __builtin_fmaf(a[u].v[j], k.a[j], k.c0[j]);
+                    const float dn = act ? g[u].v[j] * dsilu_f(n) : g[u].v[j];
+                    const float xh = __builtin_fmaf(a[u].v[j], rstd[j], mr[j]);
+                    o.v[j] = __builtin_fmaf(k1[j], dn, -__builtin_fmaf(xh, k3[j], k2[j]));
+                }
+                o.store(dx + base + vv * C);
+            }
+        }
     }
 }
 
@@ -317,15 +415,16 @@ extern "C" int tdx_gn_bwd(const void* x, const void* dy, const float* stats, con
     TDX_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     TDX_CHECK_ARG((scale == nullptr) == (dscale == nullptr) && (dscale == nullptr) == (dshift == nullptr));
     if (!gn_shape_ok(C, G)) return TDX_ESHAPE;
-    double* acc = (double*)workspace;
-    float* gsum = (float*)(acc + (size_t)B * C * 2);
-    hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * C * 2 * sizeof(double), as_stream(stream));
-    if (e != hipSuccess) return (int)e;
-    dim3 grid(ceil_div(V, GN_VOX_PER_BLOCK), B);
+    const int nblk = gn_blocks_per_sample(B, V, C);
+    double* acc = (double*)workspace;                      // [B][C][2]
+    float* gsum = (float*)(acc + (size_t)B * C * 2);       // [B][G][2] (G <= C)
+    float* partial = gsum + (size_t)B * C * 2;             // [B][nblk][C][2]
+    dim3 grid(nblk, B);
     hipStream_t st = as_stream(stream);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T>), grid, dim3(GN_THREADS), 0, st,
-                                                  (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, acc, V,
-                                                  C, G, act));
+                                                  (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, partial,
+                                                  V, C, G, act));
+    hipLaunchKernelGGL(gn_bwd_sum_partials, dim3(B * C), dim3(64), 0, st, partial, acc, nblk, C);
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(ceil_div(B * G, 64)), dim3(64), 0, st, acc, gamma, scale, gsum, B, C, G,
                        V);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, acc, gamma, beta, scale, dgamma,
