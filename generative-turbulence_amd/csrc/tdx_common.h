@@ -78,6 +78,39 @@ struct Vec8<bf16> {
     }
 };
 
+// raw (unconverted) 8-element loads: lets a kernel issue several loads back to back and convert later
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = reinterpret_cast<const float4*>(p)[0];
+        b = reinterpret_cast<const float4*>(p)[1];
+    }
+    __device__ __forceinline__ Vec8<float> get() const {
+        Vec8<float> r;
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+        r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+        return r;
+    }
+};
+template <>
+struct Raw8<bf16> {
+    uint4 u;
+    __device__ __forceinline__ void load(const bf16* p) { u = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ Vec8<bf16> get() const {
+        Vec8<bf16> r;
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r.v[2 * i] = __uint_as_float(w[i] << 16);
+            r.v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+        return r;
+    }
+};
+
 // ---- wave / block reductions (wave = 64 lanes) -----------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

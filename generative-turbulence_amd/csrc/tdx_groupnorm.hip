@@ -132,25 +132,42 @@ __device__ __forceinline__ void gn_load_coef(GnCoef& k, float (&mean)[8], float 
                                              const float* __restrict__ scale, const float* __restrict__ shift, int b,
                                              int C, int G, int cbase) {
     const int cpg = C / G;
+    // issue every load before the first use (one exposed latency per block instead of one per channel)
+    float be[8], sc[8], sh[8];
+    float2 st[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st[j] = *reinterpret_cast<const float2*>(stats + ((size_t)b * G + (cbase + j) / cpg) * 2);
+    {
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + cbase), g1 = *reinterpret_cast<const float4*>(gamma + cbase + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + cbase), b1 = *reinterpret_cast<const float4*>(beta + cbase + 4);
+        gam[0] = g0.x; gam[1] = g0.y; gam[2] = g0.z; gam[3] = g0.w; gam[4] = g1.x; gam[5] = g1.y; gam[6] = g1.z; gam[7] = g1.w;
+        be[0] = b0.x; be[1] = b0.y; be[2] = b0.z; be[3] = b0.w; be[4] = b1.x; be[5] = b1.y; be[6] = b1.z; be[7] = b1.w;
+    }
+    if (scale) {
+        const float* sp = scale + (size_t)b * C + cbase;
+        const float* hp = shift + (size_t)b * C + cbase;
+        const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+        const float4 h0 = *reinterpret_cast<const float4*>(hp), h1 = *reinterpret_cast<const float4*>(hp + 4);
+        sc[0] = s0.x; sc[1] = s0.y; sc[2] = s0.z; sc[3] = s0.w; sc[4] = s1.x; sc[5] = s1.y; sc[6] = s1.z; sc[7] = s1.w;
+        sh[0] = h0.x; sh[1] = h0.y; sh[2] = h0.z; sh[3] = h0.w; sh[4] = h1.x; sh[5] = h1.y; sh[6] = h1.z; sh[7] = h1.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = 0.f; sh[j] = 0.f; }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int c = cbase + j;
-        const int g = c / cpg;
-        mean[j] = stats[((size_t)b * G + g) * 2];
-        rstd[j] = stats[((size_t)b * G + g) * 2 + 1];
-        gam[j] = gamma[c];
-        const float be = beta[c];
-        film[j] = scale ? 1.0f + scale[(size_t)b * C + c] : 1.0f;
-        const float sh = shift ? shift[(size_t)b * C + c] : 0.0f;
+        mean[j] = st[j].x;
+        rstd[j] = st[j].y;
+        film[j] = 1.0f + sc[j];
         k.a[j] = rstd[j] * gam[j] * film[j];
-        k.c0[j] = (be - mean[j] * rstd[j] * gam[j]) * film[j] + sh;
+        k.c0[j] = (be[j] - mean[j] * rstd[j] * gam[j]) * film[j] + sh[j];
     }
 }
 
 // Streaming skeleton of the apply / backward passes: block (bx, b) walks the voxels of sample b
 // with stride gridDim.x * rows, GN_UNROLL voxels per thread per trip (independent 16-B loads in
-// flight); the grid is sized to about 8 resident blocks per CU so per-block set-up (coefficient
-// loads) is paid once per ~MB streamed.
+// flight, no branches between them); the grid is sized to about 8 resident blocks per CU so the
+// per-block set-up (coefficient loads) is paid once per ~MB streamed.
 #define GN_UNROLL 4
 #define GN_MAX_BLOCKS 512  // per sample; bounds the backward partial-sum buffer
 
@@ -163,11 +180,11 @@ static int gn_blocks_per_sample(int B, int64_t V, int C) {
     return want < 1 ? 1 : (int)want;
 }
 
-template <typename T>
+template <typename T, bool HAS_RES, bool ACT>
 __global__ void __launch_bounds__(GN_THREADS)
 gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
                 const float* __restrict__ beta, const float* __restrict__ scale, const float* __restrict__ shift,
-                const T* __restrict__ res, T* __restrict__ y, int64_t V, int C, int G, int act) {
+                const T* __restrict__ res, T* __restrict__ y, int64_t V, int C, int G) {
     const int b = blockIdx.y;
     const int L = C >> 3;
     const int rows = GN_THREADS / L;
@@ -179,33 +196,34 @@ gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const 
     gn_load_coef(k, mean, rstd, gam, film, stats, gamma, beta, scale, shift, b, C, G, lc * 8);
     const int64_t base = ((int64_t)b * V) * C + lc * 8;
     const int64_t stride = (int64_t)gridDim.x * rows;
-    for (int64_t v = (int64_t)blockIdx.x * rows + r; v < V; v += stride * GN_UNROLL) {
-        Vec8<T> a[GN_UNROLL], rr[GN_UNROLL];
+    auto one = [&](const Vec8<T>& a, const Vec8<T>& rr, int64_t vv) {
+        Vec8<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float n = __builtin_fmaf(a.v[j], k.a[j], k.c0[j]);
+            o.v[j] = ACT ? silu_f(n) : n;
+            if (HAS_RES) o.v[j] += rr.v[j];
+        }
+        o.store(y + base + vv * C);
+    };
+    int64_t v = (int64_t)blockIdx.x * rows + r;
+    // full trips: GN_UNROLL independent loads in flight, no branches between them
+    for (; v + (GN_UNROLL - 1) * stride < V; v += stride * GN_UNROLL) {
+        Raw8<T> a[GN_UNROLL], rr[GN_UNROLL];
 #pragma unroll
         for (int u = 0; u < GN_UNROLL; ++u) {
-            const int64_t vv = v + u * stride;
-            if (vv < V) {
-                a[u].load(x + base + vv * C);
-                if (res) rr[u].load(res + base + vv * C);
-            }
+            a[u].load(x + base + (v + u * stride) * C);
+            if (HAS_RES) rr[u].load(res + base + (v + u * stride) * C);
         }
+        __builtin_amdgcn_sched_barrier(0);  // all loads of the trip are issued before any arithmetic
 #pragma unroll
-        for (int u = 0; u < GN_UNROLL; ++u) {
-            const int64_t vv = v + u * stride;
-            if (vv < V) {
-                Vec8<T> o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float n = __builtin_fmaf(a[u].v[j], k.a[j], k.c0[j]);
-                    o.v[j] = act ? silu_f(n) : n;
-                }
-                if (res) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o.v[j] += rr[u].v[j];
-                }
-                o.store(y + base + vv * C);
-            }
-        }
+        for (int u = 0; u < GN_UNROLL; ++u) one(a[u].get(), HAS_RES ? rr[u].get() : Vec8<T>(), v + u * stride);
+    }
+    for (; v < V; v += stride) {
+        Vec8<T> a, rr;
+        a.load(x + base + v * C);
+        if (HAS_RES) rr.load(res + base + v * C);
+        one(a, rr, v);
     }
 }
 
@@ -216,9 +234,16 @@ extern "C" int tdx_gn_apply(const void* x, const float* stats, const float* gamm
     TDX_CHECK_ARG((scale == nullptr) == (shift == nullptr));
     if (!gn_shape_ok(C, G)) return TDX_ESHAPE;
     dim3 grid(gn_blocks_per_sample(B, V, C), B);
-    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_kernel<T>), grid, dim3(GN_THREADS), 0, as_stream(stream),
-                                                  (const T*)x, stats, gamma, beta, scale, shift, (const T*)res, (T*)y,
-                                                  V, C, G, act));
+#define GN_APPLY_GO(R, A)                                                                                              \
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_kernel<T, R, A>), grid, dim3(GN_THREADS), 0,                \
+                                                  as_stream(stream), (const T*)x, stats, gamma, beta, scale, shift,    \
+                                                  (const T*)res, (T*)y, V, C, G))
+    if (res) {
+        if (act) GN_APPLY_GO(true, true); else GN_APPLY_GO(true, false);
+    } else {
+        if (act) GN_APPLY_GO(false, true); else GN_APPLY_GO(false, false);
+    }
+#undef GN_APPLY_GO
     return tdx_launch_status();
 }
 
@@ -229,11 +254,11 @@ extern "C" int tdx_gn_apply(const void* x, const float* stats, const float* gamm
 //   apply pass  : dx = rstd (k dn - A - xhat Bq)
 // partial[(b * nblk + blk) * C + c][2] holds one block's sums; the finalize kernels add them in f64
 // in a fixed order, so the result is deterministic.
-template <typename T>
+template <typename T, bool ACT>
 __global__ void __launch_bounds__(GN_THREADS)
 gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
                      const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
-                     const float* __restrict__ shift, float* __restrict__ partial, int64_t V, int C, int G, int act) {
+                     const float* __restrict__ shift, float* __restrict__ partial, int64_t V, int C, int G) {
     __shared__ float red[GN_THREADS][17];
     const int b = blockIdx.y;
     const int L = C >> 3;
@@ -252,29 +277,33 @@ gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const fl
         for (int j = 0; j < 8; ++j) mr[j] = -mean[j] * rstd[j];
         const int64_t base = ((int64_t)b * V) * C + lc * 8;
         const int64_t stride = (int64_t)gridDim.x * rows;
-        for (int64_t v = (int64_t)blockIdx.x * rows + r; v < V; v += stride * GN_UNROLL) {
-            Vec8<T> a[GN_UNROLL], g[GN_UNROLL];
+        auto one = [&](const Vec8<T>& a, const Vec8<T>& g) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float n = __builtin_fmaf(a.v[j], k.a[j], k.c0[j]);
+                const float dn = ACT ? g.v[j] * dsilu_f(n) : g.v[j];
+                const float xh = __builtin_fmaf(a.v[j], rstd[j], mr[j]);
+                s[0][j] += dn;
+                s[1][j] = __builtin_fmaf(dn, xh, s[1][j]);
+            }
+        };
+        int64_t v = (int64_t)blockIdx.x * rows + r;
+        for (; v + (GN_UNROLL - 1) * stride < V; v += stride * GN_UNROLL) {
+            Raw8<T> a[GN_UNROLL], g[GN_UNROLL];
 #pragma unroll
             for (int u = 0; u < GN_UNROLL; ++u) {
-                const int64_t vv = v + u * stride;
-                if (vv < V) {
-                    a[u].load(x + base + vv * C);
-                    g[u].load(dy + base + vv * C);
-                }
+                a[u].load(x + base + (v + u * stride) * C);
+                g[u].load(dy + base + (v + u * stride) * C);
             }
+        __builtin_amdgcn_sched_barrier(0);  // all loads of the trip are issued before any arithmetic
 #pragma unroll
-            for (int u = 0; u < GN_UNROLL; ++u) {
-                if (v + u * stride < V) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float n = __builtin_fmaf(a[u].v[j], k.a[j], k.c0[j]);
-                        const float dn = act ? g[u].v[j] * dsilu_f(n) : g[u].v[j];
-                        const float xh = __builtin_fmaf(a[u].v[j], rstd[j], mr[j]);
-                        s[0][j] += dn;
-                        s[1][j] = __builtin_fmaf(dn, xh, s[1][j]);
-                    }
-                }
-            }
+            for (int u = 0; u < GN_UNROLL; ++u) one(a[u].get(), g[u].get());
+        }
+        for (; v < V; v += stride) {
+            Vec8<T> a, g;
+            a.load(x + base + v * C);
+            g.load(dy + base + v * C);
+            one(a, g);
         }
     }
 #pragma unroll
@@ -351,12 +380,12 @@ __global__ void gn_bwd_param_kernel(const double* __restrict__ acc, const float*
     dbeta[c] = (float)db;
 }
 
-template <typename T>
+template <typename T, bool ACT>
 __global__ void __launch_bounds__(GN_THREADS)
 gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ gsum, T* __restrict__ dx, int64_t V,
-                    int C, int G, int act) {
+                    int C, int G) {
     const int b = blockIdx.y;
     const int L = C >> 3;
     const int rows = GN_THREADS / L;
@@ -379,31 +408,34 @@ gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const flo
     }
     const int64_t base = ((int64_t)b * V) * C + lc * 8;
     const int64_t stride = (int64_t)gridDim.x * rows;
-    for (int64_t v = (int64_t)blockIdx.x * rows + r; v < V; v += stride * GN_UNROLL) {
-        Vec8<T> a[GN_UNROLL], g[GN_UNROLL];
+    auto one = [&](const Vec8<T>& a, const Vec8<T>& g, int64_t vv) {
+        Vec8<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float n = __builtin_fmaf(a.v[j], k.a[j], k.c0[j]);
+            const float dn = ACT ? g.v[j] * dsilu_f(n) : g.v[j];
+            const float xh = __builtin_fmaf(a.v[j], rstd[j], mr[j]);
+            o.v[j] = __builtin_fmaf(k1[j], dn, -__builtin_fmaf(xh, k3[j], k2[j]));
+        }
+        o.store(dx + base + vv * C);
+    };
+    int64_t v = (int64_t)blockIdx.x * rows + r;
+    for (; v + (GN_UNROLL - 1) * stride < V; v += stride * GN_UNROLL) {
+        Raw8<T> a[GN_UNROLL], g[GN_UNROLL];
 #pragma unroll
         for (int u = 0; u < GN_UNROLL; ++u) {
-            const int64_t vv = v + u * stride;
-            if (vv < V) {
-                a[u].load(x + base + vv * C);
-                g[u].load(dy + base + vv * C);
-            }
+            a[u].load(x + base + (v + u * stride) * C);
+            g[u].load(dy + base + (v + u * stride) * C);
         }
+        __builtin_amdgcn_sched_barrier(0);  // all loads of the trip are issued before any arithmetic
 #pragma unroll
-        for (int u = 0; u < GN_UNROLL; ++u) {
-            const int64_t vv = v + u * stride;
-            if (vv < V) {
-                Vec8<T> o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float n = __builtin_fmaf(a[u].v[j], k.a[j], k.c0[j]);
-                    const float dn = act ? g[u].v[j] * dsilu_f(n) : g[u].v[j];
-                    const float xh = __builtin_fmaf(a[u].v[j], rstd[j], mr[j]);
-                    o.v[j] = __builtin_fmaf(k1[j], dn, -__builtin_fmaf(xh, k3[j], k2[j]));
-                }
-                o.store(dx + base + vv * C);
-            }
-        }
+        for (int u = 0; u < GN_UNROLL; ++u) one(a[u].get(), g[u].get(), v + u * stride);
+    }
+    for (; v < V; v += stride) {
+        Vec8<T> a, g;
+        a.load(x + base + v * C);
+        g.load(dy + base + v * C);
+        one(a, g, v);
     }
 }
 
@@ -421,16 +453,26 @@ extern "C" int tdx_gn_bwd(const void* x, const void* dy, const float* stats, con
     float* partial = gsum + (size_t)B * C * 2;             // [B][nblk][C][2]
     dim3 grid(nblk, B);
     hipStream_t st = as_stream(stream);
-    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T>), grid, dim3(GN_THREADS), 0, st,
-                                                  (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, partial,
-                                                  V, C, G, act));
+    if (act)
+        TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, true>), grid, dim3(GN_THREADS), 0, st,
+                                                      (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift,
+                                                      partial, V, C, G));
+    else
+        TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, false>), grid, dim3(GN_THREADS), 0, st,
+                                                      (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift,
+                                                      partial, V, C, G));
     hipLaunchKernelGGL(gn_bwd_sum_partials, dim3(B * C), dim3(64), 0, st, partial, acc, nblk, C);
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(ceil_div(B * G, 64)), dim3(64), 0, st, acc, gamma, scale, gsum, B, C, G,
                        V);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, acc, gamma, beta, scale, dgamma,
                        dbeta, dscale, dshift, B, C);
-    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), grid, dim3(GN_THREADS), 0, st,
-                                                  (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, gsum,
-                                                  (T*)dx, V, C, G, act));
+    if (act)
+        TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, true>), grid, dim3(GN_THREADS), 0, st,
+                                                      (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, gsum,
+                                                      (T*)dx, V, C, G));
+    else
+        TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, false>), grid, dim3(GN_THREADS), 0, st,
+                                                      (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, gsum,
+                                                      (T*)dx, V, C, G));
     return tdx_launch_status();
 }
