@@ -98,7 +98,15 @@ struct Raw8<float> {
 template <>
 struct Raw8<bf16> {
     uint4 u;
-    __device__ __forceinline__ void load(const bf16* p) { u = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void load(const bf16* p) {
+#ifdef TDX_NT_LOADS
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        u = make_uint4(t.x, t.y, t.z, t.w);
+#else
+        u = *reinterpret_cast<const uint4*>(p);
+#endif
+    }
     __device__ __forceinline__ Vec8<bf16> get() const {
         Vec8<bf16> r;
         const unsigned w[4] = {u.x, u.y, u.z, u.w};

@@ -34,5 +34,5 @@ int conv3_direct_launch(const void* x1, int C1, const void* x2, int C2, const vo
 
 // tdx_groupnorm.hip: (mean, rstd) per (b, group) from per-channel f64 (sum, sumsq)
 #define TDX_GN_REPLICAS 32  // == GN_REPLICAS in tdx_groupnorm.hip (sizes tdx_gn_workspace_bytes)
-int gn_finalize_launch(const double* acc, float* stats, int B, int C, int G, int64_t V, float eps, int replicas,
+int gn_finalize_launch(double* acc, float* stats, int B, int C, int G, int64_t V, float eps, int replicas,
                        hipStream_t st);

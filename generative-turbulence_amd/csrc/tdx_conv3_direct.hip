@@ -32,25 +32,74 @@ __global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ w
         if (wb) stf(wb + wp_index(lb, 26 - tap, co, ci, Cout, Cin), v);
     }
 }
+// Tiled variant for the case that both operands use the MFMA layout: a workgroup owns a
+// 16 (co) x 16 (ci) tile, reads its 16 runs of 16*27 contiguous floats, and writes, per tap, one
+// 512-B run of wf ([ci/16][tap][co][16 ci]) and one of wb ([co/16][26-tap][ci][16 co]).
+__global__ void __launch_bounds__(256)
+conv3_pack_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wb, int Cin, int Cout) {
+    __shared__ float t[16][16 * 27 + 1];  // [co][ci*27 + tap]
+    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 16 * 432; i += 256) {
+        const int co = i / 432, r = i - co * 432;
+        t[co][r] = w[((int64_t)(co0 + co) * Cin + ci0) * 27 + r];
+    }
+    __syncthreads();
+    // 27 taps x 256 (row, k) pairs; thread -> (row = tid / 16, k = tid % 16): 2-B stores, 32 B per row
+    const int row = tid >> 4, k = tid & 15;
+    for (int tap = 0; tap < 27; ++tap) {
+        if (wf)  // row = co, k = ci
+            wf[((((int64_t)(ci0 >> 4) * 27 + tap) * Cout + co0 + row) << 4) + k] = __float2bfloat16(t[row][k * 27 + tap]);
+        if (wb)  // row = ci, k = co
+            wb[((((int64_t)(co0 >> 4) * 27 + (26 - tap)) * Cin + ci0 + row) << 4) + k] = __float2bfloat16(t[k][row * 27 + tap]);
+    }
+}
+
 extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream) {
     TDX_CHECK_ARG(w && (wf || wb) && Cin > 0 && Cout > 0);
     const int64_t n = (int64_t)Cout * Cin * 27;
+    const bool lf = conv3_uses_mfma_layout(dtype, Cin, Cout), lb = conv3_uses_mfma_layout(dtype, Cout, Cin);
+    if (dtype == TDX_BF16 && (lf || !wf) && (lb || !wb) && (Cin % 16) == 0 && (Cout % 16) == 0) {
+        hipLaunchKernelGGL(conv3_pack_tiled_kernel, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
+                           (bf16*)wf, (bf16*)wb, Cin, Cout);
+        return tdx_launch_status();
+    }
     int grid = (int)min((int64_t)1024, (n + 255) / 256);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv3_pack_kernel<T>), dim3(grid), dim3(256), 0, as_stream(stream),
-                                                  w, (T*)wf, (T*)wb, Cin, Cout,
-                                                  conv3_uses_mfma_layout(dtype, Cin, Cout),
-                                                  conv3_uses_mfma_layout(dtype, Cout, Cin)));
+                                                  w, (T*)wf, (T*)wb, Cin, Cout, lf, lb));
     return tdx_launch_status();
 }
 
-// dwp [27][Cin][Cout] f32 -> dw (Cout, Cin, 27) f32
-__global__ void conv3_unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cin, int Cout) {
-    const int64_t n = (int64_t)Cout * Cin * 27;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % 27);
-        const int64_t r = i / 27;
-        const int ci = (int)(r % Cin), co = (int)(r / Cin);
-        dw[i] = dwp[((int64_t)tap * Cin + ci) * Cout + co];
+// dwp [27][Cin][Cout] f32 -> dw (Cout, Cin, 27) f32, through a 16 (ci) x 16 (co) LDS tile so that
+// both sides move 64-B+ runs; the accumulators are cleared behind the read (the workspace is left
+// all-zero, see TDX_WS_CLEAN), and block (0, *) also moves the bias-gradient accumulator.
+__global__ void __launch_bounds__(256)
+conv3_unpack_wgrad_kernel(float* __restrict__ dwp, float* __restrict__ dw, float* __restrict__ dbw,
+                          float* __restrict__ dbias, int Cin, int Cout) {
+    __shared__ float t[16][16 * 27 + 1];  // [co][ci*27 + tap]
+    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
+    const int tid = threadIdx.x;
+    const int ci = tid >> 4, co = tid & 15;
+    const bool ok = ci0 + ci < Cin && co0 + co < Cout;
+    for (int tap = 0; tap < 27; ++tap) {
+        float v = 0.f;
+        if (ok) {
+            float* src = dwp + ((int64_t)tap * Cin + ci0 + ci) * Cout + co0 + co;
+            v = *src;
+            *src = 0.f;
+        }
+        t[co][ci * 27 + tap] = v;
+    }
+    __syncthreads();
+    const int nci = min(16, Cin - ci0);
+    for (int i = tid; i < 16 * nci * 27; i += 256) {
+        const int c = i / (nci * 27), r = i - c * (nci * 27);
+        if (co0 + c < Cout) dw[((int64_t)(co0 + c) * Cin + ci0) * 27 + r] = t[c][r];
+    }
+    if (blockIdx.x == 0 && tid < 16 && co0 + tid < Cout) {
+        const float b = dbw[co0 + tid];
+        dbw[co0 + tid] = 0.f;
+        if (dbias) dbias[co0 + tid] = b;
     }
 }
 
@@ -389,6 +438,8 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
                                 int Cout, int dtype, int impl, void* stream) {
     TDX_CHECK_ARG(x1 && wf && y && stats && gn_workspace && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && C2 >= 0);
     TDX_CHECK_ARG(Cout > 0 && G > 0 && (Cout % G) == 0 && (C2 == 0 || x2));
+    const bool clean = (impl & TDX_WS_CLEAN) != 0;
+    impl &= 0xff;
     const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout));
     if (!use_mfma) {  // unfused: conv, then the streaming statistics pass
         int rc = tdx_conv3_fwd(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, dtype, impl, stream);
@@ -398,8 +449,10 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     if (!mfma_ok(dtype, C1, C2, Cout)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
     hipStream_t st = as_stream(stream);
     double* acc = (double*)gn_workspace;
-    hipError_t e = hipMemsetAsync(acc, 0, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
-    if (e != hipSuccess) return (int)e;
+    if (!clean) {
+        hipError_t e = hipMemsetAsync(acc, 0, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
+        if (e != hipSuccess) return (int)e;
+    }
     Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
     int rc = conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, st, acc);
     if (rc != TDX_OK) return rc;
@@ -464,7 +517,7 @@ extern "C" int tdx_conv3_bwd_data_add(const void* dy, const void* wb, void* dx1,
 
 extern "C" size_t tdx_conv3_bwd_weight_workspace_bytes(int Cin, int Cout, int impl) {
     (void)impl;
-    return (size_t)27 * Cin * Cout * sizeof(float) + 256;
+    return (size_t)27 * Cin * Cout * sizeof(float) + (size_t)Cout * sizeof(float) + 256;  // dw + dbias accumulators
 }
 
 extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dw,
@@ -475,11 +528,12 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
     const int Cin = C1 + C2;
     if ((C1 % 8) || (C2 % 8) || (Cout % 8)) return TDX_ESHAPE;
     hipStream_t st = as_stream(stream);
+    const bool clean = (impl & TDX_WS_CLEAN) != 0;
+    impl &= 0xff;
     float* dwp = (float*)workspace;
-    hipError_t e = hipMemsetAsync(dwp, 0, (size_t)27 * Cin * Cout * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    if (dbias) {
-        e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
+    float* dbw = dwp + (size_t)27 * Cin * Cout;  // bias-gradient accumulator
+    if (!clean) {
+        hipError_t e = hipMemsetAsync(dwp, 0, ((size_t)27 * Cin * Cout + Cout) * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
     const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && dtype == TDX_BF16 &&
@@ -487,18 +541,17 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
     if (use_mfma) {
         if (dtype != TDX_BF16) return TDX_EDTYPE;
         if (!conv3_wgrad_mfma_supported(C1, C2, Cout)) return TDX_ESHAPE;
-        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st);
+        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st);
         if (rc != TDX_OK) return rc;
     } else {
         const int64_t nvox = (int64_t)B * X * Y * Z;
         const int nci = ceil_div(Cin, D3_BM), nco = ceil_div(Cout, D3_BN);
         dim3 grid(ceil_div(nvox, D3W_VOX), 27, nci * nco);
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv3_wgrad_direct_kernel<T>), grid, dim3(256), 0, st,
-                                                      (const T*)x1, C1, (const T*)x2, C2, (const T*)dy, dwp, dbias, B,
-                                                      X, Y, Z, Cout, nci));
+                                                      (const T*)x1, C1, (const T*)x2, C2, (const T*)dy, dwp,
+                                                      dbias ? dbw : nullptr, B, X, Y, Z, Cout, nci));
     }
-    const int64_t n = (int64_t)Cout * Cin * 27;
-    hipLaunchKernelGGL(conv3_unpack_wgrad_kernel, dim3((int)min((int64_t)1024, (n + 255) / 256)), dim3(256), 0, st, dwp,
-                       dw, Cin, Cout);
+    hipLaunchKernelGGL(conv3_unpack_wgrad_kernel, dim3(ceil_div(Cin, 16), ceil_div(Cout, 16)), dim3(256), 0, st, dwp, dw,
+                       dbw, dbias, Cin, Cout);
     return tdx_launch_status();
 }

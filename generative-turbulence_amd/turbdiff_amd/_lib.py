@@ -18,6 +18,7 @@ LIB_PATH = Path(os.environ.get("TDX_LIB", _HERE / "libtdx_hip.so"))  # TDX_LIB: 
 
 F32, BF16 = 0, 1
 CONV_AUTO, CONV_DIRECT, CONV_MFMA = 0, 1, 2
+WS_CLEAN = 0x100  # TDX_WS_CLEAN (include/tdx.h)
 
 _vp, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 

@@ -18,6 +18,8 @@ from __future__ import annotations
 
 import weakref
 
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -26,6 +28,22 @@ from . import _lib as L
 
 def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+_CLEAN = {}
+WS_CLEAN = 0 if os.environ.get("TDX_WS_CLEAN", "1") == "0" else L.WS_CLEAN
+
+
+def _clean_ws(nbytes: int, device) -> torch.Tensor:
+    """Persistent all-zero workspace for the calls that take TDX_WS_CLEAN (include/tdx.h): they find
+    it zero and leave it zero, so a training step launches no memsets for accumulator buffers."""
+    if not WS_CLEAN:
+        return _ws(nbytes, device)
+    key = (str(device), int(nbytes))
+    buf = _CLEAN.get(key)
+    if buf is None:
+        buf = _CLEAN[key] = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    return buf
 
 
 def _grid(x: torch.Tensor):
@@ -225,10 +243,10 @@ class _Conv3(torch.autograd.Function):
         ctx.wshape = tuple(weight.shape)
         if gn_groups:
             stats = torch.empty((B, gn_groups, 2), dtype=torch.float32, device=x1.device)
-            ws = _ws(L.query("tdx_gn_workspace_bytes", B, Cout), x1.device)
+            ws = _clean_ws(L.query("tdx_gn_workspace_bytes", B, Cout), x1.device)
             L.call("tdx_conv3_fwd_gn", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats),
-                   gn_groups, float(gn_eps), L.ptr(ws), B, X, Y, Z, Cout, L.dtype_code(dt), L.conv_impl(), L.stream(),
-                   work=flops)
+                   gn_groups, float(gn_eps), L.ptr(ws), B, X, Y, Z, Cout, L.dtype_code(dt), L.conv_impl() | WS_CLEAN,
+                   L.stream(), work=flops)
             ctx.mark_non_differentiable(stats)
             return y, stats
         L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Cout,
@@ -255,9 +273,9 @@ class _Conv3(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gw = torch.empty(ctx.wshape, dtype=torch.float32, device=dev)
             gb = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
-            ws = _ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cin, Cout, impl), dev)
+            ws = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cin, Cout, impl), dev)
             L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z,
-                   Cout, code, impl, L.ptr(ws), st, work=54.0 * Cin * Cout * B * X * Y * Z)
+                   Cout, code, impl | WS_CLEAN, L.ptr(ws), st, work=54.0 * Cin * Cout * B * X * Y * Z)
         return gx1, gx2, gw, gb, None, None
 
 
@@ -553,13 +571,13 @@ class _ResnetBlock(torch.autograd.Function):
         f32c = lambda t: t.detach().float().contiguous()
         g1, be1, g2, be2 = f32c(g1), f32c(be1), f32c(g2), f32c(be2)
         scale, shift = f32c(scale.reshape(B, Cout)), f32c(shift.reshape(B, Cout))
-        gws = _ws(L.query("tdx_gn_workspace_bytes", B, Cout), dev)
+        gws = _clean_ws(L.query("tdx_gn_workspace_bytes", B, Cout), dev)
 
         def conv_gn(xa, Ca, xb, Cb, wf, bias):
             y = torch.empty((B, X, Y, Z, Cout), dtype=dt, device=dev)
             stats = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
             L.call("tdx_conv3_fwd_gn", L.ptr(xa), Ca, L.ptr(xb), Cb, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats), groups,
-                   float(eps), L.ptr(gws), B, X, Y, Z, Cout, code, impl, st, work=54.0 * (Ca + Cb) * Cout * B * V)
+                   float(eps), L.ptr(gws), B, X, Y, Z, Cout, code, impl | WS_CLEAN, st, work=54.0 * (Ca + Cb) * Cout * B * V)
             return y, stats
 
         h1, st1 = conv_gn(x1, C1, x2, C2, wf1, b1)
@@ -605,9 +623,9 @@ class _ResnetBlock(torch.autograd.Function):
         L.call("tdx_gn_bwd", L.ptr(h2), L.ptr(gy), L.ptr(st2), L.ptr(g2), L.ptr(be2), None, None, L.ptr(dh2), L.ptr(dg2),
                L.ptr(dbe2), None, None, B, V, Cout, groups, 1, code, L.ptr(gws), st)
         dw2, db2 = f32(*w2s), (f32(Cout) if hb2 else None)
-        wws = _ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", max(Cin, Cout), Cout, impl), dev)
+        wws = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", max(Cin, Cout), Cout, impl), dev)
         L.call("tdx_conv3_bwd_weight", L.ptr(a1), Cout, None, 0, L.ptr(dh2), L.ptr(dw2), L.ptr(db2), B, X, Y, Z, Cout, code,
-               impl, L.ptr(wws), st, work=flops(Cout))
+               impl | WS_CLEAN, L.ptr(wws), st, work=flops(Cout))
         da1 = torch.empty_like(a1)
         dws = _ws(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, max(Cin, Cout), code, impl), dev)
         L.call("tdx_conv3_bwd_data", L.ptr(dh2), L.ptr(wb2), L.ptr(da1), Cout, None, 0, 0, B, X, Y, Z, Cout, code, impl,
@@ -620,7 +638,7 @@ class _ResnetBlock(torch.autograd.Function):
         del da1
         dw1, db1 = f32(*w1s), (f32(Cout) if hb1 else None)
         L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
-               impl, L.ptr(wws), st, work=flops(Cin))
+               impl | WS_CLEAN, L.ptr(wws), st, work=flops(Cin))
         # ---- input gradient = conv1 data gradient + residual-path gradient
         gx1 = torch.empty_like(x1)
         gx2 = None if x2 is None else torch.empty_like(x2)

@@ -43,6 +43,11 @@ extern "C" {
 #define TDX_CONV_AUTO 0    /* MFMA implicit GEMM when dtype/shape allow, else direct     */
 #define TDX_CONV_DIRECT 1  /* vector-ALU reference kernels (any dtype)                    */
 #define TDX_CONV_MFMA 2    /* MFMA implicit GEMM (bf16 only); TDX_ESHAPE if unsupported  */
+/* OR-able into `impl` of tdx_conv3_fwd_gn and tdx_conv3_bwd_weight: the caller guarantees that the
+ * workspace is all-zero on entry; the call skips its memsets and, as always, leaves the workspace
+ * all-zero on exit (the kernels that read the accumulators clear them).  Lets a host keep one
+ * persistent zeroed workspace per shape instead of paying ~90 memset launches per training step. */
+#define TDX_WS_CLEAN 0x100
 
 int tdx_version(void);
 /* name of the gfx target the library was built for ("gfx950") */
@@ -100,7 +105,8 @@ int tdx_conv3_bwd_data_add(const void* dy, const void* wb, void* dx1, int C1, vo
 
 /* Weight + bias gradient.  dw is written in the reference's parameter layout
  * (Cout, Cin, 3, 3, 3) f32, dbias (Cout) f32 (may be NULL).  Overwrites.
- * workspace: tdx_conv3_bwd_weight_workspace_bytes(). */
+ * workspace: tdx_conv3_bwd_weight_workspace_bytes(); zeroed by the call unless impl has
+ * TDX_WS_CLEAN, and left all-zero on return. */
 size_t tdx_conv3_bwd_weight_workspace_bytes(int Cin, int Cout, int impl);
 int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dw, float* dbias,
                          int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* workspace, void* stream);

@@ -506,3 +506,48 @@ def test_conv3_thin_slab_bricks(grid, monkeypatch):
     assert rel_l2(outs["mfma"][0], outs["direct"][0]) < 3e-3
     assert rel_l2(outs["mfma"][1], outs["direct"][1]) < 3e-3
     assert torch.allclose(outs["mfma"][2], outs["direct"][2], rtol=2e-3, atol=2e-3)
+
+
+def test_clean_workspace_protocol():
+    """TDX_WS_CLEAN (include/tdx.h): with an all-zero workspace the fused-statistics forward and
+    the weight gradient give the same results as the self-zeroing calls and leave the workspace
+    all-zero, twice in a row."""
+    from turbdiff_amd import _lib as L, ops
+
+    torch.manual_seed(0)
+    d = torch.device("cuda:0")
+    B, X, Y, Z, Ci, Co = 2, 9, 8, 10, 32, 64
+    x = torch.randn(B, X, Y, Z, Ci, device=d).bfloat16()
+    w = (torch.randn(Co, Ci, 3, 3, 3, device=d) * 0.05)
+    bias = torch.randn(Co, device=d)
+    gy = torch.randn(B, X, Y, Z, Co, device=d).bfloat16()
+    wf, _ = ops._packed_conv3(w, torch.bfloat16)
+    st = L.stream()
+
+    def fwd(ws, impl):
+        y = torch.empty(B, X, Y, Z, Co, device=d, dtype=torch.bfloat16)
+        stats = torch.empty(B, 8, 2, device=d)
+        L.call("tdx_conv3_fwd_gn", L.ptr(x), Ci, None, 0, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats), 8, 1e-5, L.ptr(ws),
+               B, X, Y, Z, Co, L.BF16, impl, st)
+        return y, stats
+
+    def wgrad(ws, impl):
+        gw, gb = torch.empty_like(w), torch.empty(Co, device=d)
+        L.call("tdx_conv3_bwd_weight", L.ptr(x), Ci, None, 0, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z, Co, L.BF16, impl,
+               L.ptr(ws), st)
+        return gw, gb
+
+    n1, n2 = L.query("tdx_gn_workspace_bytes", B, Co), L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, 0)
+    dirty1 = torch.full((n1,), 0x5A, dtype=torch.uint8, device=d)
+    dirty2 = torch.full((n2,), 0x5A, dtype=torch.uint8, device=d)
+    ref_y, ref_stats = fwd(dirty1, L.CONV_AUTO)
+    ref_gw, ref_gb = wgrad(dirty2, L.CONV_AUTO)
+    assert rel_l2(ref_gb.cpu(), gy.float().sum((0, 1, 2, 3)).cpu()) < 1e-3
+    clean1 = torch.zeros(n1, dtype=torch.uint8, device=d)
+    clean2 = torch.zeros(n2, dtype=torch.uint8, device=d)
+    for _ in range(2):
+        y, stats = fwd(clean1, L.CONV_AUTO | L.WS_CLEAN)
+        gw, gb = wgrad(clean2, L.CONV_AUTO | L.WS_CLEAN)
+        assert torch.equal(y, ref_y) and rel_l2(stats.cpu(), ref_stats.cpu()) < 1e-6
+        assert rel_l2(gw.cpu(), ref_gw.cpu()) < 1e-5 and rel_l2(gb.cpu(), ref_gb.cpu()) < 1e-5
+        assert int(clean1.count_nonzero()) == 0 and int(clean2.count_nonzero()) == 0
