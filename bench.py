@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--sample-steps", type=int, default=6, help="reverse steps timed for the sampling leg (0 = skip)")
     ap.add_argument("--sample-batch", type=int, default=8)
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
+                    help="fused: ClipRAdam (clip + RAdam in 3 launches); torch: clip_grad_norm_ + torch.optim.RAdam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--torch-baseline", action="store_true",
@@ -183,7 +185,13 @@ def main():
 
     diff = build_model(dev, dtype)
     ddp = parallel.BucketedDataParallel(diff)
-    opt = torch.optim.RAdam(diff.parameters(), lr=1e-4)
+    fused_opt = args.optimizer == "fused"
+    if fused_opt:  # clip 0.1 + RAdam in three launches (turbdiff_amd/optim.py)
+        from turbdiff_amd.optim import ClipRAdam
+
+        opt = ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1)
+    else:
+        opt = torch.optim.RAdam(diff.parameters(), lr=1e-4)
     x, c_local, cell_idx = synthetic_inputs(B, dev)
     from turbdiff_amd.models.conditioning import Conditioning
 
@@ -194,7 +202,8 @@ def main():
         loss, _ = diff(x, C, md, None)
         loss.backward()
         ddp.finish()
-        torch.nn.utils.clip_grad_norm_(diff.parameters(), 0.1)
+        if not fused_opt:
+            torch.nn.utils.clip_grad_norm_(diff.parameters(), 0.1)
         opt.step()
         opt.zero_grad(set_to_none=True)
         return loss
@@ -247,7 +256,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: turbdiff U-Net dim32 x 4 levels GN(8), 192x64x48 (u,p), "
                                "DDPM train step (fwd+bwd+clip+RAdam)", "per_gpu_batch": B, "global_batch": B * world,
-                   "grid": list(GRID), "timesteps": 500, "parallelism": f"dp{world}"},
+                   "grid": list(GRID), "timesteps": 500, "parallelism": f"dp{world}",
+                   "optimizer": "ClipRAdam (fused clip 0.1 + RAdam)" if fused_opt else "clip_grad_norm_ + torch.optim.RAdam"},
         "loss": float(loss),
     }
     if rank == 0:

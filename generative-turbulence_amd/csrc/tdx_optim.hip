@@ -1,0 +1,142 @@
+// Fused tail of a training step: global gradient-norm clipping (the reference trains with
+// gradient_clip_val = 0.1, config/train.yaml:30-31) + the RAdam update (diffusion.py:210-218,
+// torch.optim.RAdam defaults) over ALL parameter tensors in three launches, instead of ~40
+// multi-tensor launches + ~70 fills of the stock foreach implementation.
+//
+// The tensors stay separate allocations (the state_dict keeps the reference's keys); the kernels
+// walk a device table of {param, grad, exp_avg, exp_avg_sq} pointers.  Work is cut into chunks of
+// OPT_CHUNK elements; chunk c belongs to tensor chunk_tensor[c] at element offset chunk_off[c]
+// (host-built once, the shapes never change).  HBM-bound: 1 read pass for the norm, 4 reads +
+// 3 writes for the update (fp32).
+#include "tdx_common.h"
+
+#define OPT_CHUNK 16384
+#define OPT_THREADS 256
+
+
+__global__ void __launch_bounds__(OPT_THREADS)
+opt_sumsq_kernel(const TdxOptTensor* __restrict__ table, const int* __restrict__ chunk_tensor,
+                 const int64_t* __restrict__ chunk_off, float* __restrict__ partial) {
+    const int c = blockIdx.x;
+    const TdxOptTensor t = table[chunk_tensor[c]];
+    const float* g = (const float*)t.grad;
+    float s = 0.f;
+    if (g != nullptr) {
+        const int64_t o = chunk_off[c];
+        const int64_t n = min((int64_t)OPT_CHUNK, t.numel - o);
+        const float* gp = g + o;
+        const int64_t n4 = n >> 2;
+        for (int64_t i = threadIdx.x; i < n4; i += OPT_THREADS) {
+            const float4 a = reinterpret_cast<const float4*>(gp)[i];
+            s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        }
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += OPT_THREADS) s += gp[i] * gp[i];
+    }
+    __shared__ float red[OPT_THREADS / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[c] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0)
+__global__ void __launch_bounds__(OPT_THREADS)
+opt_norm_finalize_kernel(const float* __restrict__ partial, int nchunks, float max_norm, float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nchunks; i += OPT_THREADS) s += (double)partial[i];
+    __shared__ double red[OPT_THREADS / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+        out[0] = norm;
+        out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+    }
+}
+
+struct RAdamArgs {
+    float lr, beta1, beta2, eps;
+    float inv_bc1;   // 1 / (1 - beta1^t)
+    float sqrt_bc2;  // sqrt(1 - beta2^t)
+    float rect;      // variance rectification term, or < 0 while rho_t <= 5 (plain momentum step)
+};
+
+__device__ __forceinline__ void radam_elem(float& p, float g, float& m, float& v, const RAdamArgs& a) {
+    m = m + (g - m) * (1.0f - a.beta1);             // exp_avg.lerp_(grad, 1 - beta1)
+    v = v * a.beta2 + (1.0f - a.beta2) * g * g;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float mhat = m * a.inv_bc1;
+    float upd = mhat * a.lr;
+    if (a.rect >= 0.f) upd = upd * (a.sqrt_bc2 / (sqrtf(v) + a.eps)) * a.rect;
+    p -= upd;
+}
+
+template <bool WRITE_GRAD>
+__global__ void __launch_bounds__(OPT_THREADS)
+opt_radam_kernel(const TdxOptTensor* __restrict__ table, const int* __restrict__ chunk_tensor,
+                 const int64_t* __restrict__ chunk_off, const float* __restrict__ clip, RAdamArgs a) {
+    const int c = blockIdx.x;
+    const TdxOptTensor t = table[chunk_tensor[c]];
+    if (t.grad == nullptr) return;  // parameter without a gradient this step: untouched, as torch does
+    const float coef = clip ? clip[1] : 1.0f;
+    const int64_t o = chunk_off[c];
+    const int64_t n = min((int64_t)OPT_CHUNK, t.numel - o);
+    float* p = (float*)t.param + o;
+    float* g = (float*)t.grad + o;
+    float* m = (float*)t.exp_avg + o;
+    float* v = (float*)t.exp_avg_sq + o;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = threadIdx.x; i < n4; i += OPT_THREADS) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        gg.x *= coef; gg.y *= coef; gg.z *= coef; gg.w *= coef;
+        radam_elem(pp.x, gg.x, mm.x, vv.x, a);
+        radam_elem(pp.y, gg.y, mm.y, vv.y, a);
+        radam_elem(pp.z, gg.z, mm.z, vv.z, a);
+        radam_elem(pp.w, gg.w, mm.w, vv.w, a);
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        if (WRITE_GRAD) reinterpret_cast<float4*>(g)[i] = gg;
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += OPT_THREADS) {
+        float pp = p[i], gg = g[i] * coef, mm = m[i], vv = v[i];
+        radam_elem(pp, gg, mm, vv, a);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (WRITE_GRAD) g[i] = gg;
+    }
+}
+
+extern "C" int64_t tdx_opt_chunk_elems(void) { return OPT_CHUNK; }
+
+extern "C" int tdx_grad_norm(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
+                             float max_norm, float* partial, float* out, void* stream) {
+    TDX_CHECK_ARG(table && chunk_tensor && chunk_off && partial && out && nchunks > 0);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(opt_sumsq_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, st, table, chunk_tensor, chunk_off, partial);
+    hipLaunchKernelGGL(opt_norm_finalize_kernel, dim3(1), dim3(OPT_THREADS), 0, st, partial, nchunks, max_norm, out);
+    return tdx_launch_status();
+}
+
+extern "C" int tdx_radam_step(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
+                              const float* clip, int64_t step, float lr, float beta1, float beta2, float eps,
+                              int write_grad, void* stream) {
+    TDX_CHECK_ARG(table && chunk_tensor && chunk_off && nchunks > 0 && step >= 1);
+    TDX_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f);
+    // scalar schedule of torch.optim.radam._single_tensor_radam, in double like the Python floats there
+    const double b1 = beta1, b2 = beta2, t = (double)step;
+    const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+    const double rho_inf = 2.0 / (1.0 - b2) - 1.0;
+    const double rho_t = rho_inf - 2.0 * t * pow(b2, t) / bc2;
+    RAdamArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+    a.inv_bc1 = (float)(1.0 / bc1);
+    a.sqrt_bc2 = (float)sqrt(bc2);
+    a.rect = rho_t > 5.0 ? (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t)) : -1.0f;
+    hipStream_t st = as_stream(stream);
+    if (write_grad)
+        hipLaunchKernelGGL(opt_radam_kernel<true>, dim3(nchunks), dim3(OPT_THREADS), 0, st, table, chunk_tensor, chunk_off, clip, a);
+    else
+        hipLaunchKernelGGL(opt_radam_kernel<false>, dim3(nchunks), dim3(OPT_THREADS), 0, st, table, chunk_tensor, chunk_off, clip, a);
+    return tdx_launch_status();
+}

@@ -59,6 +59,9 @@ SIGNATURES = {
     "tdx_masked_loss_workspace_bytes": (_sz, []),
     "tdx_randn": (_i, [_vp, _i64, _u64, _u64, _vp, _vp]),
     "tdx_randn_batched": (_i, [_vp, _i, _i64, _u64, _vp, _vp, _vp]),
+    "tdx_opt_chunk_elems": (_i64, []),
+    "tdx_grad_norm": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
+    "tdx_radam_step": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
 }
 
 _lib = None

@@ -97,6 +97,7 @@ class DiffusionTrainer(nn.Module):
         self.learning_rate, self.min_learning_rate = learning_rate, min_learning_rate
         self.lr_decay, self.max_train_steps, self.optimizer = lr_decay, max_train_steps, optimizer
         self.gradient_clip_val = gradient_clip_val
+        self.fused_optimizer = True  # ClipRAdam on GPU; False -> clip_grad_norm_ + torch.optim.RAdam
         self._opt = self._sched = None
         self.ddp = None  # set to a parallel.BucketedDataParallel(self) for multi-GPU training
 
@@ -130,7 +131,13 @@ class DiffusionTrainer(nn.Module):
         klass = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "radam": torch.optim.RAdam}.get(self.optimizer)
         if klass is None:
             raise RuntimeError(f"Unknown optimizer {self.optimizer}")
-        opt = klass(self.parameters(), lr=self.learning_rate)
+        params = list(self.parameters())
+        if self.optimizer == "radam" and self.fused_optimizer and params[0].is_cuda:
+            from .optim import ClipRAdam  # clip + RAdam fused; same arithmetic as the two torch calls
+
+            opt = ClipRAdam(params, lr=self.learning_rate, max_norm=self.gradient_clip_val or None)
+        else:
+            opt = klass(params, lr=self.learning_rate)
         sched = None
         if self.lr_decay == "exp":
             rate = math.log(self.min_learning_rate / self.learning_rate) / self.max_train_steps
@@ -146,7 +153,7 @@ class DiffusionTrainer(nn.Module):
         loss.backward()
         if self.ddp is not None:
             self.ddp.finish()
-        if self.gradient_clip_val:
+        if self.gradient_clip_val and not hasattr(self._opt, "max_norm"):
             torch.nn.utils.clip_grad_norm_(self.parameters(), self.gradient_clip_val)
         self._opt.step()
         if self._sched is not None:

@@ -222,6 +222,32 @@ int tdx_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t
 int tdx_randn_batched(float* out, int B, int64_t n, uint64_t seed, const uint64_t* stream_ids, uint64_t* offset_dev,
                       void* stream);
 
+/* ---- optimiser tail of the training step ------------------------------------------------------
+ * Replaces torch.nn.utils.clip_grad_norm_ (Lightning gradient_clip_val = 0.1, config/train.yaml:30-31)
+ * and torch.optim.RAdam.step (models/diffusion.py:210-218; betas (0.9, 0.999), eps 1e-8, no weight
+ * decay) over all parameter tensors at once.  `table`: device array of one TdxOptTensor per
+ * parameter (fp32, contiguous; grad == NULL: the parameter is skipped).  The element range of every
+ * tensor is cut into chunks of tdx_opt_chunk_elems(); chunk c covers tensor chunk_tensor[c] from
+ * element chunk_off[c] (device arrays of nchunks entries, built once by the host). */
+typedef struct {
+    void* param;
+    void* grad;
+    void* exp_avg;
+    void* exp_avg_sq;
+    int64_t numel;
+} TdxOptTensor;
+int64_t tdx_opt_chunk_elems(void);
+/* out[0] = L2 norm over all gradients, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6))
+ * (1 when max_norm <= 0).  partial: nchunks floats of scratch.  No host synchronisation. */
+int tdx_grad_norm(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
+                  float max_norm, float* partial, float* out, void* stream);
+/* One RAdam step number `step` (1-based) with gradients scaled by clip[1] (clip: the `out` of
+ * tdx_grad_norm, or NULL for no clipping); write_grad != 0 also stores the scaled gradients back,
+ * as clip_grad_norm_ does. */
+int tdx_radam_step(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
+                   const float* clip, int64_t step, float lr, float beta1, float beta2, float eps, int write_grad,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

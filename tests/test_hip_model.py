@@ -111,22 +111,30 @@ def test_p_sample_mean_logvar_golden(golden):
     assert torch.equal(log_var.cpu(), g["p_sample_t6/log_var"])
 
 
-def test_three_training_steps_golden(golden):
+@pytest.mark.parametrize("fused", [False, True])
+def test_three_training_steps_golden(golden, fused):
     """clip 0.1 -> RAdam(1e-4) -> exp LambdaLR, as DiffusionTraining.configure_optimizers
-    (diffusion.py:210-235) with trainer.gradient_clip_val = 0.1 (train.yaml:30-31)."""
+    (diffusion.py:210-235) with trainer.gradient_clip_val = 0.1 (train.yaml:30-31); with the stock
+    torch calls and with the fused ClipRAdam."""
     import math
+
+    from turbdiff_amd.optim import ClipRAdam
 
     g = golden("train_cfg1")
     diff = build_cfg1(golden)
-    opt = torch.optim.RAdam(diff.parameters(), lr=1e-4)
+    opt = ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1) if fused else torch.optim.RAdam(diff.parameters(), lr=1e-4)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: math.exp(math.log(1e-6 / 1e-4) / 20 * min(s, 20)))
     x, C, md = g["x"].to(dev()), cond(g["c_local"]), SimpleNamespace(cell_idx=g["cell_idx"].to(dev()))
     for step in range(3):
         loss, _ = diff.p_losses(x, g[f"step{step}/t"].to(dev()), C, md, None, noise=g[f"step{step}/noise"].to(dev()))
         opt.zero_grad()
         loss.backward()
-        gn = torch.nn.utils.clip_grad_norm_(diff.parameters(), 0.1)
-        opt.step()
+        if fused:
+            opt.step()
+            gn = opt.last_grad_norm
+        else:
+            gn = torch.nn.utils.clip_grad_norm_(diff.parameters(), 0.1)
+            opt.step()
         sched.step()
         assert abs(loss.item() - g[f"step{step}/loss"].item()) < 2e-4 * abs(g[f"step{step}/loss"].item())
         assert abs(gn.item() - g[f"step{step}/grad_norm"].item()) < 2e-3 * g[f"step{step}/grad_norm"].item()

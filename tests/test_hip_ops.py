@@ -551,3 +551,40 @@ def test_clean_workspace_protocol():
         assert torch.equal(y, ref_y) and rel_l2(stats.cpu(), ref_stats.cpu()) < 1e-6
         assert rel_l2(gw.cpu(), ref_gw.cpu()) < 1e-5 and rel_l2(gb.cpu(), ref_gb.cpu()) < 1e-5
         assert int(clean1.count_nonzero()) == 0 and int(clean2.count_nonzero()) == 0
+
+
+@pytest.mark.parametrize("max_norm", [0.1, None])
+def test_clip_radam_matches_torch(max_norm):
+    """ClipRAdam == clip_grad_norm_ + torch.optim.RAdam over 8 steps (the first 5 take RAdam's
+    un-rectified branch), odd tensor sizes, a parameter without gradient, LR changed mid-way."""
+    from turbdiff_amd.optim import ClipRAdam
+
+    torch.manual_seed(0)
+    d = torch.device("cuda:0")
+    shapes = [(3,), (17, 5), (64, 64, 3, 3, 3), (1,), (40000,), (33, 7, 2)]
+    pa = [torch.randn(s, device=d).requires_grad_() for s in shapes]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    oa = torch.optim.RAdam(pa, lr=1e-2)
+    ob = ClipRAdam(pb, lr=1e-2, max_norm=max_norm, write_clipped_grads=True)
+    for step in range(8):
+        gs = [torch.randn(s, device=d) * (3.0 if step % 2 else 0.01) for s in shapes]
+        for k, (a, b, g) in enumerate(zip(pa, pb, gs)):
+            a.grad, b.grad = (None, None) if k == 3 else (g.clone(), g.clone())
+        if step == 4:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 3e-3
+        if max_norm:
+            ref_norm = torch.nn.utils.clip_grad_norm_(pa, max_norm)
+        versions = [b._version for b in pb]
+        oa.step()
+        ob.step()
+        assert all((b._version > v) == (k != 3) for k, (b, v) in enumerate(zip(pb, versions)))
+        if max_norm:
+            assert abs(ob.last_grad_norm.item() - ref_norm.item()) < 1e-5 * ref_norm.item()
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (step, k, (a - b).abs().max().item())
+            if k != 3:
+                assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-9)
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    for k in sa:
+        assert float(sa[k]["step"]) == float(sb[k]["step"])
+        assert torch.allclose(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-4, atol=1e-12)
