@@ -1,5 +1,8 @@
 // Trilinear resize, align_corners=True, NDHWC (ddpm.py:359-361, 367-369).
 // HBM-bound gather kernels: one lane owns 8 channels of one voxel (16 B bf16 / 32 B f32).
+// A workgroup owns a compact 4 x 8 x 8 tile of the tensor it WRITES, so that the voxels it gathers
+// from form a small 3D region that stays in the CU's L1 (a linear thread->voxel map re-fetched every
+// gathered voxel ~17x from L2); all loads of a thread are issued before the arithmetic.
 // Index arithmetic follows ATen's upsample_trilinear3d exactly (float scale, float source
 // index, truncation, clamped second tap) so that tap selection matches the reference.
 #include "tdx_common.h"
@@ -15,56 +18,87 @@ __host__ __device__ inline AxisMap make_axis(int in, int out) {
     return a;
 }
 // taps of output index o: i0, i1, weight of i1
-__device__ __forceinline__ void axis_taps(const AxisMap& a, int o, int& i0, int& i1, float& w1) {
+__host__ __device__ __forceinline__ void axis_taps(const AxisMap& a, int o, int& i0, int& i1, float& w1) {
     const float src = a.scale * (float)o;
     i0 = min((int)src, a.in - 1);
     w1 = fminf(fmaxf(src - (float)i0, 0.0f), 1.0f);
     i1 = i0 + ((i0 + 1 < a.in) ? 1 : 0);
 }
 
+// tile of the written grid owned by one workgroup: tx x ty x tz voxels (powers of two, <= 4 x 8 x 8),
+// shrunk for wide channel counts so that a workgroup makes at most ~8 passes of 256 lanes
+struct TileGrid {
+    int nx, ny, nz;     // tiles per axis
+    int sy, sz;         // log2(ty), log2(tz)
+    int tx, ty, tz;
+};
+#define RS_MAXT 8   // largest tile extent along an axis
+#define RS_KMAX 12  // largest number of outputs reading one input along an axis (backward)
+
+__device__ __forceinline__ void tile_origin(const TileGrid& tg, int& b, int& x0, int& y0, int& z0) {
+    int t = blockIdx.x;
+    z0 = (t % tg.nz) * tg.tz; t /= tg.nz;
+    y0 = (t % tg.ny) * tg.ty; t /= tg.ny;
+    x0 = (t % tg.nx) * tg.tx;
+    b = t / tg.nx;
+}
+
+// Per-axis interpolation tables of the tile live in LDS: they are computed once per workgroup by a
+// few threads instead of once per lane (the index arithmetic, not the gather, was the bottleneck).
 template <typename T>
 __global__ void __launch_bounds__(256)
-resize_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, AxisMap ax, AxisMap ay, AxisMap az, int C, int64_t total) {
+resize_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, AxisMap ax, AxisMap ay, AxisMap az, int C, TileGrid tg) {
+    __shared__ int s_i0[3][RS_MAXT], s_i1[3][RS_MAXT];
+    __shared__ float s_w[3][RS_MAXT];
+    int b, ox0, oy0, oz0;
+    tile_origin(tg, b, ox0, oy0, oz0);
+    if (threadIdx.x < 3 * RS_MAXT) {
+        const int a = threadIdx.x / RS_MAXT, k = threadIdx.x % RS_MAXT;
+        const AxisMap& m = a == 0 ? ax : (a == 1 ? ay : az);
+        const int o = min((a == 0 ? ox0 : (a == 1 ? oy0 : oz0)) + k, m.out - 1);
+        int i0, i1;
+        float w1;
+        axis_taps(m, o, i0, i1, w1);
+        s_i0[a][k] = i0; s_i1[a][k] = i1; s_w[a][k] = w1;
+    }
+    __syncthreads();
     const int L = C >> 3;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int lc = (int)(i % L);
-    int64_t v = i / L;
-    const int oz = (int)(v % az.out); v /= az.out;
-    const int oy = (int)(v % ay.out); v /= ay.out;
-    const int ox = (int)(v % ax.out);
-    const int b = (int)(v / ax.out);
-    int x0, x1, y0, y1, z0, z1;
-    float wx, wy, wz;
-    axis_taps(ax, ox, x0, x1, wx);
-    axis_taps(ay, oy, y0, y1, wy);
-    axis_taps(az, oz, z0, z1, wz);
-    const T* xb = x + ((int64_t)b * ax.in * ay.in * az.in) * C + lc * 8;
-    float acc[8];
+    const int per_pass = 256 / L;
+    const int lc = (int)threadIdx.x % L;
+    const int nvox = tg.tx * tg.ty * tg.tz;
+    if ((int)threadIdx.x >= per_pass * L) return;
+    for (int slot = (int)threadIdx.x / L; slot < nvox; slot += per_pass) {
+        const int kz = slot & (tg.tz - 1), ky = (slot >> tg.sz) & (tg.ty - 1), kx = slot >> (tg.sz + tg.sy);
+        const int ox = ox0 + kx, oy = oy0 + ky, oz = oz0 + kz;
+        if (ox >= ax.out || oy >= ay.out || oz >= az.out) continue;
+        const float wx = s_w[0][kx], wy = s_w[1][ky], wz = s_w[2][kz];
+        const T* xb = x + ((int64_t)b * ax.in * ay.in * az.in) * C + lc * 8;
+        const int xs[2] = {s_i0[0][kx], s_i1[0][kx]}, ys[2] = {s_i0[1][ky], s_i1[1][ky]}, zs[2] = {s_i0[2][kz], s_i1[2][kz]};
+        const float wxs[2] = {1.0f - wx, wx}, wys[2] = {1.0f - wy, wy}, wzs[2] = {1.0f - wz, wz};
+        Raw8<T> t[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    const int xs[2] = {x0, x1}, ys[2] = {y0, y1}, zs[2] = {z0, z1};
-    const float wxs[2] = {1.0f - wx, wx}, wys[2] = {1.0f - wy, wy}, wzs[2] = {1.0f - wz, wz};
+        for (int k = 0; k < 8; ++k)
+            t[k].load(xb + (((int64_t)xs[k >> 2] * ay.in + ys[(k >> 1) & 1]) * az.in + zs[k & 1]) * C);
+        __builtin_amdgcn_sched_barrier(0);
+        float acc[8];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
+        for (int k = 0; k < 8; ++k) {  // x outer, y, z inner
+            const float w = wxs[k >> 2] * wys[(k >> 1) & 1] * wzs[k & 1];
+            const Vec8<T> v = t[k].get();
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float w = wxs[a] * wys[bb] * wzs[c];
-                Vec8<T> t;
-                t.load(xb + (((int64_t)xs[a] * ay.in + ys[bb]) * az.in + zs[c]) * C);
+            for (int j = 0; j < 8; ++j) acc[j] += w * v.v[j];
+        }
+        Vec8<T> o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += w * t.v[j];
-            }
-    Vec8<T> o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
-    o.store(y + ((((int64_t)b * ax.out + ox) * ay.out + oy) * az.out + oz) * C + lc * 8);
+        for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+        o.store(y + ((((int64_t)b * ax.out + ox) * ay.out + oy) * az.out + oz) * C + lc * 8);
+    }
 }
 
 // range [lo, hi] of outputs that can read input index i (a superset; weights decide)
-__device__ __forceinline__ void axis_range(const AxisMap& a, int i, int& lo, int& hi) {
+__host__ __device__ __forceinline__ void axis_range(const AxisMap& a, int i, int& lo, int& hi) {
     if (a.scale > 0.f) {
         lo = max(0, (int)floorf((float)(i - 1) / a.scale) - 1);
         hi = min(a.out - 1, (int)ceilf((float)(i + 1) / a.scale) + 1);
@@ -73,7 +107,7 @@ __device__ __forceinline__ void axis_range(const AxisMap& a, int i, int& lo, int
     }
 }
 // weight with which output o reads input i (adjoint of axis_taps); 0 if it does not
-__device__ __forceinline__ float axis_weight(const AxisMap& a, int o, int i) {
+__host__ __device__ __forceinline__ float axis_weight(const AxisMap& a, int o, int i) {
     int i0, i1;
     float w1;
     axis_taps(a, o, i0, i1, w1);
@@ -82,73 +116,146 @@ __device__ __forceinline__ float axis_weight(const AxisMap& a, int o, int i) {
     if (i1 == i) w += w1;
     return w;
 }
+// first output with a non-zero weight on input i and the number of outputs up to the last one
+__host__ __device__ __forceinline__ void axis_span(const AxisMap& a, int i, int& first, int& cnt) {
+    int lo, hi;
+    axis_range(a, i, lo, hi);
+    first = hi + 1;
+    int last = lo - 1;
+    for (int o = lo; o <= hi; ++o)
+        if (axis_weight(a, o, i) != 0.f) {
+            first = min(first, o);
+            last = o;
+        }
+    cnt = last - first + 1;
+    if (cnt < 0) cnt = 0;
+}
 
-// adjoint gather: dx[i] = sum over outputs o of w(o, i) dy[o]; weights are recomputed on the
-// fly (a handful of VALU ops) instead of being tabulated, so nothing lives in scratch
-template <typename T>
+// adjoint gather: dx[i] = sum over outputs o of w(o, i) dy[o].  Per axis and tile entry the LDS
+// tables hold the first contributing output, their number (<= RS_KMAX, host-checked) and weights.
+// K bounds the z candidates at compile time: per (x, y) candidate row the K z-loads go out
+// together (clamped addresses, zero weights for the unused ones).
+template <typename T, int K>
 __global__ void __launch_bounds__(256)
-resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, AxisMap ay, AxisMap az, int C, int64_t total) {
+resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, AxisMap ay, AxisMap az, int C, TileGrid tg) {
+    __shared__ int s_first[3][RS_MAXT], s_cnt[3][RS_MAXT];
+    __shared__ float s_w[3][RS_MAXT][RS_KMAX];
+    int b, ix0, iy0, iz0;
+    tile_origin(tg, b, ix0, iy0, iz0);
+    if (threadIdx.x < 3 * RS_MAXT) {
+        const int a = threadIdx.x / RS_MAXT, k = threadIdx.x % RS_MAXT;
+        const AxisMap& m = a == 0 ? ax : (a == 1 ? ay : az);
+        const int i = min((a == 0 ? ix0 : (a == 1 ? iy0 : iz0)) + k, m.in - 1);
+        int f, c;
+        axis_span(m, i, f, c);
+        s_first[a][k] = f; s_cnt[a][k] = c;
+        for (int j = 0; j < RS_KMAX; ++j) s_w[a][k][j] = j < c ? axis_weight(m, f + j, i) : 0.f;
+    }
+    __syncthreads();
     const int L = C >> 3;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int lc = (int)(i % L);
-    int64_t v = i / L;
-    const int iz = (int)(v % az.in); v /= az.in;
-    const int iy = (int)(v % ay.in); v /= ay.in;
-    const int ix = (int)(v % ax.in);
-    const int b = (int)(v / ax.in);
-    int x0, x1, y0, y1, z0, z1;
-    axis_range(ax, ix, x0, x1);
-    axis_range(ay, iy, y0, y1);
-    axis_range(az, iz, z0, z1);
-    const T* gb = dy + ((int64_t)b * ax.out * ay.out * az.out) * C + lc * 8;
-    float acc[8];
+    const int per_pass = 256 / L;
+    const int lc = (int)threadIdx.x % L;
+    const int nvox = tg.tx * tg.ty * tg.tz;
+    if ((int)threadIdx.x >= per_pass * L) return;
+    for (int slot = (int)threadIdx.x / L; slot < nvox; slot += per_pass) {
+        const int kz = slot & (tg.tz - 1), ky = (slot >> tg.sz) & (tg.ty - 1), kx = slot >> (tg.sz + tg.sy);
+        const int ix = ix0 + kx, iy = iy0 + ky, iz = iz0 + kz;
+        if (ix >= ax.in || iy >= ay.in || iz >= az.in) continue;
+        const int fx = s_first[0][kx], cx = s_cnt[0][kx], fy = s_first[1][ky], cy = s_cnt[1][ky], fz = s_first[2][kz];
+        float wz[K];
+        int oz[K];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int ox = x0; ox <= x1; ++ox) {
-        const float wx = axis_weight(ax, ox, ix);
-        if (wx == 0.f) continue;
-        for (int oy = y0; oy <= y1; ++oy) {
-            const float wxy = wx * axis_weight(ay, oy, iy);
-            if (wxy == 0.f) continue;
-            const T* row = gb + (((int64_t)ox * ay.out + oy) * az.out) * C;
-            for (int oz = z0; oz <= z1; ++oz) {
-                const float w = wxy * axis_weight(az, oz, iz);
-                if (w == 0.f) continue;
-                Vec8<T> t;
-                t.load(row + (int64_t)oz * C);
+        for (int k = 0; k < K; ++k) {
+            oz[k] = min(fz + k, az.out - 1);
+            wz[k] = s_w[2][kz][k];
+        }
+        const T* gb = dy + ((int64_t)b * ax.out * ay.out * az.out) * C + lc * 8;
+        float acc[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += w * t.v[j];
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int a = 0; a < cx; ++a) {
+            const float wx = s_w[0][kx][a];
+            for (int bb = 0; bb < cy; ++bb) {
+                const float wxy = wx * s_w[1][ky][bb];
+                const T* row = gb + (((int64_t)(fx + a) * ay.out + (fy + bb)) * az.out) * C;
+                Raw8<T> t[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) t[k].load(row + (int64_t)oz[k] * C);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float w = wxy * wz[k];
+                    const Vec8<T> v = t[k].get();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += w * v.v[j];
+                }
             }
         }
-    }
-    Vec8<T> o;
+        Vec8<T> o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
-    o.store(dx + ((((int64_t)b * ax.in + ix) * ay.in + iy) * az.in + iz) * C + lc * 8);
+        for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+        o.store(dx + ((((int64_t)b * ax.in + ix) * ay.in + iy) * az.in + iz) * C + lc * 8);
+    }
 }
 
 static int resize_args_ok(int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C) {
     return B > 0 && Xi > 0 && Yi > 0 && Zi > 0 && Xo > 0 && Yo > 0 && Zo > 0 && C > 0;
 }
+static TileGrid make_tiles(int X, int Y, int Z, int C) {
+    // ~8 passes of (256 / L) voxels: 256 voxels up to 64 channels, halved for every doubling beyond
+    const int L = C >> 3;
+    int vox = 256;
+    while (vox > 8 && vox * L > 8 * 256) vox >>= 1;
+    TileGrid t;
+    t.tz = 8; t.ty = 8; t.tx = 4;
+    // shrink x first, then y, then z, down to the voxel budget
+    while (t.tx * t.ty * t.tz > vox && t.tx > 1) t.tx >>= 1;
+    while (t.tx * t.ty * t.tz > vox && t.ty > 1) t.ty >>= 1;
+    while (t.tx * t.ty * t.tz > vox && t.tz > 1) t.tz >>= 1;
+    t.sy = 0; while ((1 << t.sy) < t.ty) ++t.sy;
+    t.sz = 0; while ((1 << t.sz) < t.tz) ++t.sz;
+    t.nx = ceil_div(X, t.tx); t.ny = ceil_div(Y, t.ty); t.nz = ceil_div(Z, t.tz);
+    return t;
+}
 extern "C" int tdx_resize_fwd(const void* x, void* y, int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C,
                               int dtype, void* stream) {
     TDX_CHECK_ARG(x && y && resize_args_ok(B, Xi, Yi, Zi, Xo, Yo, Zo, C));
-    if (C % 8) return TDX_ESHAPE;
-    const int64_t total = (int64_t)B * Xo * Yo * Zo * (C / 8);
-    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_fwd_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0,
+    if (C % 8 || C / 8 > 256) return TDX_ESHAPE;
+    const TileGrid tg = make_tiles(Xo, Yo, Zo, C);
+    const int64_t blocks = (int64_t)B * tg.nx * tg.ny * tg.nz;
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_fwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0,
                                                   as_stream(stream), (const T*)x, (T*)y, make_axis(Xi, Xo),
-                                                  make_axis(Yi, Yo), make_axis(Zi, Zo), C, total));
+                                                  make_axis(Yi, Yo), make_axis(Zi, Zo), C, tg));
     return tdx_launch_status();
+}
+
+// largest number of outputs that read one input along an axis (exact, same float arithmetic)
+static int axis_max_span(const AxisMap& a) {
+    int m = 0;
+    for (int i = 0; i < a.in; ++i) {
+        int f, c;
+        axis_span(a, i, f, c);
+        m = c > m ? c : m;
+    }
+    return m;
 }
 
 extern "C" int tdx_resize_bwd(const void* dy, void* dx, int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C,
                               int dtype, void* stream) {
     TDX_CHECK_ARG(dy && dx && resize_args_ok(B, Xi, Yi, Zi, Xo, Yo, Zo, C));
-    if (C % 8) return TDX_ESHAPE;
-    const int64_t total = (int64_t)B * Xi * Yi * Zi * (C / 8);
-    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_bwd_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0,
-                                                  as_stream(stream), (const T*)dy, (T*)dx, make_axis(Xi, Xo),
-                                                  make_axis(Yi, Yo), make_axis(Zi, Zo), C, total));
+    if (C % 8 || C / 8 > 256) return TDX_ESHAPE;
+    const AxisMap ax = make_axis(Xi, Xo), ay = make_axis(Yi, Yo), az = make_axis(Zi, Zo);
+    const int kx = axis_max_span(ax), ky = axis_max_span(ay), kz = axis_max_span(az);
+    if (kx > RS_KMAX || ky > RS_KMAX || kz > RS_KMAX) return TDX_ESHAPE;  // more than ~6x upsampling along an axis
+    const TileGrid tg = make_tiles(Xi, Yi, Zi, C);
+    const dim3 grid((unsigned)((int64_t)B * tg.nx * tg.ny * tg.nz));
+#define RS_BWD(KV)                                                                                                     \
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_bwd_kernel<T, KV>), grid, dim3(256), 0, as_stream(stream),     \
+                                                  (const T*)dy, (T*)dx, ax, ay, az, C, tg))
+    if (kz <= 2) RS_BWD(2);
+    else if (kz <= 4) RS_BWD(4);
+    else if (kz <= 6) RS_BWD(6);
+    else RS_BWD(RS_KMAX);
+#undef RS_BWD
     return tdx_launch_status();
 }
