@@ -224,13 +224,18 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-    float bsum = 0.f;
     const bool do_bias = dbias != nullptr && ci0 == 0;
     const int64_t nchunks = (rows + C1M_ROWS - 1) / C1M_ROWS;
 
-    for (int64_t ch = split; ch < nchunks; ch += nsplit) {
+    // software pipeline: the rows of chunk ch + nsplit are in flight (registers) while chunk ch is
+    // reduced out of LDS.  A thread always stages the same 8 output channels (chunk tid & 3 of plane
+    // (tid >> 2) % NT), so the bias gradient is accumulated from its registers, not re-read from LDS.
+    uint4 xr[MT * 4], gr[NT * 4];
+    float bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+    auto load_chunk = [&](int64_t ch) {
         const int64_t row0 = ch * C1M_ROWS;
-        uint4 xr[MT * 4], gr[NT * 4];
 #pragma unroll
         for (int i = 0; i < MT * 4; ++i) {
             const int pc = tid + i * 256;  // (row, plane, chunk): chunk fastest
@@ -245,6 +250,9 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
             gr[i] = make_uint4(0, 0, 0, 0);
             if (row0 + rr < rows) gr[i] = *reinterpret_cast<const uint4*>(dy + (row0 + rr) * Cout + co0 + pl * 32 + c * 8);
         }
+    };
+    if (split < nchunks) load_chunk(split);
+    for (int64_t ch = split; ch < nchunks; ch += nsplit) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < MT * 4; ++i) {
@@ -257,16 +265,17 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
             const int pc = tid + i * 256;
             const int c = pc & 3, pl = (pc >> 2) % NT, rr = pc / (4 * NT);
             *reinterpret_cast<uint4*>(sG + pl * C1W_PLANE + rr * 64 + c * 16) = gr[i];
+            if (do_bias) {
+                const unsigned wds[4] = {gr[i].x, gr[i].y, gr[i].z, gr[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bs[2 * e] += __uint_as_float(wds[e] << 16);
+                    bs[2 * e + 1] += __uint_as_float(wds[e] & 0xffff0000u);
+                }
+            }
         }
         __syncthreads();
-        if (do_bias) {
-            constexpr int NCO = 32 * NT;
-            const int co = tid % NCO, part = tid / NCO, nparts = 256 / NCO;
-            const unsigned char* gp = sG + (co >> 5) * C1W_PLANE + (co & 31) * 2;
-            float s = 0.f;
-            for (int v = part; v < C1M_ROWS; v += nparts) s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(gp + v * 64));
-            bsum += s;
-        }
+        if (ch + nsplit < nchunks) load_chunk(ch + nsplit);
         // wave reduces rows [64 wave, 64 wave + 64): 4 K-steps of 16 rows
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -299,7 +308,21 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
                 const int ci = ci0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
                 atomicAdd(&dw[(size_t)ci * ldw + co0 + n * 32 + r], acc[m][n][i]);
             }
-    if (do_bias) atomicAdd(&dbias[co0 + tid % (32 * NT)], bsum);
+    if (do_bias) {
+        // threads with equal (tid & 3, (tid >> 2) % NT) hold partial sums of the same 8 channels
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);  // [256][8]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bs[e];
+        __syncthreads();
+        if (tid < 32 * NT) {
+            const int pl = tid >> 5, c = (tid & 31) >> 3, e = tid & 7;
+            float t = 0.f;
+            for (int k = 0; k < 256; ++k)
+                if ((k & 3) == c && ((k >> 2) % NT) == pl) t += red[k * 8 + e];
+            atomicAdd(&dbias[co0 + tid], t);
+        }
+    }
 }
 
 int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
@@ -308,7 +331,9 @@ int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, fl
     const int n_ci = Cin / (32 * MT), n_co = Cout / (32 * NT);
     const int ntiles = n_ci * n_co;
     const int64_t nchunks = (rows + C1M_ROWS - 1) / C1M_ROWS;
-    int nsplit = (1024 + ntiles - 1) / ntiles;
+    // one full wave of resident workgroups (LDS-limited occupancy), so that no partial second round trails
+    const int per_cu = 160 / ((MT + NT) * 16);
+    int nsplit = (per_cu * 256 + ntiles - 1) / ntiles;
     if (nsplit > nchunks) nsplit = (int)nchunks;
     if (nsplit < 1) nsplit = 1;
     dim3 grid((unsigned)(ntiles * nsplit));
