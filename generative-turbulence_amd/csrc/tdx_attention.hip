@@ -12,6 +12,21 @@
 #include "tdx_common.h"
 #include <stdlib.h>
 
+// The "other side" rows are walked in tiles of 64 staged in LDS as f32 (thread t stages row t with
+// 16-B loads); the inner loops then read them with wave-uniform (broadcast) LDS loads instead of a
+// chain of dependent global loads per row.
+#define AT_TILE 64
+template <typename T, int D>
+__device__ __forceinline__ void attn_stage_row(float* __restrict__ dst, const T* __restrict__ src, bool ok) {
+#pragma unroll
+    for (int c = 0; c < D / 8; ++c) {
+        Vec8<T> v;
+        if (ok) v.load(src + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[c * 8 + e] = ok ? v.v[e] : 0.f;
+    }
+}
+
 template <typename T, int D>
 __global__ void __launch_bounds__(64)
 attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse, int N, int H) {
@@ -26,19 +41,26 @@ attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restric
 #pragma unroll
     for (int d = 0; d < D; ++d) { q[d] = ldf(base + (int64_t)ii * ld + h * D + d) * scale; acc[d] = 0.f; }
     float m = -INFINITY, l = 0.f;
-    for (int j = 0; j < N; ++j) {
-        const T* kr = base + (int64_t)j * ld + H * D + h * D;
-        const T* vr = kr + H * D;
-        float s = 0.f;
+    __shared__ float sK[AT_TILE][D], sV[AT_TILE][D];
+    for (int j0 = 0; j0 < N; j0 += AT_TILE) {
+        const int jr = j0 + (int)threadIdx.x;
+        __syncthreads();
+        attn_stage_row<T, D>(sK[threadIdx.x], base + (int64_t)jr * ld + H * D + h * D, jr < N);
+        attn_stage_row<T, D>(sV[threadIdx.x], base + (int64_t)jr * ld + 2 * H * D + h * D, jr < N);
+        __syncthreads();
+        const int nj = min(AT_TILE, N - j0);
+        for (int j = 0; j < nj; ++j) {
+            float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) s += q[d] * ldf(kr + d);
-        const float mn = fmaxf(m, s);
-        const float alpha = __expf(m - mn);
-        const float p = __expf(s - mn);
-        l = l * alpha + p;
+            for (int d = 0; d < D; ++d) s += q[d] * sK[j][d];
+            const float mn = fmaxf(m, s);
+            const float alpha = __expf(m - mn);
+            const float p = __expf(s - mn);
+            l = l * alpha + p;
 #pragma unroll
-        for (int d = 0; d < D; ++d) acc[d] = acc[d] * alpha + p * ldf(vr + d);
-        m = mn;
+            for (int d = 0; d < D; ++d) acc[d] = acc[d] * alpha + p * sV[j][d];
+            m = mn;
+        }
     }
     if (valid) {
         const float inv = 1.0f / l;
@@ -88,15 +110,22 @@ attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const 
     }
     const float L = lse[((int64_t)b * H + h) * N + ii];
     const float dl = delta[((int64_t)b * H + h) * N + ii];
-    for (int j = 0; j < N; ++j) {
-        const T* kr = base + (int64_t)j * ld + H * D + h * D;
-        const T* vr = kr + H * D;
-        float s = 0.f, dp = 0.f;
+    __shared__ float sK[AT_TILE][D], sV[AT_TILE][D];
+    for (int j0 = 0; j0 < N; j0 += AT_TILE) {
+        const int jr = j0 + (int)threadIdx.x;
+        __syncthreads();
+        attn_stage_row<T, D>(sK[threadIdx.x], base + (int64_t)jr * ld + H * D + h * D, jr < N);
+        attn_stage_row<T, D>(sV[threadIdx.x], base + (int64_t)jr * ld + 2 * H * D + h * D, jr < N);
+        __syncthreads();
+        const int nj = min(AT_TILE, N - j0);
+        for (int j = 0; j < nj; ++j) {
+            float s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) { s += q[d] * ldf(kr + d); dp += g[d] * ldf(vr + d); }
-        const float ds = __expf(s - L) * (dp - dl);
+            for (int d = 0; d < D; ++d) { s += q[d] * sK[j][d]; dp += g[d] * sV[j][d]; }
+            const float ds = __expf(s - L) * (dp - dl);
 #pragma unroll
-        for (int d = 0; d < D; ++d) acc[d] += ds * ldf(kr + d);
+            for (int d = 0; d < D; ++d) acc[d] += ds * sK[j][d];
+        }
     }
     if (valid) {
         T* o = dqkv + ((int64_t)b * N + i) * ld + h * D;
@@ -124,18 +153,25 @@ attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const
         v[d] = ldf(base + (int64_t)jj * ld + 2 * H * D + h * D + d);
         dk[d] = dv[d] = 0.f;
     }
-    for (int i = 0; i < N; ++i) {
-        const T* qr = base + (int64_t)i * ld + h * D;
-        const T* gr = dout + ((int64_t)b * N + i) * (H * D) + h * D;
-        const float L = lse[((int64_t)b * H + h) * N + i];
-        const float dl = delta[((int64_t)b * H + h) * N + i];
-        float s = 0.f, dp = 0.f;
+    __shared__ float sQ[AT_TILE][D], sG[AT_TILE][D], sL[AT_TILE], sDl[AT_TILE];
+    for (int i0 = 0; i0 < N; i0 += AT_TILE) {
+        const int ir = i0 + (int)threadIdx.x;
+        __syncthreads();
+        attn_stage_row<T, D>(sQ[threadIdx.x], base + (int64_t)ir * ld + h * D, ir < N);
+        attn_stage_row<T, D>(sG[threadIdx.x], dout + ((int64_t)b * N + ir) * (H * D) + h * D, ir < N);
+        sL[threadIdx.x] = ir < N ? lse[((int64_t)b * H + h) * N + ir] : 0.f;
+        sDl[threadIdx.x] = ir < N ? delta[((int64_t)b * H + h) * N + ir] : 0.f;
+        __syncthreads();
+        const int ni = min(AT_TILE, N - i0);
+        for (int i = 0; i < ni; ++i) {
+            float s = 0.f, dp = 0.f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) { s += k[d] * ldf(qr + d); dp += v[d] * ldf(gr + d); }
-        const float p = __expf(s - L);
-        const float ds = p * (dp - dl);
+            for (int d = 0; d < D; ++d) { s += k[d] * sQ[i][d]; dp += v[d] * sG[i][d]; }
+            const float p = __expf(s - sL[i]);
+            const float ds = p * (dp - sDl[i]);
 #pragma unroll
-        for (int d = 0; d < D; ++d) { dv[d] += p * ldf(gr + d); dk[d] += ds * ldf(qr + d); }
+            for (int d = 0; d < D; ++d) { dv[d] += p * sG[i][d]; dk[d] += ds * sQ[i][d]; }
+        }
     }
     if (valid) {
         T* ok = dqkv + ((int64_t)b * N + j) * ld + H * D + h * D;
