@@ -13,7 +13,8 @@
 #include "tdx_common.h"
 
 #define CD_THREADS 256
-#define CD_VOX 2048  // voxels per block
+#define CD_VOX 512  // voxels per block (~4 resident blocks per CU at 192x64x48)
+#define CD_VOX_DEC 2048  // decode: grid already has a batch dimension; fewer blocks -> fewer gradient atomics
 #define CD_MAXF 8
 
 template <int N>
@@ -102,30 +103,38 @@ encode_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, const f
         float dcl[F];
 #pragma unroll
         for (int k = 0; k < F; ++k) dcl[k] = 0.f;
-        for (int b = 0; b < B; ++b) {
-            Vec8<T> g;
+        // samples in groups of 3: all loads of a group are issued before the arithmetic
+        for (int b0 = 0; b0 < B; b0 += 3) {
+            Raw8<T> graw[3];
+            float in[3][F];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) g.v[j] = 0.f;
-            float in[F];
-#pragma unroll
-            for (int k = 0; k < F; ++k) in[k] = 0.f;
-            if (ok) {
-                g.load(dy + ((int64_t)b * V + v) * Dtot + lc * 8);
+            for (int u = 0; u < 3; ++u) {
+                const int b = min(b0 + u, B - 1);
+                const bool okb = ok && b0 + u < B;
+                graw[u].load(dy + ((int64_t)b * V + (okb ? v : v0)) * Dtot + lc * 8);
                 const float* src = is_x ? x + (int64_t)b * F * V : c;
 #pragma unroll
-                for (int k = 0; k < F; ++k) in[k] = src[(int64_t)k * V + v];
+                for (int k = 0; k < F; ++k) in[u][k] = src[(int64_t)k * V + (okb ? v : v0)];
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int u = 0; u < 3; ++u) {
+                const bool okb = ok && b0 + u < B;
+                Vec8<T> g = graw[u].get();
 #pragma unroll
-                for (int k = 0; k < F; ++k) s[j * F + k] += g.v[j] * in[k];
-                s[8 * F + j] += g.v[j];
-            }
-            if (!is_x) {
+                for (int j = 0; j < 8; ++j) g.v[j] = okb ? g.v[j] : 0.f;
 #pragma unroll
-                for (int k = 0; k < F; ++k)
+                for (int j = 0; j < 8; ++j) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dcl[k] += wr[j][k] * g.v[j];
+                    for (int k = 0; k < F; ++k) s[j * F + k] += g.v[j] * in[u][k];
+                    s[8 * F + j] += g.v[j];
+                }
+                if (!is_x) {
+#pragma unroll
+                    for (int k = 0; k < F; ++k)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) dcl[k] += wr[j][k] * g.v[j];
+                }
             }
         }
         if (dc != nullptr && Lc > 0) {
@@ -205,7 +214,7 @@ decode_fwd_kernel(const T* __restrict__ h, const float* __restrict__ w, const fl
     for (int f = 0; f < F; ++f)
 #pragma unroll
         for (int j = 0; j < 8; ++j) wr[f][j] = w[f * D + lc * 8 + j];
-    const int64_t v0 = (int64_t)blockIdx.x * CD_VOX, v1 = min(V, v0 + CD_VOX);
+    const int64_t v0 = (int64_t)blockIdx.x * CD_VOX_DEC, v1 = min(V, v0 + CD_VOX_DEC);
     for (int64_t vb = v0; vb < v1; vb += rows) {
         const int64_t v = vb + r;
         const bool ok = r < rows && v < v1;
@@ -239,7 +248,7 @@ decode_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ h, const f
         for (int j = 0; j < 8; ++j) wr[f][j] = w[f * D + lc * 8 + j];
 #pragma unroll
     for (int j = 0; j < F * 8 + F; ++j) s[j] = 0.f;
-    const int64_t v0 = (int64_t)blockIdx.x * CD_VOX, v1 = min(V, v0 + CD_VOX);
+    const int64_t v0 = (int64_t)blockIdx.x * CD_VOX_DEC, v1 = min(V, v0 + CD_VOX_DEC);
     if (active) {
         for (int64_t v = v0 + r; v < v1; v += rows) {
             float g[F];
@@ -280,7 +289,7 @@ extern "C" int tdx_decode_fwd(const void* h, const float* w, const float* bias, 
                               int dtype, void* stream) {
     TDX_CHECK_ARG(h && w && bias && y && B > 0 && V > 0 && D > 0);
     if ((D % 8) || !pow2(D / 8) || D / 8 > 64 || F != 4) return TDX_ESHAPE;
-    dim3 grid(ceil_div(V, CD_VOX), B);
+    dim3 grid(ceil_div(V, CD_VOX_DEC), B);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((decode_fwd_kernel<T, 4>), grid, dim3(CD_THREADS), 0, as_stream(stream),
                                                  (const T*)h, w, bias, y, V, D));
     return tdx_launch_status();
@@ -294,7 +303,7 @@ extern "C" int tdx_decode_bwd(const float* dy, const void* h, const float* w, vo
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)F * D * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)F * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
-    dim3 grid(ceil_div(V, CD_VOX), B);
+    dim3 grid(ceil_div(V, CD_VOX_DEC), B);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((decode_bwd_kernel<T, 4>), grid, dim3(CD_THREADS), 0, st, dy,
                                                  (const T*)h, w, (T*)dh, dw, db, V, D));
     return tdx_launch_status();
