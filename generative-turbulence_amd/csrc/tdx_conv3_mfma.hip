@@ -75,7 +75,7 @@ __device__ __forceinline__ int out_addr(int v, int c) {
     return v * 64 + ((c ^ ((v >> 1) & 3)) << 4);
 }
 
-template <int NT, bool XT, bool ZERO_PAD>
+template <int NT, bool XT, bool ZERO_PAD, bool PERM>
 __global__ void __launch_bounds__(256, 2)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                   const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, ConvView g,
@@ -208,7 +208,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
             const int toff = (ex * HY + ey) * SZ + ez;
             // the weight tap is indexed in GLOBAL axes; thin bricks run on permuted local axes
-            const int wtap = XT ? (ex + 1) * g.ws[0] + (ey + 1) * g.ws[1] + (ez + 1) * g.ws[2] : tap;
+            const int wtap = (XT || PERM) ? (ex + 1) * g.ws[0] + (ey + 1) * g.ws[1] + (ez + 1) * g.ws[2] : tap;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
                 xf[buf][mt] = *reinterpret_cast<const bf16x8*>(sA + hh * APLANE + (a_h[mt] + toff) * 16);
@@ -341,14 +341,14 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     }
 }
 
-template <int NT, bool XT, bool ZP>
+template <int NT, bool XT, bool ZP, bool PERM>
 static int launch_view(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                        const ConvView& v, int Cout, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
                        const void* a1, const void* a2) {
     constexpr int BN = NT * 32;
     constexpr int HXv = (XT ? 2 : 4) + 2, HYv = (XT ? 16 : 8) + 2, SZv = XT ? 10 : 12;
     const size_t lds = (size_t)2 * (HXv * HYv * SZv * 16 + 64) + (size_t)27 * BN * 32 + 128;
-    auto kern = conv3_mfma_kernel<NT, XT, ZP>;
+    auto kern = conv3_mfma_kernel<NT, XT, ZP, PERM>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -398,16 +398,32 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
             v.r0[k] = lo[a]; v.r1[k] = hi[a];
             v.nb[k] = ceil_div(hi[a] - lo[a], bl[k]);
         }
-#define M3_GO(NTV, XTV)                                                                                               \
-    (zero_pad ? launch_view<NTV, XTV, true>(x1, C1, x2, C2, wp, bias, y, v, Cout, st, gn_acc, d1, D1, d2, a1, a2)     \
-              : launch_view<NTV, XTV, false>(x1, C1, x2, C2, wp, bias, y, v, Cout, st, gn_acc, d1, D1, d2, a1, a2))
-        if (NT == 2) return xt ? M3_GO(2, true) : M3_GO(2, false);
-        return xt ? M3_GO(1, true) : M3_GO(1, false);
+#define M3_GO(NTV, XTV, PV)                                                                                            \
+    (zero_pad ? launch_view<NTV, XTV, true, PV>(x1, C1, x2, C2, wp, bias, y, v, Cout, st, gn_acc, d1, D1, d2, a1, a2)  \
+              : launch_view<NTV, XTV, false, PV>(x1, C1, x2, C2, wp, bias, y, v, Cout, st, gn_acc, d1, D1, d2, a1, a2))
+        const bool permuted = !xt && !(perm[0] == 0 && perm[1] == 1 && perm[2] == 2);
+        if (NT == 2) return xt ? M3_GO(2, true, false) : (permuted ? M3_GO(2, false, true) : M3_GO(2, false, false));
+        return xt ? M3_GO(1, true, false) : (permuted ? M3_GO(1, false, true) : M3_GO(1, false, false));
 #undef M3_GO
     };
     const int id[3] = {0, 1, 2};
     const int lo[3] = {0, 0, 0}, hi[3] = {main_end[0], main_end[1], main_end[2]};
-    int rc = launch(id, lo, hi, false);
+    // main region: the brick is 4 x 8 x 8; put its short axis on the global axis that leaves the fewest
+    // bricks (e.g. 48 x 16 x 12: 36 bricks with the 4 along z instead of 48) -- ragged grids only
+    static const bool no_perm = getenv("TDX_CONV3_PERM") && atoi(getenv("TDX_CONV3_PERM")) == 0;  // A/B switch
+    int best[3] = {0, 1, 2};
+    if (!no_perm) {
+        const int cand[3][3] = {{0, 1, 2}, {1, 0, 2}, {2, 0, 1}};
+        int64_t best_n = -1;
+        for (int c = 0; c < 3; ++c) {
+            const int64_t n = (int64_t)ceil_div(hi[cand[c][0]], 4) * ceil_div(hi[cand[c][1]], 8) * ceil_div(hi[cand[c][2]], 8);
+            if (best_n < 0 || n < best_n) {
+                best_n = n;
+                for (int k = 0; k < 3; ++k) best[k] = cand[c][k];
+            }
+        }
+    }
+    int rc = launch(best, lo, hi, false);
     if (rc != TDX_OK) return rc;
     // x slab: [main_end_x, Xo) x all y x all z           (local axes x, y, z)
     if (thin[0]) {
