@@ -18,6 +18,7 @@
 // atomics (128-B contiguous per half-wave) into dwp[27][Cin][Cout].
 #include "tdx_common.h"
 #include "tdx_conv3.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -37,6 +38,17 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 #define W3_GPLANE (W3_NVOX * 64)    // one 32-channel dy plane
 #define W3_TAPS_PER_WAVE 7
 
+// grid in the kernel's local axes (local axis k = global axis perm[k]; the brick is 4 x 8 x 8 in local
+// axes, and the short axis is put where it leaves the fewest bricks)
+struct WgradView {
+    int B;
+    int E[3];     // extents
+    int s[3];     // voxel strides
+    int ws[3];    // weight-tap strides: global tap = sum_k (e_k + 1) * ws[k]
+    int nb[3];    // bricks per axis
+    int batch;    // voxels per sample
+};
+
 bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout) {
     return C1 > 0 && (C1 % 32) == 0 && (C2 % 32) == 0 && (Cout % 32) == 0;
 }
@@ -53,8 +65,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_lo, const un
 template <int NT>
 __global__ void __launch_bounds__(256, NT == 2 ? 1 : 2)
 conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
-                        const bf16* __restrict__ dy, float* __restrict__ dwp, float* __restrict__ dbias, int B, int X,
-                        int Y, int Z, int Cout, int nbx, int nby, int nbz, int nsplit, int n_ci_tiles) {
+                        const bf16* __restrict__ dy, float* __restrict__ dwp, float* __restrict__ dbias, WgradView gv,
+                        int Cout, int nsplit, int n_ci_tiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;
     unsigned char* sG = smem + W3_XBYTES;
@@ -70,7 +82,7 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
     int Cs, cbase;
     if (ci0 < C1) { xs = x1; Cs = C1; cbase = ci0; } else { xs = x2; Cs = C2; cbase = ci0 - C1; }
 
-    const int nbricks = B * nbx * nby * nbz;
+    const int nbricks = gv.B * gv.nb[0] * gv.nb[1] * gv.nb[2];
 
     // ---- fragment lane geometry (see file header)
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
@@ -84,8 +96,10 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][nt][i] = 0.f;
-    float bsum = 0.f;
     const bool do_bias = dbias != nullptr && ci0 == 0;
+    float bs[8];  // bias gradient: this thread always stages the same 8 dy channels (chunk tid % (4 NT))
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
 
     // halo offsets (in voxels) of this wave's taps
     int toff[W3_TAPS_PER_WAVE];
@@ -108,9 +122,9 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
 
     auto load_brick = [&](int brick) {
         int bb = brick;
-        const int bz = bb % nbz; bb /= nbz;
-        const int by = bb % nby; bb /= nby;
-        const int bx = bb % nbx; bb /= nbx;
+        const int bz = bb % gv.nb[2]; bb /= gv.nb[2];
+        const int by = bb % gv.nb[1]; bb /= gv.nb[1];
+        const int bx = bb % gv.nb[0]; bb /= gv.nb[0];
         const int b = bb;
         const int ox0 = bx * W3_BX, oy0 = by * W3_BY, oz0 = bz * W3_BZ;
 #pragma unroll
@@ -121,9 +135,9 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                 const int hv = pc >> 2, q4 = pc & 3;
                 const int hx = hv / (W3_HY * W3_HZ), rem = hv - hx * (W3_HY * W3_HZ);
                 const int hy = rem / W3_HZ, hz = rem - hy * W3_HZ;
-                const int sx = min(max(ox0 + hx - 1, 0), X - 1), sy = min(max(oy0 + hy - 1, 0), Y - 1),
-                          sz = min(max(oz0 + hz - 1, 0), Z - 1);
-                const int64_t vox = (((int64_t)b * X + sx) * Y + sy) * Z + sz;
+                const int sx = min(max(ox0 + hx - 1, 0), gv.E[0] - 1), sy = min(max(oy0 + hy - 1, 0), gv.E[1] - 1),
+                          sz = min(max(oz0 + hz - 1, 0), gv.E[2] - 1);
+                const int64_t vox = (int64_t)b * gv.batch + sx * gv.s[0] + sy * gv.s[1] + sz * gv.s[2];
                 xreg[i] = *reinterpret_cast<const uint4*>(xs + vox * Cs + cbase + q4 * 8);
             }
         }
@@ -133,8 +147,8 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
             const int v = pc / (4 * NT), q8 = pc - v * (4 * NT);
             const int vx = ox0 + (v >> 6), vy = oy0 + ((v >> 3) & 7), vz = oz0 + (v & 7);
             greg[i] = make_uint4(0, 0, 0, 0);
-            if (vx < X && vy < Y && vz < Z) {
-                const int64_t vox = (((int64_t)b * X + vx) * Y + vy) * Z + vz;
+            if (vx < gv.E[0] && vy < gv.E[1] && vz < gv.E[2]) {
+                const int64_t vox = (int64_t)b * gv.batch + vx * gv.s[0] + vy * gv.s[1] + vz * gv.s[2];
                 greg[i] = *reinterpret_cast<const uint4*>(dy + vox * Cout + co0 + q8 * 8);
             }
         }
@@ -150,6 +164,14 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
             const int pc = tid + i * 256;
             const int v = pc / (4 * NT), q8 = pc - v * (4 * NT);
             *reinterpret_cast<uint4*>(sG + (q8 >> 2) * W3_GPLANE + v * 64 + (q8 & 3) * 16) = greg[i];
+            if (do_bias) {
+                const unsigned wds[4] = {greg[i].x, greg[i].y, greg[i].z, greg[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bs[2 * e] += __uint_as_float(wds[e] << 16);
+                    bs[2 * e + 1] += __uint_as_float(wds[e] & 0xffff0000u);
+                }
+            }
         }
     };
 
@@ -160,16 +182,6 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
         store_brick();
         __syncthreads();
         if (brick + nsplit < nbricks) load_brick(brick + nsplit);  // in flight during the MFMA phase
-
-        if (do_bias) {
-            // column sums of the dy brick: thread -> (co = tid & (32 NT - 1), voxel slice)
-            constexpr int NCO = 32 * NT;
-            const int co = tid % NCO, part = tid / NCO, nparts = 256 / NCO;
-            const unsigned char* gp = sG + (co >> 5) * W3_GPLANE + (co & 31) * 2;
-            float s = 0.f;
-            for (int v = part; v < W3_NVOX; v += nparts) s += bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(gp + v * 64));
-            bsum += s;
-        }
 
         // K-step s: voxels (x = s >> 2, y = 2 (s & 3) + kh, z = q (+4)).  One wave per SIMD, so the
         // LDS latency has to be hidden inside the wave: while step s issues its 7 x NT MFMAs from
@@ -242,8 +254,9 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int t = 0; t < W3_TAPS_PER_WAVE; ++t) {
-        const int tap = wave + 4 * t;
-        if (tap < 27) {
+        const int ltap = wave + 4 * t;  // tap in local axes -> tap of the weight tensor
+        if (ltap < 27) {
+            const int tap = (ltap / 9) * gv.ws[0] + ((ltap / 3) % 3) * gv.ws[1] + (ltap % 3) * gv.ws[2];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -253,15 +266,44 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                 }
         }
     }
-    if (do_bias) atomicAdd(&dbias[co0 + tid % (32 * NT)], bsum);
+    if (do_bias) {
+        // threads with equal tid % (4 NT) hold partial sums of the same 8 channels
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);  // [256][8]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[tid * 8 + e] = bs[e];
+        __syncthreads();
+        if (tid < 32 * NT) {
+            const int q8 = tid >> 3, e = tid & 7;
+            float t = 0.f;
+            for (int k = q8; k < 256; k += 4 * NT) t += red[k * 8 + e];
+            atomicAdd(&dbias[co0 + tid], t);
+        }
+    }
 }
 
 int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
                             int B, int X, int Y, int Z, int Cout, hipStream_t st) {
     const int Cin = C1 + C2;
     const int NT = (Cout % 64 == 0) ? 2 : 1;
-    const int nbx = ceil_div(X, W3_BX), nby = ceil_div(Y, W3_BY), nbz = ceil_div(Z, W3_BZ);
-    const int nbricks = B * nbx * nby * nbz;
+    // local axes: brick 4 x 8 x 8; the short axis goes where it leaves the fewest bricks
+    const int E[3] = {X, Y, Z}, gs[3] = {Y * Z, Z, 1}, gw[3] = {9, 3, 1};
+    const int cand[3][3] = {{0, 1, 2}, {1, 0, 2}, {2, 0, 1}};
+    static const bool no_perm = getenv("TDX_CONV3_PERM") && atoi(getenv("TDX_CONV3_PERM")) == 0;  // A/B switch
+    int best = 0;
+    int64_t best_n = -1;
+    for (int c = 0; c < (no_perm ? 1 : 3); ++c) {
+        const int64_t n = (int64_t)ceil_div(E[cand[c][0]], W3_BX) * ceil_div(E[cand[c][1]], W3_BY) * ceil_div(E[cand[c][2]], W3_BZ);
+        if (best_n < 0 || n < best_n) { best_n = n; best = c; }
+    }
+    WgradView g;
+    g.B = B; g.batch = X * Y * Z;
+    const int bdim[3] = {W3_BX, W3_BY, W3_BZ};
+    for (int k = 0; k < 3; ++k) {
+        const int a = cand[best][k];
+        g.E[k] = E[a]; g.s[k] = gs[a]; g.ws[k] = gw[a]; g.nb[k] = ceil_div(E[a], bdim[k]);
+    }
+    const int nbricks = B * g.nb[0] * g.nb[1] * g.nb[2];
     const int n_ci = Cin / 32, n_co = Cout / (32 * NT);
     const int ntiles = n_ci * n_co;
     // one workgroup per CU (224 accumulator registers -> one wave per SIMD): aim at 256
@@ -278,7 +320,7 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2, (const bf16*)dy, \
-                           dwp, dbias, B, X, Y, Z, Cout, nbx, nby, nbz, nsplit, n_ci);                               \
+                           dwp, dbias, g, Cout, nsplit, n_ci);                               \
     } while (0)
     if (NT == 2) W3_LAUNCH(2); else W3_LAUNCH(1);
 #undef W3_LAUNCH
