@@ -68,6 +68,13 @@ struct ConvView {
     int in_batch, out_batch;  // voxels per sample
 };
 
+// up to three regions handled by ONE launch (the three remainder slabs of a grid): blocks
+// [start[r], start[r + 1]) belong to region r
+struct ConvViews {
+    ConvView v[3];
+    int start[4];
+};
+
 // output tile rows of 64 B (BN = 32) or 128 B (BN = 64); 16-B chunk c of row v at c ^ swizzle(v)
 template <int BN>
 __device__ __forceinline__ int out_addr(int v, int c) {
@@ -78,7 +85,7 @@ __device__ __forceinline__ int out_addr(int v, int c) {
 template <int NT, bool XT, bool ZERO_PAD, bool PERM>
 __global__ void __launch_bounds__(256, 2)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
-                  const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, ConvView g,
+                  const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, ConvViews gs,
                   int Cout, double* __restrict__ gn_acc, bf16* __restrict__ d1, int D1, bf16* __restrict__ d2,
                   const bf16* __restrict__ a1, const bf16* __restrict__ a2) {
     constexpr int BN = NT * 32;
@@ -97,8 +104,11 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
 
-    // block -> (n tile, b, brick)
+    // block -> region -> (n tile, b, brick)
     int bid = blockIdx.x;
+    const int region = bid >= gs.start[1] ? (bid >= gs.start[2] ? 2 : 1) : 0;
+    const ConvView& g = gs.v[region];
+    bid -= gs.start[region];
     const int b2 = bid % g.nb[2]; bid /= g.nb[2];
     const int b1 = bid % g.nb[1]; bid /= g.nb[1];
     const int b0 = bid % g.nb[0]; bid /= g.nb[0];
@@ -343,7 +353,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 
 template <int NT, bool XT, bool ZP, bool PERM>
 static int launch_view(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
-                       const ConvView& v, int Cout, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
+                       const ConvViews& v, int Cout, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
                        const void* a1, const void* a2) {
     constexpr int BN = NT * 32;
     constexpr int HXv = (XT ? 2 : 4) + 2, HYv = (XT ? 16 : 8) + 2, SZv = XT ? 10 : 12;
@@ -355,7 +365,7 @@ static int launch_view(const void* x1, int C1, const void* x2, int C2, const voi
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid((unsigned)((int64_t)v.B * v.nb[0] * v.nb[1] * v.nb[2]), Cout / BN);
+    dim3 grid((unsigned)v.start[3], Cout / BN);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2, (const bf16*)wp, bias,
                        (bf16*)y, v, Cout, gn_acc, (bf16*)d1, D1, (bf16*)d2, (const bf16*)a1, (const bf16*)a2);
     return tdx_launch_status();
@@ -384,29 +394,32 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
         thin[a] = !no_thin && rem >= 1 && rem <= 2 && Eo[a] > bdim[a] && big;
         main_end[a] = thin[a] ? Eo[a] - rem : Eo[a];
     }
-    auto launch = [&](const int perm[3], const int lo[3], const int hi[3], bool xt) -> int {
-        // local axis k = global axis perm[k]; region [lo, hi) in global output coordinates
-        ConvView v;
+    // view of region [lo, hi) (global output coordinates) with local axis k = global axis perm[k];
+    // returns the number of bricks (0: empty region)
+    auto make_view = [&](const int perm[3], const int lo[3], const int hi[3], bool xt, ConvView& v) -> int {
         v.B = g.B; v.off = g.off;
         v.in_batch = g.Xi * g.Yi * g.Zi; v.out_batch = g.Xo * g.Yo * g.Zo;
         const int bl[3] = {xt ? 2 : 4, xt ? 16 : 8, 8};
+        int64_t n = g.B;
         for (int k = 0; k < 3; ++k) {
             const int a = perm[k];
-            if (hi[a] <= lo[a]) return TDX_OK;  // empty region
             v.Ei[k] = Ei[a]; v.si[k] = si[a]; v.so[k] = so[a];
             v.ws[k] = (a == 0) ? 9 : (a == 1 ? 3 : 1);
             v.r0[k] = lo[a]; v.r1[k] = hi[a];
-            v.nb[k] = ceil_div(hi[a] - lo[a], bl[k]);
+            v.nb[k] = hi[a] > lo[a] ? ceil_div(hi[a] - lo[a], bl[k]) : 0;
+            n *= v.nb[k];
         }
-#define M3_GO(NTV, XTV, PV)                                                                                            \
-    (zero_pad ? launch_view<NTV, XTV, true, PV>(x1, C1, x2, C2, wp, bias, y, v, Cout, st, gn_acc, d1, D1, d2, a1, a2)  \
-              : launch_view<NTV, XTV, false, PV>(x1, C1, x2, C2, wp, bias, y, v, Cout, st, gn_acc, d1, D1, d2, a1, a2))
-        const bool permuted = !xt && !(perm[0] == 0 && perm[1] == 1 && perm[2] == 2);
+        return (int)n;
+    };
+    auto launch = [&](const ConvViews& vs, bool xt, bool permuted) -> int {
+        if (vs.start[3] == 0) return TDX_OK;
+#define M3_GO(NTV, XTV, PV)                                                                                             \
+    (zero_pad ? launch_view<NTV, XTV, true, PV>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1, a2)  \
+              : launch_view<NTV, XTV, false, PV>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1, a2))
         if (NT == 2) return xt ? M3_GO(2, true, false) : (permuted ? M3_GO(2, false, true) : M3_GO(2, false, false));
         return xt ? M3_GO(1, true, false) : (permuted ? M3_GO(1, false, true) : M3_GO(1, false, false));
 #undef M3_GO
     };
-    const int id[3] = {0, 1, 2};
     const int lo[3] = {0, 0, 0}, hi[3] = {main_end[0], main_end[1], main_end[2]};
     // main region: the brick is 4 x 8 x 8; put its short axis on the global axis that leaves the fewest
     // bricks (e.g. 48 x 16 x 12: 36 bricks with the 4 along z instead of 48) -- ragged grids only
@@ -423,24 +436,33 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
             }
         }
     }
-    int rc = launch(best, lo, hi, false);
+    ConvViews mainv;
+    const int nmain = make_view(best, lo, hi, false, mainv.v[0]);
+    mainv.v[1] = mainv.v[2] = mainv.v[0];
+    mainv.start[0] = 0; mainv.start[1] = mainv.start[2] = mainv.start[3] = nmain;
+    int rc = launch(mainv, false, !(best[0] == 0 && best[1] == 1 && best[2] == 2));
     if (rc != TDX_OK) return rc;
-    // x slab: [main_end_x, Xo) x all y x all z           (local axes x, y, z)
-    if (thin[0]) {
-        const int l[3] = {main_end[0], 0, 0}, h[3] = {Eo[0], Eo[1], Eo[2]};
-        if ((rc = launch(id, l, h, true)) != TDX_OK) return rc;
-    }
-    // y slab: main x range x [main_end_y, Yo) x all z    (local axes y, x, z)
-    if (thin[1]) {
-        const int pm[3] = {1, 0, 2};
-        const int l[3] = {0, main_end[1], 0}, h[3] = {main_end[0], Eo[1], Eo[2]};
-        if ((rc = launch(pm, l, h, true)) != TDX_OK) return rc;
-    }
-    // z slab: main x, y ranges x [main_end_z, Zo)         (local axes z, x, y)
-    if (thin[2]) {
-        const int pm[3] = {2, 0, 1};
-        const int l[3] = {0, 0, main_end[2]}, h[3] = {main_end[0], main_end[1], Eo[2]};
-        if ((rc = launch(pm, l, h, true)) != TDX_OK) return rc;
+    // remainder slabs, all in ONE launch of the thin-brick kernel (each has too few workgroups to
+    // fill the chip alone):
+    //   x slab: [main_end_x, Xo) x all y x all z           (local axes x, y, z)
+    //   y slab: main x range x [main_end_y, Yo) x all z    (local axes y, x, z)
+    //   z slab: main x, y ranges x [main_end_z, Zo)         (local axes z, x, y)
+    if (thin[0] || thin[1] || thin[2]) {
+        const int pm[3][3] = {{0, 1, 2}, {1, 0, 2}, {2, 0, 1}};
+        const int l[3][3] = {{main_end[0], 0, 0}, {0, main_end[1], 0}, {0, 0, main_end[2]}};
+        const int h[3][3] = {{Eo[0], Eo[1], Eo[2]}, {main_end[0], Eo[1], Eo[2]}, {main_end[0], main_end[1], Eo[2]}};
+        ConvViews tv;
+        int total = 0;
+        for (int r = 0; r < 3; ++r) {
+            tv.start[r] = total;
+            const int n = make_view(pm[r], l[r], h[r], true, tv.v[r]);
+            if (thin[r]) total += n;
+        }
+        tv.start[3] = total;
+        // regions that are not thin own an empty block range [start, start)
+        for (int r = 2; r >= 0; --r)
+            if (!thin[r]) tv.start[r] = tv.start[r + 1];
+        if ((rc = launch(tv, true, false)) != TDX_OK) return rc;
     }
     return TDX_OK;
 }
