@@ -20,10 +20,17 @@ struct Conv3Geom {
 bool conv3_mfma_supported(int C1, int C2, int Cout);
 static inline bool conv3_uses_mfma_layout(int dtype, int K, int N) { return dtype == 1 && conv3_mfma_supported(K, 0, N); }
 
+// optional extras of the MFMA forward: input row strides (0: dense) and a tensor the accumulators
+// start from ([B][V][Cout] bf16, or [V][Cout] shared by the batch)
+struct Conv3Ext {
+    int ld1, ld2;
+    const void* init;
+    bool init_shared;
+};
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                       const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr,
                       void* d1 = nullptr, int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr,
-                      const void* a2 = nullptr);
+                      const void* a2 = nullptr, const Conv3Ext* ext = nullptr);
 
 bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout);
 int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,

@@ -459,6 +459,30 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     return gn_finalize_launch(acc, stats, B, Cout, G, (int64_t)X * Y * Z, eps, TDX_GN_REPLICAS, st);
 }
 
+// Forward with a strided first input and accumulators that start from a precomputed partial
+// convolution (bf16 MFMA path only): y = conv3(x1[..., :C1] with row stride ld1, wf) + bias + init.
+extern "C" int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void* wf, const float* bias,
+                                     const void* init, int init_shared, void* y, float* stats, int G, float eps,
+                                     void* gn_workspace, int B, int X, int Y, int Z, int Cout, int dtype, int impl,
+                                     void* stream) {
+    TDX_CHECK_ARG(x1 && wf && y && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && Cout > 0 && ld1 >= C1 && (ld1 % 8) == 0);
+    TDX_CHECK_ARG(stats == nullptr || (gn_workspace && G > 0 && (Cout % G) == 0));
+    const bool clean = (impl & TDX_WS_CLEAN) != 0;
+    if (!mfma_ok(dtype, C1, 0, Cout)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
+    hipStream_t st = as_stream(stream);
+    double* acc = stats ? (double*)gn_workspace : nullptr;
+    if (acc && !clean) {
+        hipError_t e = hipMemsetAsync(acc, 0, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
+    Conv3Ext ext = {ld1, 0, init, init_shared != 0};
+    int rc = conv3_mfma_launch(x1, C1, nullptr, 0, wf, bias, y, g, Cout, false, st, acc, nullptr, 0, nullptr, nullptr, nullptr,
+                               &ext);
+    if (rc != TDX_OK || !stats) return rc;
+    return gn_finalize_launch(acc, stats, B, Cout, G, (int64_t)X * Y * Z, eps, TDX_GN_REPLICAS, st);
+}
+
 extern "C" size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z, int Cin, int dtype, int impl) {
     (void)impl;
     return (size_t)B * (X + 2) * (Y + 2) * (Z + 2) * Cin * (dtype == TDX_BF16 ? 2 : 4) + 256;

@@ -66,6 +66,8 @@ struct ConvView {
     int off;     // output voxel o reads input voxel o + off + e
     int ws[3];   // weight-tap strides of the local axes: tap index = sum_k (e_k + 1) * ws[k]  ({9,3,1} permuted)
     int in_batch, out_batch;  // voxels per sample
+    int ld1, ld2;             // row strides (elements per voxel) of the two inputs (>= C1 / C2)
+    int init_batch;           // voxels between samples of the accumulator-init tensor (0: shared by the batch)
 };
 
 // up to three regions handled by ONE launch (the three remainder slabs of a grid): blocks
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(256, 2)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                   const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, ConvViews gs,
                   int Cout, double* __restrict__ gn_acc, bf16* __restrict__ d1, int D1, bf16* __restrict__ d2,
-                  const bf16* __restrict__ a1, const bf16* __restrict__ a2) {
+                  const bf16* __restrict__ a1, const bf16* __restrict__ a2, const bf16* __restrict__ init) {
     constexpr int BN = NT * 32;
     constexpr int BX = XT ? 2 : 4, BY = XT ? 16 : 8, BZ = 8;
     constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
@@ -160,7 +162,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         const int k0 = c * M3_KC;
         const bf16* xs;
         int Cs, kk;
-        if (k0 < C1) { xs = x1; Cs = C1; kk = k0; } else { xs = x2; Cs = C2; kk = k0 - C1; }
+        if (k0 < C1) { xs = x1; Cs = g.ld1; kk = k0; } else { xs = x2; Cs = g.ld2; kk = k0 - C1; }
         xs += batch_vox * Cs + kk;
 #pragma unroll
         for (int i = 0; i < A_PER_THREAD; ++i) {
@@ -287,7 +289,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         const int v = p / CHUNKS, cidx = p % CHUNKS;
         const int c0 = o0 + (v >> 3) / BY, c1 = o1 + (v >> 3) % BY, c2 = o2 + (v & 7);
         if (c0 < g.r1[0] && c1 < g.r1[1] && c2 < g.r1[2]) {
-            const uint4 val = *reinterpret_cast<const uint4*>(sO + out_addr<BN>(v, cidx));
+            uint4 val = *reinterpret_cast<const uint4*>(sO + out_addr<BN>(v, cidx));
             bool direct = false;
             if (ZERO_PAD && d1 != nullptr) {
                 // data gradient: padded position = original voxel + 1.  Interior positions go
@@ -316,6 +318,17 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             }
             if (!direct) {
                 const int64_t ov = (int64_t)b * g.out_batch + c0 * g.so[0] + c1 * g.so[1] + c2 * g.so[2];
+                if (init != nullptr) {
+                    // continue from a precomputed partial convolution ([B or 1][voxels][Cout] bf16), added in
+                    // the coalesced store loop; the statistics below see the sum
+                    const int64_t iv = (int64_t)b * g.init_batch + c0 * g.so[0] + c1 * g.so[1] + c2 * g.so[2];
+                    Vec8<bf16> va, vb;
+                    va.load(reinterpret_cast<const bf16*>(&val));
+                    vb.load(init + iv * Cout + n0 + cidx * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) va.v[e] += vb.v[e];
+                    va.store(reinterpret_cast<bf16*>(&val));
+                }
                 *reinterpret_cast<uint4*>(y + ov * Cout + n0 + cidx * 8) = val;
             }
             if (gn_acc != nullptr) {
@@ -354,7 +367,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 template <int NT, bool XT, bool ZP, bool PERM>
 static int launch_view(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                        const ConvViews& v, int Cout, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
-                       const void* a1, const void* a2) {
+                       const void* a1, const void* a2, const void* init) {
     constexpr int BN = NT * 32;
     constexpr int HXv = (XT ? 2 : 4) + 2, HYv = (XT ? 16 : 8) + 2, SZv = XT ? 10 : 12;
     const size_t lds = (size_t)2 * (HXv * HYv * SZv * 16 + 64) + (size_t)27 * BN * 32 + 128;
@@ -367,14 +380,15 @@ static int launch_view(const void* x1, int C1, const void* x2, int C2, const voi
     }
     dim3 grid((unsigned)v.start[3], Cout / BN);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2, (const bf16*)wp, bias,
-                       (bf16*)y, v, Cout, gn_acc, (bf16*)d1, D1, (bf16*)d2, (const bf16*)a1, (const bf16*)a2);
+                       (bf16*)y, v, Cout, gn_acc, (bf16*)d1, D1, (bf16*)d2, (const bf16*)a1, (const bf16*)a2, (const bf16*)init);
     return tdx_launch_status();
 }
 
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                       const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1,
-                      void* d2, const void* a1, const void* a2) {
+                      void* d2, const void* a1, const void* a2, const Conv3Ext* ext) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
+    const void* init = ext ? ext->init : nullptr;
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
     static const bool no_thin = getenv("TDX_CONV3_THIN") && atoi(getenv("TDX_CONV3_THIN")) == 0;  // A/B switch
 
@@ -399,6 +413,9 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
     auto make_view = [&](const int perm[3], const int lo[3], const int hi[3], bool xt, ConvView& v) -> int {
         v.B = g.B; v.off = g.off;
         v.in_batch = g.Xi * g.Yi * g.Zi; v.out_batch = g.Xo * g.Yo * g.Zo;
+        v.ld1 = ext && ext->ld1 ? ext->ld1 : C1;
+        v.ld2 = ext && ext->ld2 ? ext->ld2 : C2;
+        v.init_batch = ext && ext->init && !ext->init_shared ? v.out_batch : 0;
         const int bl[3] = {xt ? 2 : 4, xt ? 16 : 8, 8};
         int64_t n = g.B;
         for (int k = 0; k < 3; ++k) {
@@ -414,8 +431,10 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
     auto launch = [&](const ConvViews& vs, bool xt, bool permuted) -> int {
         if (vs.start[3] == 0) return TDX_OK;
 #define M3_GO(NTV, XTV, PV)                                                                                             \
-    (zero_pad ? launch_view<NTV, XTV, true, PV>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1, a2)  \
-              : launch_view<NTV, XTV, false, PV>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1, a2))
+    (zero_pad ? launch_view<NTV, XTV, true, PV>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1, a2,  \
+                                                init)                                                                   \
+              : launch_view<NTV, XTV, false, PV>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1, a2, \
+                                                 init))
         if (NT == 2) return xt ? M3_GO(2, true, false) : (permuted ? M3_GO(2, false, true) : M3_GO(2, false, false));
         return xt ? M3_GO(1, true, false) : (permuted ? M3_GO(1, false, true) : M3_GO(1, false, false));
 #undef M3_GO

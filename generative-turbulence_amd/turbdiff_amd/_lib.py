@@ -32,6 +32,7 @@ SIGNATURES = {
     "tdx_conv3_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tdx_conv3_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_fwd_gn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tdx_conv3_fwd_partial": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_bwd_data_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "tdx_conv3_bwd_data": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "tdx_conv3_bwd_data_add": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

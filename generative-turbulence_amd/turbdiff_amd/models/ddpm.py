@@ -77,6 +77,8 @@ class SinusoidalPosEmb(nn.Module):
 import os as _os
 
 FUSE_BLOCKS = _os.environ.get("TDX_FUSE_BLOCKS", "1") != "0"
+# TDX_CACHE_COND_CONV=0: sampling recomputes the conditioning half of the first conv every step (A/B switch)
+CACHE_COND_CONV = _os.environ.get("TDX_CACHE_COND_CONV", "1") != "0"
 
 
 def _norm_groups(norm: nn.GroupNorm) -> int:
@@ -122,16 +124,23 @@ class ResnetBlock(nn.Module):
         self.conv = nn.Conv3d(dim_in, dim_out, 1) if dim_in != dim_out else nn.Identity()
         self.dim_out = dim_out
 
-    def forward(self, x, c, x2=None):
+    def fused(self, x2=None):
+        identity = isinstance(self.conv, nn.Identity)
+        return self.block1._fused_act and self.block2._fused_act and not (identity and x2 is not None) and FUSE_BLOCKS
+
+    def forward(self, x, c, x2=None, partial=None):
+        """partial = (n_lead, init): inference only -- block1's conv runs over the leading n_lead channels
+        of x and continues from `init`, the precomputed conv of the batch-shared remaining channels."""
         film = self.project_onto_scale_shift(c)  # (B, 2*dim_out): [scale | shift]
         scale, shift = film[:, : self.dim_out], film[:, self.dim_out :]
         identity = isinstance(self.conv, nn.Identity)
-        if self.block1._fused_act and self.block2._fused_act and not (identity and x2 is not None) and FUSE_BLOCKS:
+        if self.fused(x2):
             b1, b2 = self.block1, self.block2
             return ops.resnet_block(x, x2, scale, shift, (b1.conv.weight, b1.conv.bias), (b1.norm.weight, b1.norm.bias),
                                     (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias),
                                     None if identity else (self.conv.weight, self.conv.bias), _norm_groups(b1.norm),
-                                    b1.norm.eps)
+                                    b1.norm.eps, partial=partial)
+        assert partial is None
         h = self.block1(x, scale_shift=(scale, shift), x2=x2)
         if isinstance(self.conv, nn.Identity):
             skip = x if x2 is None else torch.cat((x, x2), dim=-1)
@@ -200,10 +209,10 @@ class UNet(nn.Module):
         self.downsampling_factor = downsampling_factor
         self.scale_factor = 1 / downsampling_factor
 
-    def forward(self, x, c):
+    def forward(self, x, c, first_partial=None):
         skips = []
-        for blk in self.downsampling_blocks:
-            x = blk(x, c)
+        for i, blk in enumerate(self.downsampling_blocks):
+            x = blk(x, c, partial=first_partial) if (i == 0 and first_partial is not None) else blk(x, c)
             skips.append(x)
             x = ops.resize(x, [max(int(s * self.scale_factor), 3) for s in x.shape[1:4]])
         x = self.center_block(x, c=c)
@@ -307,7 +316,16 @@ class DenoisingModel(nn.Module):
         if c_local is None:
             return None
         cl = ops.to_nvc(c_local[None].float(), self.compute_dtype)
-        return ops.conv1(cl, self.encode_c_local.weight, self.encode_c_local.bias)
+        enc = ops.conv1(cl, self.encode_c_local.weight, self.encode_c_local.bias)
+        # The conditioning half of the first U-Net conv does not depend on x or t either: without
+        # autograd it is computed here once and the per-step conv continues from it.
+        first = self.u_net.downsampling_blocks[0]
+        n_lead = self.encode_x.out_channels
+        if (CACHE_COND_CONV and not torch.is_grad_enabled() and isinstance(first, ResnetBlock) and first.fused()
+                and first.block1.conv.in_channels == n_lead + enc.shape[-1]
+                and ops.conv3_partial_supported(enc, first.block1.conv.weight, n_lead)):
+            enc.first_conv_partial = (n_lead, ops.conv3_shared_tail(enc, first.block1.conv.weight, n_lead))
+        return enc
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
         B = x.shape[0]
@@ -323,7 +341,8 @@ class DenoisingModel(nn.Module):
             e = encoded_local if encoded_local is not None else self.encode_local(C)
             if e is not None:
                 h = torch.cat((h, e.expand(B, -1, -1, -1, -1)), dim=-1)
-        h = self.u_net(h, c)
+        partial = getattr(encoded_local, "first_conv_partial", None) if not torch.is_grad_enabled() else None
+        h = self.u_net(h, c, first_partial=partial)
         h = self.decode[0](h, c)
         if ops.decode_supported(h, self.decode[1].weight):
             return ops.decode(h, self.decode[1].weight, self.decode[1].bias)

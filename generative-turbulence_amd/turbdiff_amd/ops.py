@@ -225,6 +225,40 @@ def _packed_conv3(weight: torch.Tensor, dtype: torch.dtype):
     return wf, wb
 
 
+def _packed_conv3_cin_slice(weight: torch.Tensor, lo: int, hi: int, dtype: torch.dtype):
+    """Forward operand of conv3 restricted to input channels [lo, hi) of `weight`, cached like
+    _packed_conv3 (keyed on the full parameter's version)."""
+    key = (id(weight), dtype, lo, hi)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
+    Cout, Cin = weight.shape[0], hi - lo
+    w = weight.detach()[:, lo:hi].contiguous()
+    wf = torch.empty(27 * Cin * Cout, dtype=dtype, device=w.device)
+    L.call("tdx_conv3_pack_weight", L.ptr(w), L.ptr(wf), None, Cin, Cout, L.dtype_code(dtype), L.stream())
+    _pack_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wf, None)
+    return wf
+
+
+def conv3_partial_supported(x, weight, n_lead: int) -> bool:
+    """tdx_conv3_fwd_partial: bf16 MFMA path on the leading n_lead input channels."""
+    return (x.dtype == torch.bfloat16 and n_lead % 16 == 0 and weight.shape[0] % 32 == 0 and x.shape[-1] % 8 == 0
+            and L.conv_impl() != L.CONV_DIRECT)
+
+
+def conv3_shared_tail(e, weight, n_lead: int):
+    """conv3 of the batch-shared channels [n_lead, Cin) of the first U-Net conv: e is (1, X, Y, Z, Cin - n_lead);
+    no bias (the per-sample conv adds it).  Result (1, X, Y, Z, Cout), the `init` of conv3_partial."""
+    Cin = weight.shape[1]
+    B, X, Y, Z, Ce = _grid(e)
+    assert B == 1 and Ce == Cin - n_lead
+    wf = _packed_conv3_cin_slice(weight, n_lead, Cin, e.dtype)
+    y = torch.empty((1, X, Y, Z, weight.shape[0]), dtype=e.dtype, device=e.device)
+    L.call("tdx_conv3_fwd", L.ptr(e.contiguous()), Ce, None, 0, L.ptr(wf), None, L.ptr(y), 1, X, Y, Z, weight.shape[0],
+           L.dtype_code(e.dtype), L.conv_impl(), L.stream())
+    return y
+
+
 class _Conv3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, gn_groups=0, gn_eps=1e-5):
@@ -557,7 +591,7 @@ class _ResnetBlock(torch.autograd.Function):
     cuts the number of autograd nodes per block from 6-7 to 1."""
 
     @staticmethod
-    def forward(ctx, x1, x2, scale, shift, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps):
+    def forward(ctx, x1, x2, scale, shift, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps, partial=None):
         B, X, Y, Z, C1 = _grid(x1)
         C2 = 0 if x2 is None else x2.shape[-1]
         Cin, Cout = C1 + C2, w1.shape[0]
@@ -580,7 +614,18 @@ class _ResnetBlock(torch.autograd.Function):
                    float(eps), L.ptr(gws), B, X, Y, Z, Cout, code, impl | WS_CLEAN, st, work=54.0 * (Ca + Cb) * Cout * B * V)
             return y, stats
 
-        h1, st1 = conv_gn(x1, C1, x2, C2, wf1, b1)
+        if partial is not None:
+            # inference only: conv1 over the leading n_lead channels of x1, continued from the
+            # precomputed convolution of the batch-shared tail (tdx_conv3_fwd_partial)
+            n_lead, init = partial
+            assert x2 is None and not torch.is_grad_enabled() and tuple(init.shape) == (1, X, Y, Z, Cout)
+            h1 = torch.empty((B, X, Y, Z, Cout), dtype=dt, device=dev)
+            st1 = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
+            L.call("tdx_conv3_fwd_partial", L.ptr(x1), n_lead, C1, L.ptr(_packed_conv3_cin_slice(w1, 0, n_lead, dt)),
+                   L.ptr(b1), L.ptr(init), 1, L.ptr(h1), L.ptr(st1), groups, float(eps), L.ptr(gws), B, X, Y, Z, Cout, code,
+                   impl | WS_CLEAN, st, work=54.0 * n_lead * Cout * B * V)
+        else:
+            h1, st1 = conv_gn(x1, C1, x2, C2, wf1, b1)
         a1 = torch.empty_like(h1)
         L.call("tdx_gn_apply", L.ptr(h1), L.ptr(st1), L.ptr(g1), L.ptr(be1), L.ptr(scale), L.ptr(shift), None, L.ptr(a1),
                B, V, Cout, groups, 1, code, st)
@@ -663,12 +708,13 @@ class _ResnetBlock(torch.autograd.Function):
                 L.call("tdx_conv1_bwd_weight", L.ptr(x2), C2, L.ptr(gy), Cout, dwt.data_ptr() + 4 * C1 * Cout, Cout, None,
                        B * V, code, st)
             dwr = dwt.t().reshape(wrs)
-        return (gx1, gx2, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None)
+        return (gx1, gx2, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None)
 
 
-def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, skip_wb, groups, eps=1e-5):
+def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, skip_wb, groups, eps=1e-5, partial=None):
     """Fused ResnetBlock; *_wb are (weight, bias) pairs, skip_wb is None for an identity skip.
-    Requires SiLU activations and bf16/f32 NDHWC inputs; scale/shift are (B, Cout)."""
+    Requires SiLU activations and bf16/f32 NDHWC inputs; scale/shift are (B, Cout).
+    partial = (n_lead, init): no-grad only, see conv3_shared_tail."""
     wr, br = skip_wb if skip_wb is not None else (None, None)
     return _ResnetBlock.apply(x1, x2, scale, shift, conv1_wb[0], conv1_wb[1], norm1_wb[0], norm1_wb[1], conv2_wb[0],
-                              conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps)
+                              conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps, partial)

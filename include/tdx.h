@@ -87,6 +87,19 @@ int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, const void*
                      float* stats, int G, float eps, void* gn_workspace, int B, int X, int Y, int Z, int Cout,
                      int dtype, int impl, void* stream);
 
+/* Forward over a channel SUBSET of a wider tensor, continued from a partial result:
+ *     y = conv3(x1[..., 0:C1], wf) + bias + init
+ * x1 rows are ld1 elements apart (ld1 >= C1: the first C1 channels of a [.., ld1] tensor are read);
+ * init is a bf16 tensor [B][X][Y][Z][Cout], or [X][Y][Z][Cout] shared by all samples when
+ * init_shared != 0 (NULL: zeros); it is added to the bf16-rounded conv result in the store loop.  Used for the first conv of the
+ * U-Net, whose input is cat(encode_x(x), encode_c_local(c).expand(B)) (ddpm.py:495-501): the
+ * conditioning half of that conv is the same for every sample of a batch and for every reverse step
+ * of a sampling run, so it is computed once and passed as `init`.  bf16 MFMA path only
+ * (C1 % 16 == 0, Cout % 32 == 0).  stats/G/eps/gn_workspace as in tdx_conv3_fwd_gn, or stats = NULL. */
+int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void* wf, const float* bias, const void* init,
+                          int init_shared, void* y, float* stats, int G, float eps, void* gn_workspace, int B, int X,
+                          int Y, int Z, int Cout, int dtype, int impl, void* stream);
+
 /* Data gradient of the above: dx[b,u,:] = sum over (v,tap) with clamp(v+tap) == u of
  * wf[tap][:, :] dy[b,v,:]  (adjoint of the replicate-padded conv, halo folded back onto
  * the boundary).  The result has C1 + C2 channels and is split into dx1 / dx2 (dx2 may be

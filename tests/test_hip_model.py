@@ -339,3 +339,31 @@ def test_local_attention_golden(golden):
     with torch.no_grad():
         y = la(g["local_attn/x"].to(dev()))
     assert rel_l2(y.cpu(), g["local_attn/y"]) < 1e-5
+
+
+def test_cached_conditioning_conv_matches_plain_forward():
+    """Sampling-time shortcut: encode_local() precomputes the conditioning half of the first U-Net conv
+    (tdx_conv3_fwd_partial continues from it).  Against the plain forward (same kernels, full conv) and
+    against the CPU oracle, bf16, B = 3, a grid with ragged bricks."""
+    from turbdiff_amd.models.ddpm import DenoisingModel
+
+    torch.manual_seed(0)
+    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=500, dim=32,
+                         u_net_levels=2, norm_type="group")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.randn(3, 4, 26, 12, 17, generator=torch.Generator().manual_seed(1))
+    c_local = torch.randn(4, 26, 12, 17, generator=torch.Generator().manual_seed(2))
+    t = torch.tensor([3, 250, 499])
+    net.to(dev()).set_compute_dtype(torch.bfloat16)
+    C = cond(c_local)
+    with torch.no_grad():
+        ref = O.denoiser(sd, x, t, c_local, timesteps=500)
+        plain = net(x.to(dev()), t.to(dev()), C)
+        enc = net.encode_local(C)
+        assert getattr(enc, "first_conv_partial", None) is not None and enc.first_conv_partial[0] == 32
+        cached = net(x.to(dev()), t.to(dev()), C, encoded_local=enc)
+    assert rel_l2(cached.cpu(), plain.cpu()) < 1e-2
+    assert rel_l2(plain.cpu(), ref) < 3e-2 and rel_l2(cached.cpu(), ref) < 3e-2
+    # with autograd on, the shortcut is not taken (the backward needs the full conv)
+    enc2 = net.encode_local(C)
+    assert getattr(enc2, "first_conv_partial", None) is None
