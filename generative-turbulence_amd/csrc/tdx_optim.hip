@@ -25,7 +25,8 @@ opt_sumsq_kernel(const TdxOptTensor* __restrict__ table, const int* __restrict__
         const int64_t o = chunk_off[c];
         const int64_t n = min((int64_t)OPT_CHUNK, t.numel - o);
         const float* gp = g + o;
-        const int64_t n4 = n >> 2;
+        // gradients may be views into a flat all-reduce bucket: only 4-B alignment is guaranteed
+        const int64_t n4 = (reinterpret_cast<uintptr_t>(gp) & 15) == 0 ? (n >> 2) : 0;
         for (int64_t i = threadIdx.x; i < n4; i += OPT_THREADS) {
             const float4 a = reinterpret_cast<const float4*>(gp)[i];
             s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
@@ -85,7 +86,9 @@ opt_radam_kernel(const TdxOptTensor* __restrict__ table, const int* __restrict__
     float* g = (float*)t.grad + o;
     float* m = (float*)t.exp_avg + o;
     float* v = (float*)t.exp_avg_sq + o;
-    const int64_t n4 = n >> 2;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                           reinterpret_cast<uintptr_t>(v)) & 15) == 0;  // gradients may be views into a flat bucket
+    const int64_t n4 = aligned ? (n >> 2) : 0;
     for (int64_t i = threadIdx.x; i < n4; i += OPT_THREADS) {
         float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
         float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];

@@ -58,6 +58,7 @@ class BucketedDataParallel:
         self._pending: list[int] = []
         self._flat: dict[int, torch.Tensor] = {}
         self._work: list = []
+        self._pads: dict = {}
         self._launched: set[int] = set()
         if self.world > 1 and broadcast:
             for p in self.params:
@@ -105,10 +106,25 @@ class BucketedDataParallel:
 
         return hook
 
+    def _pad(self, like: torch.Tensor, n: int) -> torch.Tensor:
+        key = (like.device, like.dtype, n)
+        z = self._pads.get(key)
+        if z is None:
+            z = self._pads[key] = torch.zeros(n, dtype=like.dtype, device=like.device)
+        return z
+
     def _launch(self, b: int):
         idxs = self._buckets[b]
         grads = [self.params[i].grad if self.params[i].grad is not None else torch.zeros_like(self.params[i]) for i in idxs]
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        # every slice starts on a 16-byte boundary (zero pads in between), so that the views handed back
+        # as .grad keep the alignment the fused optimiser's 16-B accesses want
+        parts = []
+        for g in grads:
+            parts.append(g.reshape(-1))
+            r = (-g.numel()) % 4
+            if r:
+                parts.append(self._pad(g, r))
+        flat = torch.cat(parts)
         flat.div_(self.world)
         self._flat[b] = flat
         self._work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -134,7 +150,7 @@ class BucketedDataParallel:
                 p = self.params[i]
                 n = p.numel()
                 p.grad = flat[off : off + n].view_as(p)
-                off += n
+                off += n + (-n) % 4
         self._work.clear()
         self._flat.clear()
         self._launched.clear()

@@ -588,3 +588,29 @@ def test_clip_radam_matches_torch(max_norm):
     for k in sa:
         assert float(sa[k]["step"]) == float(sb[k]["step"])
         assert torch.allclose(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-4, atol=1e-12)
+
+
+def test_clip_radam_with_bucket_view_gradients():
+    """Gradients that are views into a flat all-reduce bucket (parallel.BucketedDataParallel.finish) are
+    only 4-byte aligned: the fused optimiser must not assume 16-byte alignment."""
+    from turbdiff_amd.optim import ClipRAdam
+
+    torch.manual_seed(1)
+    d = torch.device("cuda:0")
+    shapes = [(5,), (7, 3), (1001,), (64, 3, 3)]
+    pa = [torch.randn(s, device=d).requires_grad_() for s in shapes]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    oa, ob = torch.optim.RAdam(pa, lr=1e-2), ClipRAdam(pb, lr=1e-2, max_norm=0.5)
+    for step in range(7):
+        flat = torch.randn(1 + sum(p.numel() for p in pa), device=d)
+        off = 1  # odd element offset -> 4-byte aligned views
+        for a, b in zip(pa, pb):
+            n = a.numel()
+            a.grad = flat[off : off + n].view_as(a).clone()
+            b.grad = flat[off : off + n].view_as(b)
+            off += n
+        torch.nn.utils.clip_grad_norm_(pa, 0.5)
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)

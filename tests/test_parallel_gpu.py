@@ -57,7 +57,13 @@ def _worker(rank, world, port, outdir):
         loss.backward()
         ddp.finish()
         grads.append({n: p.grad.detach().cpu().clone() for n, p in diff.model.named_parameters()})
-    torch.save((grads, ddp.bucket_layout()), f"{outdir}/rank{rank}.pt")
+    # the fused optimiser on the all-reduced gradients (views into the flat buckets)
+    from turbdiff_amd.optim import ClipRAdam
+
+    opt = ClipRAdam(diff.parameters(), lr=1e-3, max_norm=0.1)
+    opt.step()
+    params = {n: p.detach().cpu().clone() for n, p in diff.model.named_parameters()}
+    torch.save((grads, ddp.bucket_layout(), params, float(opt.last_grad_norm)), f"{outdir}/rank{rank}.pt")
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -88,3 +94,10 @@ def test_two_ranks_one_gpu_gradient_average(tmp_path):
                 else:
                     assert ((got - ref).norm() / ref.norm()).item() < 2e-3, (name, r, step)
         assert torch.equal(res[0][0][1][name], res[1][0][1][name]), f"{name}: ranks disagree"
+    # one clip + RAdam step on the global-batch gradients with the stock torch calls
+    ref_norm = torch.nn.utils.clip_grad_norm_(diff.parameters(), 0.1)
+    torch.optim.RAdam(diff.parameters(), lr=1e-3).step()
+    for r in range(2):
+        assert abs(res[r][3] - ref_norm.item()) < 2e-3 * ref_norm.item()
+        for name, p in diff.model.named_parameters():
+            assert torch.allclose(res[r][2][name], p.detach().cpu(), rtol=1e-4, atol=2e-6), (name, r)
