@@ -198,6 +198,51 @@ resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, Axis
     }
 }
 
+// General fallback of the adjoint (any resampling factor): one lane per (input voxel, 8 channels),
+// candidate outputs scanned over a superset range with the weights recomputed on the fly
+template <typename T>
+__global__ void __launch_bounds__(256)
+resize_bwd_generic_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, AxisMap ay, AxisMap az, int C, int64_t total) {
+    const int L = C >> 3;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lc = (int)(i % L);
+    int64_t v = i / L;
+    const int iz = (int)(v % az.in); v /= az.in;
+    const int iy = (int)(v % ay.in); v /= ay.in;
+    const int ix = (int)(v % ax.in);
+    const int b = (int)(v / ax.in);
+    int x0, x1, y0, y1, z0, z1;
+    axis_range(ax, ix, x0, x1);
+    axis_range(ay, iy, y0, y1);
+    axis_range(az, iz, z0, z1);
+    const T* gb = dy + ((int64_t)b * ax.out * ay.out * az.out) * C + lc * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int ox = x0; ox <= x1; ++ox) {
+        const float wx = axis_weight(ax, ox, ix);
+        if (wx == 0.f) continue;
+        for (int oy = y0; oy <= y1; ++oy) {
+            const float wxy = wx * axis_weight(ay, oy, iy);
+            if (wxy == 0.f) continue;
+            const T* row = gb + (((int64_t)ox * ay.out + oy) * az.out) * C;
+            for (int oz = z0; oz <= z1; ++oz) {
+                const float w = wxy * axis_weight(az, oz, iz);
+                if (w == 0.f) continue;
+                Vec8<T> t;
+                t.load(row + (int64_t)oz * C);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += w * t.v[j];
+            }
+        }
+    }
+    Vec8<T> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    o.store(dx + ((((int64_t)b * ax.in + ix) * ay.in + iy) * az.in + iz) * C + lc * 8);
+}
+
 static int resize_args_ok(int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C) {
     return B > 0 && Xi > 0 && Yi > 0 && Zi > 0 && Xo > 0 && Yo > 0 && Zo > 0 && C > 0;
 }
@@ -246,7 +291,12 @@ extern "C" int tdx_resize_bwd(const void* dy, void* dx, int B, int Xi, int Yi, i
     if (C % 8 || C / 8 > 256) return TDX_ESHAPE;
     const AxisMap ax = make_axis(Xi, Xo), ay = make_axis(Yi, Yo), az = make_axis(Zi, Zo);
     const int kx = axis_max_span(ax), ky = axis_max_span(ay), kz = axis_max_span(az);
-    if (kx > RS_KMAX || ky > RS_KMAX || kz > RS_KMAX) return TDX_ESHAPE;  // more than ~6x upsampling along an axis
+    if (kx > RS_KMAX || ky > RS_KMAX || kz > RS_KMAX) {  // more than ~6x upsampling along an axis: general kernel
+        const int64_t total = (int64_t)B * Xi * Yi * Zi * (C / 8);
+        TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_bwd_generic_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0,
+                                                      as_stream(stream), (const T*)dy, (T*)dx, ax, ay, az, C, total));
+        return tdx_launch_status();
+    }
     const TileGrid tg = make_tiles(Xi, Yi, Zi, C);
     const dim3 grid((unsigned)((int64_t)B * tg.nx * tg.ny * tg.nz));
 #define RS_BWD(KV)                                                                                                     \

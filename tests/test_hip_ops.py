@@ -614,3 +614,23 @@ def test_clip_radam_with_bucket_view_gradients():
         ob.step()
         for a, b in zip(pa, pb):
             assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("C,src,dst", [(24, (5, 4, 3), (9, 9, 17)), (8, (3, 3, 3), (20, 7, 30)), (64, (13, 9, 10), (6, 4, 5)),
+                                       (512, (6, 4, 3), (3, 3, 3))])
+def test_resize_odd_channel_counts_and_large_factors(C, src, dst):
+    """tdx_resize_fwd/bwd on the tile mappings the U-Net grids do not reach: C / 8 not a power of two,
+    up-sampling by up to 10x along an axis (up to 12 contributing outputs per input in the adjoint),
+    wide channels (1-voxel passes), down-sampling."""
+    from turbdiff_amd import ops
+
+    torch.manual_seed(0)
+    x = torch.randn(2, *src, C, device="cuda:0").requires_grad_()
+    y = ops.resize(x, list(dst))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x.detach().permute(0, 4, 1, 2, 3).cpu().requires_grad_()
+    yr = F.interpolate(xr, size=dst, mode="trilinear", align_corners=True)
+    yr.backward(gy.permute(0, 4, 1, 2, 3).cpu())
+    assert rel_l2(y.detach().permute(0, 4, 1, 2, 3).cpu(), yr.detach()) < 1e-5
+    assert rel_l2(x.grad.permute(0, 4, 1, 2, 3).cpu(), xr.grad) < 1e-5
