@@ -15,7 +15,9 @@
 // over the brick's 16 K-steps of 16 voxels, so a dy fragment is read once per K-step and
 // reused by the wave's 7 taps.  Global loads for the next brick are issued before the MFMA
 // phase of the current one and written to LDS after it.  Partial tiles are merged with f32
-// atomics (128-B contiguous per half-wave) into dwp[27][Cin][Cout].
+// atomics (128-B contiguous per half-wave) into dwp[27][Cin][Cout].  The bias gradient is summed
+// from the dy staging registers (a thread always stages the same 8 channels).  The brick's short
+// axis is put on the grid axis that leaves the fewest bricks (WgradView: local axes).
 #include "tdx_common.h"
 #include "tdx_conv3.h"
 #include <stdlib.h>
@@ -31,7 +33,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 #define W3_BZ 8
 #define W3_HY 10
 #define W3_HZ 10
-#define W3_NVOX (W3_BX * W3_BY * W3_BZ)              // 512 voxels per brick
+#define W3_NVOX (W3_BX * W3_BY * W3_BZ)              // 256 voxels per brick
 #define W3_NSTEPS (W3_NVOX / 16)                     // K-steps of 16 voxels
 #define W3_NHALO ((W3_BX + 2) * W3_HY * W3_HZ)        // 1000
 #define W3_XBYTES (W3_NHALO * 64)   // 64000
