@@ -327,6 +327,18 @@ def conv3_gn_stats(x1, weight, bias, groups, eps=1e-5, x2=None):
 # --------------------------------------------------------------------------- conv 1x1x1
 
 
+def _conv1_wt(weight: torch.Tensor) -> torch.Tensor:
+    """[Cin][Cout] f32 copy of a 1x1 conv weight (the layout tdx_conv1_fwd reads), cached until the
+    parameter changes (Tensor._version) instead of being re-transposed on every call."""
+    key = (id(weight), "wt")
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
+        return hit[3]
+    wt = weight.detach().reshape(weight.shape[0], -1).t().contiguous()
+    _pack_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wt, None)
+    return wt
+
+
 class _Conv1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, add):
@@ -339,7 +351,7 @@ class _Conv1(torch.autograd.Function):
         x2 = None if x2 is None else x2.contiguous()
         add = None if add is None else add.contiguous()
         rows = x1.numel() // C1
-        wt = w2.t().contiguous()  # [Cin][Cout]
+        wt = _conv1_wt(weight)  # [Cin][Cout]
         y = torch.empty(x1.shape[:-1] + (Cout,), dtype=x1.dtype, device=x1.device)
         L.call("tdx_conv1_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wt), Cout, L.ptr(bias), L.ptr(add), L.ptr(y), rows,
                Cout, L.dtype_code(x1.dtype), L.stream())
@@ -637,7 +649,7 @@ class _ResnetBlock(torch.autograd.Function):
         else:
             wr2 = wr.detach().reshape(Cout, Cin).contiguous()
             res = torch.empty_like(h1)
-            L.call("tdx_conv1_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wr2.t().contiguous()), Cout, L.ptr(br), None,
+            L.call("tdx_conv1_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(_conv1_wt(wr)), Cout, L.ptr(br), None,
                    L.ptr(res), B * V, Cout, code, st)
         y = torch.empty_like(h1)
         L.call("tdx_gn_apply", L.ptr(h2), L.ptr(st2), L.ptr(g2), L.ptr(be2), None, None, L.ptr(res), L.ptr(y), B, V, Cout,
