@@ -33,8 +33,12 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
                       const void* a2 = nullptr, const Conv3Ext* ext = nullptr);
 
 bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout);
+// slabs / max_slabs: optional region of max_slabs x 27*Cin*Cout floats; when the launch uses at most
+// max_slabs K-splits every split stores its partial tiles there (no atomics) and *nslab_out tells the
+// caller how many slabs to add up (0: the result was accumulated into dwp)
 int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
-                            int B, int X, int Y, int Z, int Cout, hipStream_t st);
+                            int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs = nullptr,
+                            int max_slabs = 0, int* nslab_out = nullptr);
 
 int conv3_direct_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                         const Conv3Geom& g, int Cout, int dtype, bool zero_pad, hipStream_t st);

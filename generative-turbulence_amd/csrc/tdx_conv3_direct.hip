@@ -75,7 +75,7 @@ extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin
 // all-zero, see TDX_WS_CLEAN), and block (0, *) also moves the bias-gradient accumulator.
 __global__ void __launch_bounds__(256)
 conv3_unpack_wgrad_kernel(float* __restrict__ dwp, float* __restrict__ dw, float* __restrict__ dbw,
-                          float* __restrict__ dbias, int Cin, int Cout) {
+                          float* __restrict__ dbias, int Cin, int Cout, const float* __restrict__ slabs, int nslab) {
     __shared__ float t[16][16 * 27 + 1];  // [co][ci*27 + tap]
     const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
     const int tid = threadIdx.x;
@@ -84,9 +84,14 @@ conv3_unpack_wgrad_kernel(float* __restrict__ dwp, float* __restrict__ dw, float
     for (int tap = 0; tap < 27; ++tap) {
         float v = 0.f;
         if (ok) {
-            float* src = dwp + ((int64_t)tap * Cin + ci0 + ci) * Cout + co0 + co;
-            v = *src;
-            *src = 0.f;
+            const int64_t idx = ((int64_t)tap * Cin + ci0 + ci) * Cout + co0 + co;
+            if (nslab > 0) {  // the K-splits stored their partial tiles into slabs: add them up
+                const int64_t stride = (int64_t)27 * Cin * Cout;
+                for (int k = 0; k < nslab; ++k) v += slabs[k * stride + idx];
+            } else {
+                v = dwp[idx];
+                dwp[idx] = 0.f;
+            }
         }
         t[co][ci * 27 + tap] = v;
     }
@@ -539,9 +544,12 @@ extern "C" int tdx_conv3_bwd_data_add(const void* dy, const void* wb, void* dx1,
     return conv3_bwd_data_impl(dy, wb, dx1, C1, dx2, C2, add1, add2, B, X, Y, Z, Cout, dtype, impl, workspace, stream);
 }
 
+#define W3_MAX_SLABS 8
 extern "C" size_t tdx_conv3_bwd_weight_workspace_bytes(int Cin, int Cout, int impl) {
     (void)impl;
-    return (size_t)27 * Cin * Cout * sizeof(float) + (size_t)Cout * sizeof(float) + 256;  // dw + dbias accumulators
+    // dw + dbias accumulators (the part covered by TDX_WS_CLEAN), then W3_MAX_SLABS partial-sum slabs for
+    // launches with few K-splits (scratch, never needs zeroing)
+    return (size_t)(1 + W3_MAX_SLABS) * 27 * Cin * Cout * sizeof(float) + (size_t)Cout * sizeof(float) + 512;
 }
 
 extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dw,
@@ -562,10 +570,15 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
     }
     const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && dtype == TDX_BF16 &&
                                                      conv3_wgrad_mfma_supported(C1, C2, Cout));
+    int nslab = 0;
+    const float* slab_ptr = nullptr;
     if (use_mfma) {
         if (dtype != TDX_BF16) return TDX_EDTYPE;
         if (!conv3_wgrad_mfma_supported(C1, C2, Cout)) return TDX_ESHAPE;
-        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st);
+        float* slabs = dbw + ((Cout + 63) / 64) * 64;
+        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs,
+                                         W3_MAX_SLABS, &nslab);
+        slab_ptr = slabs;
         if (rc != TDX_OK) return rc;
     } else {
         const int64_t nvox = (int64_t)B * X * Y * Z;
@@ -576,6 +589,6 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
                                                       dbias ? dbw : nullptr, B, X, Y, Z, Cout, nci));
     }
     hipLaunchKernelGGL(conv3_unpack_wgrad_kernel, dim3(ceil_div(Cin, 16), ceil_div(Cout, 16)), dim3(256), 0, st, dwp, dw,
-                       dbw, dbias, Cin, Cout);
+                       dbw, dbias, Cin, Cout, slab_ptr, nslab);
     return tdx_launch_status();
 }

@@ -68,7 +68,7 @@ template <int NT>
 __global__ void __launch_bounds__(256, NT == 2 ? 1 : 2)
 conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                         const bf16* __restrict__ dy, float* __restrict__ dwp, float* __restrict__ dbias, WgradView gv,
-                        int Cout, int nsplit, int n_ci_tiles) {
+                        int Cout, int nsplit, int n_ci_tiles, int64_t slab_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;
     unsigned char* sG = smem + W3_XBYTES;
@@ -264,7 +264,11 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int ci = ci0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    atomicAdd(&dwp[((int64_t)tap * Cin + ci) * Cout + co0 + nt * 32 + r], acc[t][nt][i]);
+                    float* dst = &dwp[((int64_t)tap * Cin + ci) * Cout + co0 + nt * 32 + r];
+                    // few splits (deep layers): every split owns a slab and stores plainly, the unpack
+                    // kernel adds the slabs; many splits (fine levels): f32 atomics into one table
+                    if (slab_stride) dst[(int64_t)split * slab_stride] = acc[t][nt][i];
+                    else atomicAdd(dst, acc[t][nt][i]);
                 }
         }
     }
@@ -285,7 +289,8 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
 }
 
 int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
-                            int B, int X, int Y, int Z, int Cout, hipStream_t st) {
+                            int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs,
+                            int* nslab_out) {
     const int Cin = C1 + C2;
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     // local axes: brick 4 x 8 x 8; the short axis goes where it leaves the fewest bricks
@@ -316,13 +321,19 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
     if (nsplit < 1) nsplit = 1;
     const size_t lds = W3_XBYTES + (size_t)NT * W3_GPLANE;
     dim3 grid((unsigned)(ntiles * nsplit));
+    // slab mode: every (tile, split) pair stores its whole partial tile, so the slabs need no zeroing
+    static const int slab_cap = getenv("TDX_WGRAD_SLABS") ? atoi(getenv("TDX_WGRAD_SLABS")) : 1 << 30;  // A/B switch
+    const bool use_slabs = slabs != nullptr && nsplit <= max_slabs && nsplit <= slab_cap;
+    const int64_t slab_stride = use_slabs ? (int64_t)27 * Cin * Cout : 0;
+    float* out = use_slabs ? slabs : dwp;
+    if (nslab_out) *nslab_out = use_slabs ? nsplit : 0;
 #define W3_LAUNCH(NTV)                                                                                               \
     do {                                                                                                             \
         auto kern = conv3_wgrad_mfma_kernel<NTV>;                                                                    \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2, (const bf16*)dy, \
-                           dwp, dbias, g, Cout, nsplit, n_ci);                               \
+                           out, dbias, g, Cout, nsplit, n_ci, slab_stride);                               \
     } while (0)
     if (NT == 2) W3_LAUNCH(2); else W3_LAUNCH(1);
 #undef W3_LAUNCH

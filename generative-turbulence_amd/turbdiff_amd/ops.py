@@ -34,12 +34,12 @@ _CLEAN = {}
 WS_CLEAN = 0 if os.environ.get("TDX_WS_CLEAN", "1") == "0" else L.WS_CLEAN
 
 
-def _clean_ws(nbytes: int, device) -> torch.Tensor:
+def _clean_ws(nbytes: int, device, tag=None) -> torch.Tensor:
     """Persistent all-zero workspace for the calls that take TDX_WS_CLEAN (include/tdx.h): they find
     it zero and leave it zero, so a training step launches no memsets for accumulator buffers."""
     if not WS_CLEAN:
         return _ws(nbytes, device)
-    key = (str(device), int(nbytes))
+    key = (str(device), int(nbytes), tag)  # tag: buffers are shared only by calls with the same internal layout
     buf = _CLEAN.get(key)
     if buf is None:
         buf = _CLEAN[key] = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=device)
@@ -307,7 +307,7 @@ class _Conv3(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gw = torch.empty(ctx.wshape, dtype=torch.float32, device=dev)
             gb = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
-            ws = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cin, Cout, impl), dev)
+            ws = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cin, Cout, impl), dev, ("w3", Cin, Cout))
             L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z,
                    Cout, code, impl | WS_CLEAN, L.ptr(ws), st, work=54.0 * Cin * Cout * B * X * Y * Z)
         return gx1, gx2, gw, gb, None, None
@@ -680,9 +680,11 @@ class _ResnetBlock(torch.autograd.Function):
         L.call("tdx_gn_bwd", L.ptr(h2), L.ptr(gy), L.ptr(st2), L.ptr(g2), L.ptr(be2), None, None, L.ptr(dh2), L.ptr(dg2),
                L.ptr(dbe2), None, None, B, V, Cout, groups, 1, code, L.ptr(gws), st)
         dw2, db2 = f32(*w2s), (f32(Cout) if hb2 else None)
-        wws = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", max(Cin, Cout), Cout, impl), dev)
+        # one workspace per (Cin, Cout): the accumulator / slab layout inside depends on both
+        wws2 = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cout, Cout, impl), dev, ("w3", Cout, Cout))
+        wws1 = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cin, Cout, impl), dev, ("w3", Cin, Cout))
         L.call("tdx_conv3_bwd_weight", L.ptr(a1), Cout, None, 0, L.ptr(dh2), L.ptr(dw2), L.ptr(db2), B, X, Y, Z, Cout, code,
-               impl | WS_CLEAN, L.ptr(wws), st, work=flops(Cout))
+               impl | WS_CLEAN, L.ptr(wws2), st, work=flops(Cout))
         da1 = torch.empty_like(a1)
         dws = _ws(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, max(Cin, Cout), code, impl), dev)
         L.call("tdx_conv3_bwd_data", L.ptr(dh2), L.ptr(wb2), L.ptr(da1), Cout, None, 0, 0, B, X, Y, Z, Cout, code, impl,
@@ -695,7 +697,7 @@ class _ResnetBlock(torch.autograd.Function):
         del da1
         dw1, db1 = f32(*w1s), (f32(Cout) if hb1 else None)
         L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
-               impl | WS_CLEAN, L.ptr(wws), st, work=flops(Cin))
+               impl | WS_CLEAN, L.ptr(wws1), st, work=flops(Cin))
         # ---- input gradient = conv1 data gradient + residual-path gradient
         gx1 = torch.empty_like(x1)
         gx2 = None if x2 is None else torch.empty_like(x2)

@@ -118,8 +118,9 @@ int tdx_conv3_bwd_data_add(const void* dy, const void* wb, void* dx1, int C1, vo
 
 /* Weight + bias gradient.  dw is written in the reference's parameter layout
  * (Cout, Cin, 3, 3, 3) f32, dbias (Cout) f32 (may be NULL).  Overwrites.
- * workspace: tdx_conv3_bwd_weight_workspace_bytes(); zeroed by the call unless impl has
- * TDX_WS_CLEAN, and left all-zero on return. */
+ * workspace: tdx_conv3_bwd_weight_workspace_bytes(Cin, Cout) = accumulators (27*Cin*Cout + Cout floats:
+ * zeroed by the call unless impl has TDX_WS_CLEAN, and left all-zero on return) followed by scratch
+ * slabs for launches with few K-splits (never needs zeroing). */
 size_t tdx_conv3_bwd_weight_workspace_bytes(int Cin, int Cout, int impl);
 int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dw, float* dbias,
                          int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* workspace, void* stream);
