@@ -23,6 +23,8 @@ The fixtures pin:
                      noise_bcs in {True, False} and a start_from=5 variant
   train_cfg1.npz     3 optimiser steps (clip 0.1 -> RAdam 1e-4 -> exp LambdaLR), losses and
                      final parameters
+  options.npz        constructor options off the shipped path: norm_type instance / layer, GELU, l1 loss,
+                     clip_denoised, learned variances with and without the ELBO term
   state_dict_manifest.txt   key / shape list of DiffusionTraining's state_dict
 """
 
@@ -411,6 +413,74 @@ def main():
     for k, v in model.model.state_dict().items():
         tx[f"final_sd/{k}"] = to_np(v)
     np.savez_compressed(OUT / "train_cfg1.npz", **tx)
+
+    # ------------------------------------------------------------------ non-default options
+    # Variants of the constructor options the shipped configuration does not use (ddpm.py:399-431,
+    # 621-633): other norm types, another activation, l1 loss, clipping, learned variances + ELBO term.
+    # Same architecture seed as cfg1, sampling-size grid; outputs: eps_hat, loss, per-parameter gradient
+    # norms (+ the small gradients in full), and the sampling result where the option affects sampling.
+    def make_variant(dm_kw=None, gd_kw=None):
+        dm_args = dict(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=10, dim=8,
+                       u_net_levels=2, norm_type="group")
+        dm_args.update(dm_kw or {})
+        gd_args = dict(timesteps=10, beta_schedule="log-snr-linear", loss_type="l2", noise_bcs=True)
+        gd_args.update(gd_kw or {})
+        torch.manual_seed(0)
+        dm = R.DenoisingModel(**dm_args)
+        gg = torch.Generator().manual_seed(77)
+        with torch.no_grad():
+            for n, p in dm.named_parameters():
+                if ".norm." in n or n.endswith("fn.norm.weight") or n.endswith("fn.norm.bias"):
+                    p.add_(0.1 * torch.randn(p.shape, generator=gg))
+        return R.GaussianDiffusion(dm, **gd_args)
+
+    ox = {"x": to_np(xs), "c_local": to_np(Cs[CT]), "cell_idx": to_np(cs)}
+    tv = torch.tensor([6, 0])  # t = 0 exercises the ELBO's log-likelihood branch
+    ox["t"] = to_np(tv)
+    variants = {
+        "instance": (dict(norm_type="instance"), {}),
+        "layer": (dict(norm_type="layer"), {}),
+        "gelu": (dict(actfn=nn.GELU), {}),
+        "l1": ({}, dict(loss_type="l1")),
+        "clip": ({}, dict(clip_denoised=True)),
+        "learned_var": (dict(out_features=8), dict(learned_variances=True, elbo_weight=0.001)),
+        "learned_var_noelbo": (dict(out_features=8), dict(learned_variances=True)),
+    }
+    base_sd = make_model(noise_bcs=True).model.state_dict()
+    for tag, (dm_kw, gd_kw) in variants.items():
+        model = make_variant(dm_kw, gd_kw)
+        # the weights equal model_cfg1.npz's `sd/` except where the option changes a shape: store those only
+        if tag != "learned_var_noelbo":  # (that one has learned_var's weights)
+            for k, v in model.model.state_dict().items():
+                if k not in base_sd or base_sd[k].shape != v.shape or not torch.equal(base_sd[k], v):
+                    ox[f"{tag}/sd/{k}"] = to_np(v).astype(np.float32)
+        with torch.no_grad():
+            ox[f"{tag}/eps_hat"] = to_np(model.model(xs, tv, Cs))
+        noises.clear()
+        torch.randn_like = rec_randn_like
+        try:
+            loss, _ = model.p_losses(xs, tv, Cs, SimpleNamespace(cell_idx=cs), None)
+        finally:
+            torch.randn_like = orig_randn_like
+        loss.backward()
+        ox[f"{tag}/noise"] = to_np(noises[0])
+        ox[f"{tag}/loss"] = to_np(loss)
+        for k, p in model.model.named_parameters():
+            ox[f"{tag}/gnorm/{k}"] = to_np(p.grad.norm())
+            if p.numel() <= 512:
+                ox[f"{tag}/grad/{k}"] = to_np(p.grad)
+        if tag == "clip":  # (the reference's own p_sample_loop raises with learned variances: broadcast_right, utils.py:11)
+            noises.clear()
+            torch.randn_like = rec_randn_like
+            try:
+                out = model.p_sample_loop(xs, Cs, cs, pbar=False)
+            finally:
+                torch.randn_like = orig_randn_like
+            ox[f"{tag}/sample"] = to_np(out)
+            ox[f"{tag}/n_noise"] = np.array(len(noises))
+            for i, n in enumerate(noises):
+                ox[f"{tag}/sample_noise/{i}"] = to_np(n)
+    np.savez_compressed(OUT / "options.npz", **ox)
 
     # ------------------------------------------------------------------ state_dict manifest
     from turbdiff.models.diffusion import DiffusionTraining

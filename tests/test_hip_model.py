@@ -367,3 +367,54 @@ def test_cached_conditioning_conv_matches_plain_forward():
     # with autograd on, the shortcut is not taken (the backward needs the full conv)
     enc2 = net.encode_local(C)
     assert getattr(enc2, "first_conv_partial", None) is None
+
+
+OPTION_VARIANTS = {
+    "instance": (dict(norm_type="instance"), {}),
+    "layer": (dict(norm_type="layer"), {}),
+    "gelu": (dict(actfn=torch.nn.GELU), {}),
+    "l1": ({}, dict(loss_type="l1")),
+    "clip": ({}, dict(clip_denoised=True)),
+    "learned_var": (dict(out_features=8), dict(learned_variances=True, elbo_weight=0.001)),
+    "learned_var_noelbo": (dict(out_features=8), dict(learned_variances=True)),
+}
+
+
+@pytest.mark.parametrize("tag", list(OPTION_VARIANTS))
+def test_constructor_options_golden(golden, tag):
+    """Constructor options off the shipped configuration (reference ddpm.py:399-431, 621-633) against vectors
+    of the unmodified reference: eps_hat, loss, every parameter's gradient norm (small gradients in full) and,
+    for clip_denoised, the sampling loop.  fp32 mode."""
+    from turbdiff_amd.models.ddpm import DenoisingModel, GaussianDiffusion
+
+    g = golden("options")
+    dm_kw, gd_kw = OPTION_VARIANTS[tag]
+    dm_args = dict(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=10, dim=8, u_net_levels=2,
+                   norm_type="group")
+    dm_args.update(dm_kw)
+    gd_args = dict(timesteps=10, beta_schedule="log-snr-linear", loss_type="l2", noise_bcs=True)
+    gd_args.update(gd_kw)
+    net = DenoisingModel(**dm_args)
+    sd = dict(golden("model_cfg1").sub("sd/"))
+    sd.update(g.sub(f"{'learned_var' if tag == 'learned_var_noelbo' else tag}/sd/"))
+    net.load_state_dict(sd, strict=True)
+    diff = GaussianDiffusion(net, **gd_args).to(dev())
+    x, C, t = g["x"].to(dev()), cond(g["c_local"]), g["t"].to(dev())
+    md = SimpleNamespace(cell_idx=g["cell_idx"].to(dev()))
+    with torch.no_grad():
+        eps = diff.model(x, t, C)
+    assert rel_l2(eps.cpu(), g[f"{tag}/eps_hat"]) < 1e-4
+    loss, _ = diff.p_losses(x, t, C, md, None, noise=g[f"{tag}/noise"].to(dev()))
+    loss.backward()
+    assert abs(loss.item() - g[f"{tag}/loss"].item()) < 1e-4 * abs(g[f"{tag}/loss"].item())
+    for name, p in diff.model.named_parameters():
+        ref = g[f"{tag}/gnorm/{name}"].item()
+        got = p.grad.norm().item()
+        assert abs(got - ref) < 2e-3 * ref + 2e-6, (name, got, ref)
+        if f"{tag}/grad/{name}" in g.z.files:
+            assert_grad_close(name, p.grad.cpu(), g[f"{tag}/grad/{name}"], 2e-3)
+    if tag == "clip":
+        it = iter([g[f"{tag}/sample_noise/{i}"].to(dev()) for i in range(int(g[f"{tag}/n_noise"]))])
+        out = diff.p_sample_loop(x, C, md.cell_idx, noise_fn=lambda like: next(it))
+        assert next(it, None) is None
+        assert rel_l2(out.cpu(), g[f"{tag}/sample"]) < 1e-4

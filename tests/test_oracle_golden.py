@@ -180,3 +180,13 @@ def test_p_sample_mean_logvar(golden):
         _, mean = O.model_mean(buf, g["x_bcs"], t, eps, g["cell_idx"], True)
     assert rel_l2(mean, g["p_sample_t6/mean"]) < TOL
     assert torch.equal(buf["log_betas"][t], g["p_sample_t6/log_var"])
+
+
+@pytest.mark.parametrize("tag,norm", [("instance", "instance"), ("layer", "layer")])
+def test_oracle_norm_type_variants(golden, tag, norm):
+    """The oracle's norm_type switch (GroupNorm with G = C / G = 1, ddpm.py:424-431) against reference vectors."""
+    g = golden("options")
+    sd = dict(golden("model_cfg1").sub("sd/"))
+    with torch.no_grad():
+        eps = O.denoiser(sd, g["x"], g["t"], g["c_local"], timesteps=10, norm_type=norm)
+    assert rel_l2(eps, g[f"{tag}/eps_hat"]) < 1e-5
