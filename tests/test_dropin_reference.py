@@ -67,6 +67,16 @@ for shape in [(1, 2, 5, 4, 6), (1, 2, 4, 4, 4)]:
     assert tuple(qa) == tuple(qb) and torch.equal(pa, pb) and torch.equal(R.unpad(pa, qa), M.unpad(pb, qb))
 x, y = torch.randn(2, 3, 4), torch.randn(1, 5, 1)
 assert torch.equal(R.expand_as(x, y, 1), M.expand_as(x, y, 1))
+# GeometryEmbedding (ddpm.py:375-395; off in the shipped config, kept on stock torch ops)
+ga, gb = R.GeometryEmbedding(4, 8, torch.nn.SiLU), M.GeometryEmbedding(4, 8, torch.nn.SiLU)
+gb.load_state_dict(ga.state_dict(), strict=True)
+cl = torch.randn(4, 55, 46, 47)
+assert torch.allclose(ga(cl), gb(cl), atol=1e-6)
+# SinusoidalPosEmb, normal_kl, normal_log_lk
+assert torch.allclose(R.SinusoidalPosEmb(16)(torch.arange(5.0)), M.SinusoidalPosEmb(16)(torch.arange(5.0)), atol=1e-6)
+a, b, c, d = (torch.randn(3, 7) for _ in range(4))
+assert torch.allclose(R.normal_kl(a, b, c, d), M.normal_kl(a, b, c, d), atol=1e-6)
+assert torch.allclose(R.normal_log_lk(a, b, c), M.normal_log_lk(a, b, c), atol=1e-6)
 print("SURFACE_OK")
 '''
 
