@@ -84,7 +84,9 @@ __device__ __forceinline__ int out_addr(int v, int c) {
     return v * 64 + ((c ^ ((v >> 1) & 3)) << 4);
 }
 
-template <int NT, bool XT, bool ZERO_PAD, bool PERM>
+// EXT: strided inputs (ConvView::ld1/ld2) and the `init` tensor of tdx_conv3_fwd_partial; a separate
+// instantiation so that the hot kernels carry none of it (it cost the 32-channel layers 7-19 %)
+template <int NT, bool XT, bool ZERO_PAD, bool PERM, bool EXT>
 __global__ void __launch_bounds__(256, 2)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                   const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, ConvViews gs,
@@ -162,7 +164,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
         const int k0 = c * M3_KC;
         const bf16* xs;
         int Cs, kk;
-        if (k0 < C1) { xs = x1; Cs = g.ld1; kk = k0; } else { xs = x2; Cs = g.ld2; kk = k0 - C1; }
+        if (k0 < C1) { xs = x1; Cs = EXT ? g.ld1 : C1; kk = k0; } else { xs = x2; Cs = EXT ? g.ld2 : C2; kk = k0 - C1; }
         xs += batch_vox * Cs + kk;
 #pragma unroll
         for (int i = 0; i < A_PER_THREAD; ++i) {
@@ -318,7 +320,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             }
             if (!direct) {
                 const int64_t ov = (int64_t)b * g.out_batch + c0 * g.so[0] + c1 * g.so[1] + c2 * g.so[2];
-                if (init != nullptr) {
+                if (EXT && init != nullptr) {
                     // continue from a precomputed partial convolution ([B or 1][voxels][Cout] bf16), added in
                     // the coalesced store loop; the statistics below see the sum
                     const int64_t iv = (int64_t)b * g.init_batch + c0 * g.so[0] + c1 * g.so[1] + c2 * g.so[2];
@@ -364,14 +366,14 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     }
 }
 
-template <int NT, bool XT, bool ZP, bool PERM>
+template <int NT, bool XT, bool ZP, bool PERM, bool EXT = false>
 static int launch_view(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                        const ConvViews& v, int Cout, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
                        const void* a1, const void* a2, const void* init) {
     constexpr int BN = NT * 32;
     constexpr int HXv = (XT ? 2 : 4) + 2, HYv = (XT ? 16 : 8) + 2, SZv = XT ? 10 : 12;
     const size_t lds = (size_t)2 * (HXv * HYv * SZv * 16 + 64) + (size_t)27 * BN * 32 + 128;
-    auto kern = conv3_mfma_kernel<NT, XT, ZP, PERM>;
+    auto kern = conv3_mfma_kernel<NT, XT, ZP, PERM, EXT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -405,7 +407,7 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
     bool thin[3];
     for (int a = 0; a < 3; ++a) {
         const int rem = Eo[a] % bdim[a];
-        thin[a] = !no_thin && rem >= 1 && rem <= 2 && Eo[a] > bdim[a] && big;
+        thin[a] = !no_thin && rem >= 1 && rem <= 2 && Eo[a] > bdim[a] && big && ext == nullptr;
         main_end[a] = thin[a] ? Eo[a] - rem : Eo[a];
     }
     // view of region [lo, hi) (global output coordinates) with local axis k = global axis perm[k];
@@ -432,9 +434,17 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
         if (vs.start[3] == 0) return TDX_OK;
 #define M3_GO(NTV, XTV, PV)                                                                                             \
     (zero_pad ? launch_view<NTV, XTV, true, PV>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1, a2,  \
-                                                init)                                                                   \
+                                                nullptr)                                                                \
               : launch_view<NTV, XTV, false, PV>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1, a2, \
-                                                 init))
+                                                 nullptr))
+        if (ext != nullptr) {  // strided input / init tensor: forward main bricks only
+            if (zero_pad || xt || permuted) return TDX_ESHAPE;
+            if (NT == 2)
+                return launch_view<2, false, false, false, true>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2,
+                                                                 a1, a2, init);
+            return launch_view<1, false, false, false, true>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1,
+                                                             a2, init);
+        }
         if (NT == 2) return xt ? M3_GO(2, true, false) : (permuted ? M3_GO(2, false, true) : M3_GO(2, false, false));
         return xt ? M3_GO(1, true, false) : (permuted ? M3_GO(1, false, true) : M3_GO(1, false, false));
 #undef M3_GO
@@ -444,7 +454,7 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
     // bricks (e.g. 48 x 16 x 12: 36 bricks with the 4 along z instead of 48) -- ragged grids only
     static const bool no_perm = getenv("TDX_CONV3_PERM") && atoi(getenv("TDX_CONV3_PERM")) == 0;  // A/B switch
     int best[3] = {0, 1, 2};
-    if (!no_perm) {
+    if (!no_perm && ext == nullptr) {
         const int cand[3][3] = {{0, 1, 2}, {1, 0, 2}, {2, 0, 1}};
         int64_t best_n = -1;
         for (int c = 0; c < 3; ++c) {
