@@ -330,42 +330,43 @@ gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const fl
     }
 }
 
-// sums the per-block partials: acc[(b*C + c)*2 + q] (f64).  One wave per (b, c) pair of sums.
-__global__ void __launch_bounds__(64)
-gn_bwd_sum_partials(const float* __restrict__ partial, double* __restrict__ acc, int nblk, int C) {
-    const int bc = blockIdx.x;  // b * C + c
-    const int b = bc / C, c = bc - b * C;
-    double p = 0.0, q = 0.0;
-    for (int k = threadIdx.x; k < nblk; k += 64) {
-        const float2 t = *reinterpret_cast<const float2*>(partial + (((size_t)b * nblk + k) * C + c) * 2);
-        p += (double)t.x;
-        q += (double)t.y;
-    }
-    p = wave_sum(p);
-    q = wave_sum(q);
-    if (threadIdx.x == 0) {
-        acc[(size_t)bc * 2] = p;
-        acc[(size_t)bc * 2 + 1] = q;
-    }
-}
-
-// finalize: one thread per (b, g) for the group sums, then per-channel parameter grads.
-__global__ void gn_bwd_group_kernel(const double* __restrict__ acc, const float* __restrict__ gamma,
-                                    const float* __restrict__ scale, float* __restrict__ gsum, int B, int C, int G,
-                                    int64_t V) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * G) return;
+// One block per (b, group): sums the per-block partials of the group's channels (f64, fixed order) into
+// acc[(b*C + c)*2 + {P, Q}] for the parameter-gradient kernel and forms the group sums
+// gsum[(b*G + g)*2] = mean_g(k P), mean_g(k Q) with k = gamma (1 + scale).
+__global__ void __launch_bounds__(256)
+gn_bwd_group_kernel(const float* __restrict__ partial, double* __restrict__ acc, const float* __restrict__ gamma,
+                    const float* __restrict__ scale, float* __restrict__ gsum, int nblk, int C, int G, int64_t V) {
+    __shared__ double sA[4], sB[4];
+    const int i = blockIdx.x;  // b * G + g
     const int b = i / G, g = i - b * G;
     const int cpg = C / G;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double A = 0.0, Bq = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-        const double k = (double)gamma[c] * (scale ? 1.0 + (double)scale[(size_t)b * C + c] : 1.0);
-        A += k * acc[((size_t)b * C + c) * 2];
-        Bq += k * acc[((size_t)b * C + c) * 2 + 1];
+    for (int cc = wave; cc < cpg; cc += 4) {
+        const int c = g * cpg + cc;
+        double p = 0.0, q = 0.0;
+        for (int k = lane; k < nblk; k += 64) {
+            const float2 t = *reinterpret_cast<const float2*>(partial + (((size_t)b * nblk + k) * C + c) * 2);
+            p += (double)t.x;
+            q += (double)t.y;
+        }
+        p = wave_sum(p);
+        q = wave_sum(q);
+        if (lane == 0) {
+            acc[((size_t)b * C + c) * 2] = p;
+            acc[((size_t)b * C + c) * 2 + 1] = q;
+        }
+        const double kk = (double)gamma[c] * (scale ? 1.0 + (double)scale[(size_t)b * C + c] : 1.0);
+        A += kk * p;
+        Bq += kk * q;
     }
-    const double n = (double)cpg * (double)V;
-    gsum[2 * i] = (float)(A / n);
-    gsum[2 * i + 1] = (float)(Bq / n);
+    if (lane == 0) { sA[wave] = A; sB[wave] = Bq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n = (double)cpg * (double)V;
+        gsum[2 * i] = (float)((sA[0] + sA[1] + sA[2] + sA[3]) / n);
+        gsum[2 * i + 1] = (float)((sB[0] + sB[1] + sB[2] + sB[3]) / n);
+    }
 }
 __global__ void gn_bwd_param_kernel(const double* __restrict__ acc, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ scale,
@@ -469,9 +470,7 @@ extern "C" int tdx_gn_bwd(const void* x, const void* dy, const float* stats, con
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, false>), grid, dim3(GN_THREADS), 0, st,
                                                       (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift,
                                                       partial, V, C, G));
-    hipLaunchKernelGGL(gn_bwd_sum_partials, dim3(B * C), dim3(64), 0, st, partial, acc, nblk, C);
-    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(ceil_div(B * G, 64)), dim3(64), 0, st, acc, gamma, scale, gsum, B, C, G,
-                       V);
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B * G), dim3(256), 0, st, partial, acc, gamma, scale, gsum, nblk, C, G, V);
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, acc, gamma, beta, scale, dgamma,
                        dbeta, dscale, dshift, B, C);
     if (act)

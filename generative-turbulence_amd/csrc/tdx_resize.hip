@@ -137,7 +137,8 @@ __host__ __device__ __forceinline__ void axis_span(const AxisMap& a, int i, int&
 // together (clamped addresses, zero weights for the unused ones).
 template <typename T, int K>
 __global__ void __launch_bounds__(256)
-resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, AxisMap ay, AxisMap az, int C, TileGrid tg) {
+resize_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ add, T* __restrict__ dx, AxisMap ax, AxisMap ay, AxisMap az,
+                  int C, TileGrid tg) {
     __shared__ int s_first[3][RS_MAXT], s_cnt[3][RS_MAXT];
     __shared__ float s_w[3][RS_MAXT][RS_KMAX];
     int b, ix0, iy0, iz0;
@@ -191,10 +192,17 @@ resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, Axis
                 }
             }
         }
+        const int64_t di = ((((int64_t)b * ax.in + ix) * ay.in + iy) * az.in + iz) * C + lc * 8;
+        if (add != nullptr) {  // second gradient of the resampled tensor (its use as a U-Net skip), fused add
+            Vec8<T> a;
+            a.load(add + di);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += a.v[j];
+        }
         Vec8<T> o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
-        o.store(dx + ((((int64_t)b * ax.in + ix) * ay.in + iy) * az.in + iz) * C + lc * 8);
+        o.store(dx + di);
     }
 }
 
@@ -202,7 +210,8 @@ resize_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, Axis
 // candidate outputs scanned over a superset range with the weights recomputed on the fly
 template <typename T>
 __global__ void __launch_bounds__(256)
-resize_bwd_generic_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap ax, AxisMap ay, AxisMap az, int C, int64_t total) {
+resize_bwd_generic_kernel(const T* __restrict__ dy, const T* __restrict__ add, T* __restrict__ dx, AxisMap ax, AxisMap ay,
+                          AxisMap az, int C, int64_t total) {
     const int L = C >> 3;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -237,10 +246,17 @@ resize_bwd_generic_kernel(const T* __restrict__ dy, T* __restrict__ dx, AxisMap 
             }
         }
     }
+    const int64_t di = ((((int64_t)b * ax.in + ix) * ay.in + iy) * az.in + iz) * C + lc * 8;
+    if (add != nullptr) {
+        Vec8<T> a;
+        a.load(add + di);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += a.v[j];
+    }
     Vec8<T> o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
-    o.store(dx + ((((int64_t)b * ax.in + ix) * ay.in + iy) * az.in + iz) * C + lc * 8);
+    o.store(dx + di);
 }
 
 static int resize_args_ok(int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C) {
@@ -285,7 +301,7 @@ static int axis_max_span(const AxisMap& a) {
     return m;
 }
 
-extern "C" int tdx_resize_bwd(const void* dy, void* dx, int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C,
+extern "C" int tdx_resize_bwd(const void* dy, const void* add, void* dx, int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C,
                               int dtype, void* stream) {
     TDX_CHECK_ARG(dy && dx && resize_args_ok(B, Xi, Yi, Zi, Xo, Yo, Zo, C));
     if (C % 8 || C / 8 > 256) return TDX_ESHAPE;
@@ -294,14 +310,14 @@ extern "C" int tdx_resize_bwd(const void* dy, void* dx, int B, int Xi, int Yi, i
     if (kx > RS_KMAX || ky > RS_KMAX || kz > RS_KMAX) {  // more than ~6x upsampling along an axis: general kernel
         const int64_t total = (int64_t)B * Xi * Yi * Zi * (C / 8);
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_bwd_generic_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0,
-                                                      as_stream(stream), (const T*)dy, (T*)dx, ax, ay, az, C, total));
+                                                      as_stream(stream), (const T*)dy, (const T*)add, (T*)dx, ax, ay, az, C, total));
         return tdx_launch_status();
     }
     const TileGrid tg = make_tiles(Xi, Yi, Zi, C);
     const dim3 grid((unsigned)((int64_t)B * tg.nx * tg.ny * tg.nz));
 #define RS_BWD(KV)                                                                                                     \
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_bwd_kernel<T, KV>), grid, dim3(256), 0, as_stream(stream),     \
-                                                  (const T*)dy, (T*)dx, ax, ay, az, C, tg))
+                                                  (const T*)dy, (const T*)add, (T*)dx, ax, ay, az, C, tg))
     if (kz <= 2) RS_BWD(2);
     else if (kz <= 4) RS_BWD(4);
     else if (kz <= 6) RS_BWD(6);

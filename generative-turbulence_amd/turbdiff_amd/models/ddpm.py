@@ -213,8 +213,8 @@ class UNet(nn.Module):
         skips = []
         for i, blk in enumerate(self.downsampling_blocks):
             x = blk(x, c, partial=first_partial) if (i == 0 and first_partial is not None) else blk(x, c)
-            skips.append(x)
-            x = ops.resize(x, [max(int(s * self.scale_factor), 3) for s in x.shape[1:4]])
+            skip, x = ops.skip_and_resize(x, [max(int(s * self.scale_factor), 3) for s in x.shape[1:4]])
+            skips.append(skip)
         x = self.center_block(x, c=c)
         for blk in self.upsampling_blocks:
             skip = skips.pop()

@@ -468,13 +468,48 @@ class _Resize(torch.autograd.Function):
         B, Xi, Yi, Zi, Xo, Yo, Zo, Cc = ctx.geom
         gy = gy.contiguous()
         gx = torch.empty((B, Xi, Yi, Zi, Cc), dtype=gy.dtype, device=gy.device)
-        L.call("tdx_resize_bwd", L.ptr(gy), L.ptr(gx), B, Xi, Yi, Zi, Xo, Yo, Zo, Cc, L.dtype_code(gy.dtype), L.stream())
+        L.call("tdx_resize_bwd", L.ptr(gy), None, L.ptr(gx), B, Xi, Yi, Zi, Xo, Yo, Zo, Cc, L.dtype_code(gy.dtype), L.stream())
         return gx, None
 
 
 def resize(x, size):
     """Trilinear resample (align_corners=True) of an NDHWC tensor to grid `size`."""
     return _Resize.apply(x, tuple(size))
+
+
+class _SkipAndResize(torch.autograd.Function):
+    """x -> (x as skip connection, resize(x)): the two uses of a U-Net level's output (reference
+    ddpm.py:355-358) as ONE node, so that the backward adds the skip gradient inside the resize adjoint
+    instead of autograd running a separate add over the level's activation."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        B, Xi, Yi, Zi, Cc = _grid(x)
+        Xo, Yo, Zo = (int(s) for s in size)
+        x = x.contiguous()
+        y = torch.empty((B, Xo, Yo, Zo, Cc), dtype=x.dtype, device=x.device)
+        L.call("tdx_resize_fwd", L.ptr(x), L.ptr(y), B, Xi, Yi, Zi, Xo, Yo, Zo, Cc, L.dtype_code(x.dtype), L.stream())
+        ctx.geom = (B, Xi, Yi, Zi, Xo, Yo, Zo, Cc)
+        ctx.set_materialize_grads(False)  # an unused output arrives as None, not as a zero tensor
+        return x.view_as(x), y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_skip, gy):
+        B, Xi, Yi, Zi, Xo, Yo, Zo, Cc = ctx.geom
+        if gy is None:
+            return g_skip, None
+        gy = gy.contiguous()
+        add = None if g_skip is None else g_skip.contiguous()
+        gx = torch.empty((B, Xi, Yi, Zi, Cc), dtype=gy.dtype, device=gy.device)
+        L.call("tdx_resize_bwd", L.ptr(gy), L.ptr(add), L.ptr(gx), B, Xi, Yi, Zi, Xo, Yo, Zo, Cc, L.dtype_code(gy.dtype),
+               L.stream())
+        return gx, None
+
+
+def skip_and_resize(x, size):
+    """(skip, resized) for a U-Net down level; the gradients of both uses are merged in one kernel."""
+    return _SkipAndResize.apply(x, tuple(size))
 
 
 # --------------------------------------------------------------------------- attention

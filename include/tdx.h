@@ -178,9 +178,12 @@ int tdx_gn_bwd(const void* x, const void* dy, const float* stats, const float* g
 /* F.interpolate(mode="trilinear", align_corners=True), ddpm.py:359-361, 367-369. */
 int tdx_resize_fwd(const void* x, void* y, int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C, int dtype,
                    void* stream);
-/* adjoint: dx (input grid) from dy (output grid); overwrites dx */
-int tdx_resize_bwd(const void* dy, void* dx, int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C, int dtype,
-                   void* stream);
+/* adjoint: dx (input grid) = A^T dy (output grid) [+ add]; overwrites dx.  `add` (input grid, may be
+ * NULL) is a second gradient of the resampled tensor -- in the U-Net the tensor that is down-sampled is
+ * also the skip connection (ddpm.py:355-358), so its two gradients are summed here instead of in a
+ * separate three-pass add. */
+int tdx_resize_bwd(const void* dy, const void* add, void* dx, int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C,
+                   int dtype, void* stream);
 
 /* ------------------------------------------------------------------ attention ---------- */
 /* F.scaled_dot_product_attention on the to_qkv output (attention.py:9-15, ddpm.py:295-308).
