@@ -19,13 +19,16 @@
 // O^T[d][q] keeps the query on the lane, so the online-softmax rescale is a per-lane scalar.
 //
 // With D = 32 the kernel is bound by the softmax VALU work (N^2 exponentials), not by the
-// matrix cores: 4 MFMAs (128 pipe cycles) per 32x32 tile against ~16 v_exp + ~70 plain VALU.
+// matrix cores: 4 MFMAs (128 pipe cycles) per 32x32 tile against 16 quarter-rate v_exp_f32 (256
+// cycles) + ~60 plain VALU instructions (v_max3, packed f32 sub / sum, packed bf16 conversion).
 #include "tdx_common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 #define FA_D 32
@@ -43,11 +46,11 @@ __device__ __forceinline__ bf16x8 fa_tr_frag(const unsigned char* lo, const unsi
     return __builtin_bit_cast(bf16x8, r);
 }
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    return (unsigned)f32_to_bf16_bits(a) | ((unsigned)f32_to_bf16_bits(b) << 16);
-}
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return pack_bf16x2(a, b); }  // one v_cvt_pk_bf16_f32
 
-__global__ void __launch_bounds__(256)
+// (256, 2): two workgroups per CU = two waves per SIMD, i.e. up to 256 architectural VGPRs per lane --
+// without the bound the allocator parks the accumulators in AGPRs and pays ~60 v_accvgpr moves per tile
+__global__ void __launch_bounds__(256, 2)
 attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse, int N, int H) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FA_KT * 64];
     unsigned char* sK = smem;                // [64 keys][32 d] bf16, swizzled 16-B chunks
@@ -107,8 +110,8 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float
         __syncthreads();
         if (k0 + FA_KT < N) load_tile(k0 + FA_KT);
 
-#pragma unroll
-        for (int kb = 0; kb < FA_KT / 32; ++kb) {
+        auto key_block = [&](int kb, auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
             // K fragments (A operand: row = key r, k = d)
             bf16x8 kf[2];
 #pragma unroll
@@ -121,7 +124,6 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float
                 const unsigned char* vp = sV + (kb * 32 + 16 * s + 4 * (g >> 1) + tq) * 64 + v_col;
                 vf[s] = fa_tr_frag(vp, vp + 8 * 64);
             }
-            const bool tail = (k0 + kb * 32 + 32 > N);
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 f32x16 st;
@@ -129,25 +131,45 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float
                 for (int i = 0; i < 16; ++i) st[i] = 0.f;
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[qt][0], st, 0, 0, 0);
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[qt][1], st, 0, 0, 0);
-                if (tail) {  // keys beyond N: register i <-> key (i & 3) + 8 (i >> 2) + 4 hh
+                if (TAIL) {  // keys beyond N: register i <-> key (i & 3) + 8 (i >> 2) + 4 hh
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
                         if (k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= N) st[i] = -INFINITY;
                 }
-                float mx = st[0];
+                // Row statistics on the vector ALU are the bottleneck of this kernel (d = 32): use the
+                // 3-input max, two-wide packed f32 ops, and skip the rescale of O while the running
+                // maximum of every query of the wave stays put (the common case after a few tiles).
+                float mx = fmaxf(st[0], st[1]);
 #pragma unroll
-                for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[i]);
+                for (int i = 2; i < 16; i += 2) mx = __builtin_fmaxf(__builtin_fmaxf(mx, st[i]), st[i + 1]);  // v_max3_f32
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float mn = fmaxf(m[qt], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);
-                float rs = 0.f;
+                if (__builtin_amdgcn_ballot_w64(mn > m[qt]) != 0) {  // wave-uniform: some query's maximum grew
+                    const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);
+                    const f32x2 a2 = {alpha, alpha};
+                    l[qt] *= alpha;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { st[i] = __builtin_amdgcn_exp2f(st[i] - mn); rs += st[i]; }
+                    for (int i = 0; i < 8; ++i) {
+                        f32x2 t = {o[qt][2 * i], o[qt][2 * i + 1]};
+                        t *= a2;  // v_pk_mul_f32
+                        o[qt][2 * i] = t.x; o[qt][2 * i + 1] = t.y;
+                    }
+                    m[qt] = mn;
+                }
+                const f32x2 mn2 = {mn, mn};
+                f32x2 rs2 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f32x2 t = {st[2 * i], st[2 * i + 1]};
+                    t -= mn2;  // v_pk_add_f32
+                    t.x = __builtin_amdgcn_exp2f(t.x);
+                    t.y = __builtin_amdgcn_exp2f(t.y);
+                    rs2 += t;  // v_pk_add_f32
+                    st[2 * i] = t.x; st[2 * i + 1] = t.y;
+                }
+                float rs = rs2.x + rs2.y;
                 rs += __shfl_xor(rs, 32, 64);
-                l[qt] = l[qt] * alpha + rs;
-                m[qt] = mn;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o[qt][i] *= alpha;
+                l[qt] += rs;
                 // P^T as the B operand of O^T += V^T P^T: registers 8 s .. 8 s + 7 -> k step s
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -157,6 +179,14 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float
                     o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], pf, o[qt], 0, 0, 0);
                 }
             }
+        };
+        // the masking of keys beyond N is compiled only into the (wave-uniform) last-tile path
+        if (k0 + FA_KT <= N) {
+#pragma unroll
+            for (int kb = 0; kb < FA_KT / 32; ++kb) key_block(kb, std::false_type{});
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < FA_KT / 32; ++kb) key_block(kb, std::true_type{});
         }
     }
 
