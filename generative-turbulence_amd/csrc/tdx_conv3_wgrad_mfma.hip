@@ -51,8 +51,11 @@ struct WgradView {
     int batch;    // voxels per sample
 };
 
+// a single input may end in a half-filled 32-channel tile (C1 % 16 == 0): its missing channels are
+// staged as zeros and their rows of dW are not written
 bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout) {
-    return C1 > 0 && (C1 % 32) == 0 && (C2 % 32) == 0 && (Cout % 32) == 0;
+    const bool c1_ok = (C1 % 32) == 0 || (C2 == 0 && (C1 % 16) == 0);
+    return C1 > 0 && c1_ok && (C2 % 32) == 0 && (Cout % 32) == 0;
 }
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_lo, const unsigned char* base_hi) {
@@ -133,7 +136,7 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
         for (int i = 0; i < XP; ++i) {
             const int pc = tid + i * 256;
             xreg[i] = make_uint4(0, 0, 0, 0);
-            if (pc < W3_NHALO * 4) {
+            if (pc < W3_NHALO * 4 && cbase + (pc & 3) * 8 < Cs) {
                 const int hv = pc >> 2, q4 = pc & 3;
                 const int hx = hv / (W3_HY * W3_HZ), rem = hv - hx * (W3_HY * W3_HZ);
                 const int hy = rem / W3_HZ, hz = rem - hy * W3_HZ;
@@ -264,6 +267,7 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const int ci = ci0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    if (ci >= Cin) continue;  // half-filled last tile
                     float* dst = &dwp[((int64_t)tap * Cin + ci) * Cout + co0 + nt * 32 + r];
                     // few splits (deep layers): every split owns a slab and stores plainly, the unpack
                     // kernel adds the slabs; many splits (fine levels): f32 atomics into one table
@@ -311,7 +315,7 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
         g.E[k] = E[a]; g.s[k] = gs[a]; g.ws[k] = gw[a]; g.nb[k] = ceil_div(E[a], bdim[k]);
     }
     const int nbricks = B * g.nb[0] * g.nb[1] * g.nb[2];
-    const int n_ci = Cin / 32, n_co = Cout / (32 * NT);
+    const int n_ci = (Cin + 31) / 32, n_co = Cout / (32 * NT);
     const int ntiles = n_ci * n_co;
     // one workgroup per CU (224 accumulator registers -> one wave per SIMD): aim at 256
     // workgroups overall, at most one split per brick.  Fewer, longer workgroups also mean fewer

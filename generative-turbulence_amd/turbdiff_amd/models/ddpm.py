@@ -77,6 +77,8 @@ class SinusoidalPosEmb(nn.Module):
 import os as _os
 
 FUSE_BLOCKS = _os.environ.get("TDX_FUSE_BLOCKS", "1") != "0"
+# TDX_COMPOSE_FIRST_CONV=0: the first U-Net conv runs on the 64 encoded channels as written in the reference
+COMPOSE_FIRST_CONV = _os.environ.get("TDX_COMPOSE_FIRST_CONV", "1") != "0"
 # TDX_CACHE_COND_CONV=0: sampling recomputes the conditioning half of the first conv every step (A/B switch)
 CACHE_COND_CONV = _os.environ.get("TDX_CACHE_COND_CONV", "1") != "0"
 
@@ -128,19 +130,26 @@ class ResnetBlock(nn.Module):
         identity = isinstance(self.conv, nn.Identity)
         return self.block1._fused_act and self.block2._fused_act and not (identity and x2 is not None) and FUSE_BLOCKS
 
-    def forward(self, x, c, x2=None, partial=None):
+    def forward(self, x, c, x2=None, partial=None, conv1=None):
         """partial = (n_lead, init): inference only -- block1's conv runs over the leading n_lead channels
-        of x and continues from `init`, the precomputed conv of the batch-shared remaining channels."""
+        of x and continues from `init`, the precomputed conv of the batch-shared remaining channels.
+        conv1 = (input, weight, bias): block1's conv replaced by an equivalent conv on another input
+        (DenoisingModel.compose_first_conv); x still feeds the identity skip."""
         film = self.project_onto_scale_shift(c)  # (B, 2*dim_out): [scale | shift]
         scale, shift = film[:, : self.dim_out], film[:, self.dim_out :]
         identity = isinstance(self.conv, nn.Identity)
         if self.fused(x2):
             b1, b2 = self.block1, self.block2
+            if conv1 is not None:
+                assert identity and x2 is None
+                return ops.resnet_block(x, None, scale, shift, (conv1[1], conv1[2]), (b1.norm.weight, b1.norm.bias),
+                                        (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias), None,
+                                        _norm_groups(b1.norm), b1.norm.eps, conv1_input=conv1[0])
             return ops.resnet_block(x, x2, scale, shift, (b1.conv.weight, b1.conv.bias), (b1.norm.weight, b1.norm.bias),
                                     (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias),
                                     None if identity else (self.conv.weight, self.conv.bias), _norm_groups(b1.norm),
                                     b1.norm.eps, partial=partial)
-        assert partial is None
+        assert partial is None and conv1 is None
         h = self.block1(x, scale_shift=(scale, shift), x2=x2)
         if isinstance(self.conv, nn.Identity):
             skip = x if x2 is None else torch.cat((x, x2), dim=-1)
@@ -209,10 +218,15 @@ class UNet(nn.Module):
         self.downsampling_factor = downsampling_factor
         self.scale_factor = 1 / downsampling_factor
 
-    def forward(self, x, c, first_partial=None):
+    def forward(self, x, c, first_partial=None, first_conv=None):
         skips = []
         for i, blk in enumerate(self.downsampling_blocks):
-            x = blk(x, c, partial=first_partial) if (i == 0 and first_partial is not None) else blk(x, c)
+            if i == 0 and first_conv is not None:
+                x = blk(x, c, conv1=first_conv)
+            elif i == 0 and first_partial is not None:
+                x = blk(x, c, partial=first_partial)
+            else:
+                x = blk(x, c)
             skip, x = ops.skip_and_resize(x, [max(int(s * self.scale_factor), 3) for s in x.shape[1:4]])
             skips.append(skip)
         x = self.center_block(x, c=c)
@@ -327,22 +341,67 @@ class DenoisingModel(nn.Module):
             enc.first_conv_partial = (n_lead, ops.conv3_shared_tail(enc, first.block1.conv.weight, n_lead))
         return enc
 
+    # The first U-Net conv reads cat(encode_x(x), encode_c_local(c)) (ddpm.py:495-501): two 1x1 convs of
+    # 4 + 4 raw channels followed by a 3x3x3 conv of 64 channels.  Both maps are linear and replicate
+    # padding commutes with a per-voxel map, so their composition is ONE 3x3x3 conv of the 8 raw channels
+    # with weights W1 . W_enc and bias b1 + sum_taps W1 . b_enc -- 1/4 of the MFMA work of the widest layer
+    # of the net in the forward pass (8 raw channels padded to 16), no data gradient at all in the backward
+    # pass (x needs none), and a weight gradient on 32 instead of 64 input channels.  The composition is
+    # done with autograd-tracked tensor ops on the (tiny) weights, so the gradients of conv.weight,
+    # encode_x and encode_c_local follow from the composed conv's weight gradient by the chain rule.
+    # each raw-channel group (x, c_local) is padded to 8 channels (16 in total: one K slice of the MFMA conv,
+    # a half-filled tile of its weight gradient), or to 16 (32 in total) when c_local itself needs a gradient
+    # (learned cell-type embedding): the data gradient w.r.t. the raw input then also runs on the MFMA path
+
+    def compose_first_conv(self, x, c_local):
+        """(raw NDHWC input (B, X, Y, Z, 32), composed weight (Cout, 32, 3, 3, 3), composed bias) or None."""
+        first = self.u_net.downsampling_blocks[0]
+        D = self.encode_x.out_channels
+        if not (COMPOSE_FIRST_CONV and isinstance(first, ResnetBlock) and first.fused() and c_local is not None
+                and isinstance(first.conv, nn.Identity) and self.in_features <= 8 and self.c_local_features <= 8
+                and first.block1.conv.in_channels == D + self.encode_c_local.out_channels):
+            return None
+        dev, P = x.device, (16 if c_local.requires_grad else 8)
+        eye = getattr(self, "_raw_eye", None)
+        if eye is None or eye[0].device != dev or eye[0].shape[0] != P:
+            ex = torch.zeros(P, self.in_features, 1, 1, 1, device=dev)
+            ec = torch.zeros(P, self.c_local_features, 1, 1, 1, device=dev)
+            ex[: self.in_features, :, 0, 0, 0] = torch.eye(self.in_features, device=dev)
+            ec[: self.c_local_features, :, 0, 0, 0] = torch.eye(self.c_local_features, device=dev)
+            eye = self._raw_eye = (ex, ec, torch.zeros(P, device=dev))
+        if not ops.encode_supported(x, c_local, eye[0]):
+            return None
+        raw = ops.encode(x, c_local, eye[0], eye[2], eye[1], eye[2], self.compute_dtype)  # [x | 0 | c | 0]
+        W1, b1 = first.block1.conv.weight, first.block1.conv.bias
+        Wx, Wc = self.encode_x.weight.flatten(1), self.encode_c_local.weight.flatten(1)  # (D, 4)
+        Co = W1.shape[0]
+        wex = torch.einsum("octuv,ck->oktuv", W1[:, :D], Wx)
+        wec = torch.einsum("octuv,ck->oktuv", W1[:, D:], Wc)
+        zx = W1.new_zeros(Co, P - self.in_features, 3, 3, 3)
+        zc = W1.new_zeros(Co, P - self.c_local_features, 3, 3, 3)
+        w_eff = torch.cat((wex, zx, wec, zc), dim=1)
+        b_eff = b1 + torch.einsum("octuv,c->o", W1[:, :D], self.encode_x.bias) \
+            + torch.einsum("octuv,c->o", W1[:, D:], self.encode_c_local.bias)
+        return raw, w_eff, b_eff
+
     def forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
         B = x.shape[0]
         c = self.conditioning_vector(t, C, B)
         c_local = local_conditioning(C) if self.c_local_features > 0 else None
+        first_conv = None
         if ops.encode_supported(x, c_local, self.encode_x.weight):
             # both encoders + NCDHW->NDHWC + concat in one kernel
             wc = self.encode_c_local.weight if c_local is not None else None
             bc = self.encode_c_local.bias if c_local is not None else None
             h = ops.encode(x, c_local, self.encode_x.weight, self.encode_x.bias, wc, bc, self.compute_dtype)
+            first_conv = self.compose_first_conv(x, c_local)
         else:
             h = ops.conv1(ops.to_nvc(x, self.compute_dtype), self.encode_x.weight, self.encode_x.bias)
             e = encoded_local if encoded_local is not None else self.encode_local(C)
             if e is not None:
                 h = torch.cat((h, e.expand(B, -1, -1, -1, -1)), dim=-1)
         partial = getattr(encoded_local, "first_conv_partial", None) if not torch.is_grad_enabled() else None
-        h = self.u_net(h, c, first_partial=partial)
+        h = self.u_net(h, c, first_partial=partial, first_conv=first_conv)
         h = self.decode[0](h, c)
         if ops.decode_supported(h, self.decode[1].weight):
             return ops.decode(h, self.decode[1].weight, self.decode[1].bias)

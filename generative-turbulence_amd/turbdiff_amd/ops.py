@@ -638,10 +638,18 @@ class _ResnetBlock(torch.autograd.Function):
     cuts the number of autograd nodes per block from 6-7 to 1."""
 
     @staticmethod
-    def forward(ctx, x1, x2, scale, shift, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps, partial=None):
+    def forward(ctx, x1, x2, scale, shift, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps, partial=None, xc=None):
+        """xc: optional separate input of block1's conv (w1 then has xc's channel count); the residual
+        path still uses x1.  Used for the U-Net's first block, whose conv is composed with the 1x1
+        encoders and therefore runs on the raw input channels (models/ddpm.py, compose_first_conv)."""
         B, X, Y, Z, C1 = _grid(x1)
         C2 = 0 if x2 is None else x2.shape[-1]
         Cin, Cout = C1 + C2, w1.shape[0]
+        if xc is not None:
+            assert x2 is None and wr is None and partial is None and xc.shape[:4] == x1.shape[:4]
+            xc = xc.contiguous()
+        Cc = xc.shape[-1] if xc is not None else Cin
+        assert w1.shape[1] == Cc
         V = X * Y * Z
         dev, dt = x1.device, x1.dtype
         code, impl, st = L.dtype_code(dt), L.conv_impl(), L.stream()
@@ -671,6 +679,8 @@ class _ResnetBlock(torch.autograd.Function):
             L.call("tdx_conv3_fwd_partial", L.ptr(x1), n_lead, C1, L.ptr(_packed_conv3_cin_slice(w1, 0, n_lead, dt)),
                    L.ptr(b1), L.ptr(init), 1, L.ptr(h1), L.ptr(st1), groups, float(eps), L.ptr(gws), B, X, Y, Z, Cout, code,
                    impl | WS_CLEAN, st, work=54.0 * n_lead * Cout * B * V)
+        elif xc is not None:
+            h1, st1 = conv_gn(xc, Cc, None, 0, wf1, b1)
         else:
             h1, st1 = conv_gn(x1, C1, x2, C2, wf1, b1)
         a1 = torch.empty_like(h1)
@@ -689,7 +699,7 @@ class _ResnetBlock(torch.autograd.Function):
         y = torch.empty_like(h1)
         L.call("tdx_gn_apply", L.ptr(h2), L.ptr(st2), L.ptr(g2), L.ptr(be2), None, None, L.ptr(res), L.ptr(y), B, V, Cout,
                groups, 1, code, st)
-        ctx.save_for_backward(x1, x2, h1, st1, a1, h2, st2, scale, shift, g1, be1, g2, be2, wb1, wb2, wr2)
+        ctx.save_for_backward(x1, x2, h1, st1, a1, h2, st2, scale, shift, g1, be1, g2, be2, wb1, wb2, wr2, xc)
         ctx.cfg = (groups, tuple(w1.shape), tuple(w2.shape), None if wr is None else tuple(wr.shape),
                    b1 is not None, b2 is not None, br is not None)
         return y
@@ -697,11 +707,12 @@ class _ResnetBlock(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x1, x2, h1, st1, a1, h2, st2, scale, shift, g1, be1, g2, be2, wb1, wb2, wr2 = ctx.saved_tensors
+        x1, x2, h1, st1, a1, h2, st2, scale, shift, g1, be1, g2, be2, wb1, wb2, wr2, xc = ctx.saved_tensors
         groups, w1s, w2s, wrs, hb1, hb2, hbr = ctx.cfg
         B, X, Y, Z, C1 = _grid(x1)
         C2 = 0 if x2 is None else x2.shape[-1]
         Cin, Cout = C1 + C2, w1s[0]
+        Cc = w1s[1]  # input channels of block1's conv (= Cin unless the conv has its own input xc)
         V = X * Y * Z
         gy = gy.contiguous()
         dev, dt = gy.device, gy.dtype
@@ -717,11 +728,11 @@ class _ResnetBlock(torch.autograd.Function):
         dw2, db2 = f32(*w2s), (f32(Cout) if hb2 else None)
         # one workspace per (Cin, Cout): the accumulator / slab layout inside depends on both
         wws2 = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cout, Cout, impl), dev, ("w3", Cout, Cout))
-        wws1 = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cin, Cout, impl), dev, ("w3", Cin, Cout))
+        wws1 = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cc, Cout, impl), dev, ("w3", Cc, Cout))
         L.call("tdx_conv3_bwd_weight", L.ptr(a1), Cout, None, 0, L.ptr(dh2), L.ptr(dw2), L.ptr(db2), B, X, Y, Z, Cout, code,
                impl | WS_CLEAN, L.ptr(wws2), st, work=flops(Cout))
         da1 = torch.empty_like(a1)
-        dws = _ws(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, max(Cin, Cout), code, impl), dev)
+        dws = _ws(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, max(Cin, Cout, Cc), code, impl), dev)
         L.call("tdx_conv3_bwd_data", L.ptr(dh2), L.ptr(wb2), L.ptr(da1), Cout, None, 0, 0, B, X, Y, Z, Cout, code, impl,
                L.ptr(dws), st, work=flops(Cout))
         del dh2
@@ -731,6 +742,18 @@ class _ResnetBlock(torch.autograd.Function):
                L.ptr(dg1), L.ptr(dbe1), L.ptr(dscale), L.ptr(dshift), B, V, Cout, groups, 1, code, L.ptr(gws), st)
         del da1
         dw1, db1 = f32(*w1s), (f32(Cout) if hb1 else None)
+        if xc is not None:
+            # block1's conv has its own input: weight gradient w.r.t. that input; the block input x1 only
+            # feeds the identity skip, so its gradient is gy; the data gradient of the conv is needed only
+            # if xc itself requires one (e.g. a learned cell-type embedding behind the raw conditioning)
+            L.call("tdx_conv3_bwd_weight", L.ptr(xc), Cc, None, 0, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
+                   impl | WS_CLEAN, L.ptr(wws1), st, work=flops(Cc))
+            dxc = None
+            if ctx.needs_input_grad[17]:
+                dxc = torch.empty_like(xc)
+                L.call("tdx_conv3_bwd_data", L.ptr(dh1), L.ptr(wb1), L.ptr(dxc), Cc, None, 0, 0, B, X, Y, Z, Cout, code, impl,
+                       L.ptr(dws), st, work=flops(Cc))
+            return (gy, None, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, dxc)
         L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
                impl | WS_CLEAN, L.ptr(wws1), st, work=flops(Cin))
         # ---- input gradient = conv1 data gradient + residual-path gradient
@@ -757,13 +780,15 @@ class _ResnetBlock(torch.autograd.Function):
                 L.call("tdx_conv1_bwd_weight", L.ptr(x2), C2, L.ptr(gy), Cout, dwt.data_ptr() + 4 * C1 * Cout, Cout, None,
                        B * V, code, st)
             dwr = dwt.t().reshape(wrs)
-        return (gx1, gx2, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None)
+        return (gx1, gx2, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None)
 
 
-def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, skip_wb, groups, eps=1e-5, partial=None):
+def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, skip_wb, groups, eps=1e-5, partial=None,
+                 conv1_input=None):
     """Fused ResnetBlock; *_wb are (weight, bias) pairs, skip_wb is None for an identity skip.
     Requires SiLU activations and bf16/f32 NDHWC inputs; scale/shift are (B, Cout).
-    partial = (n_lead, init): no-grad only, see conv3_shared_tail."""
+    partial = (n_lead, init): no-grad only, see conv3_shared_tail.
+    conv1_input: separate input tensor of block1's conv (conv1_wb then matches ITS channel count)."""
     wr, br = skip_wb if skip_wb is not None else (None, None)
     return _ResnetBlock.apply(x1, x2, scale, shift, conv1_wb[0], conv1_wb[1], norm1_wb[0], norm1_wb[1], conv2_wb[0],
-                              conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps, partial)
+                              conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps, partial, conv1_input)
