@@ -368,18 +368,18 @@ class DenoisingModel(nn.Module):
             ec = torch.zeros(P, self.c_local_features, 1, 1, 1, device=dev)
             ex[: self.in_features, :, 0, 0, 0] = torch.eye(self.in_features, device=dev)
             ec[: self.c_local_features, :, 0, 0, 0] = torch.eye(self.c_local_features, device=dev)
-            eye = self._raw_eye = (ex, ec, torch.zeros(P, device=dev))
+            Co_ = first.block1.conv.out_channels
+            eye = self._raw_eye = (ex, ec, torch.zeros(P, device=dev),
+                                   torch.zeros(Co_, P - self.in_features, 3, 3, 3, device=dev),
+                                   torch.zeros(Co_, P - self.c_local_features, 3, 3, 3, device=dev))
         if not ops.encode_supported(x, c_local, eye[0]):
             return None
         raw = ops.encode(x, c_local, eye[0], eye[2], eye[1], eye[2], self.compute_dtype)  # [x | 0 | c | 0]
         W1, b1 = first.block1.conv.weight, first.block1.conv.bias
         Wx, Wc = self.encode_x.weight.flatten(1), self.encode_c_local.weight.flatten(1)  # (D, 4)
-        Co = W1.shape[0]
         wex = torch.einsum("octuv,ck->oktuv", W1[:, :D], Wx)
         wec = torch.einsum("octuv,ck->oktuv", W1[:, D:], Wc)
-        zx = W1.new_zeros(Co, P - self.in_features, 3, 3, 3)
-        zc = W1.new_zeros(Co, P - self.c_local_features, 3, 3, 3)
-        w_eff = torch.cat((wex, zx, wec, zc), dim=1)
+        w_eff = torch.cat((wex, eye[3], wec, eye[4]), dim=1)  # zero weights on the padding channels
         b_eff = b1 + torch.einsum("octuv,c->o", W1[:, :D], self.encode_x.bias) \
             + torch.einsum("octuv,c->o", W1[:, D:], self.encode_c_local.bias)
         return raw, w_eff, b_eff
