@@ -147,6 +147,15 @@ __device__ __forceinline__ float dsilu_f(float x) {
     return s * __builtin_fmaf(x, 1.0f - s, 1.0f);
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs of the chip, each with its own L2.  xcd_contiguous maps
+// the hardware block id to a logical id such that every XCD owns ONE contiguous range of logical ids
+// (a bijection on [0, n)), so that neighbouring tiles -- which share halo voxels -- share an L2.
+__device__ __forceinline__ int xcd_contiguous(int bid, int n) {
+    const int xcd = bid & 7, k = bid >> 3;
+    const int base = n >> 3, rem = n & 7;
+    return xcd * base + min(xcd, rem) + k;
+}
+
 // dtype dispatch for launchers: calls f.template operator()<T>()
 #define TDX_DISPATCH_DTYPE(dtype, ...)                 \
     do {                                               \

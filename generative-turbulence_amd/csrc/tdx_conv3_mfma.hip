@@ -110,6 +110,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 
     // block -> region -> (n tile, b, brick)
     int bid = blockIdx.x;
+    bid = xcd_contiguous(bid, (int)gridDim.x);  // neighbouring bricks share an XCD's L2 (halo reuse)
     const int region = bid >= gs.start[1] ? (bid >= gs.start[2] ? 2 : 1) : 0;
     const ConvView& g = gs.v[region];
     bid -= gs.start[region];
