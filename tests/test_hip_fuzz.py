@@ -87,3 +87,70 @@ def test_conv3_mfma_vs_direct_random(grid, C1, C2, Co, B, extras, seed):
             continue
         assert torch.isfinite(a.float()).all(), n
         assert rel_l2(a.float().cpu(), b.float().cpu()) < tols[n], (n, grid, C1, C2, Co, B)
+
+
+def _small_cases(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        grid = (rng.randint(1, 14), rng.randint(1, 11), rng.randint(1, 12))
+        out.append((grid, rng.choice([8, 16, 24, 32, 64, 128]), rng.randint(1, 3), rng.choice([torch.float32, torch.bfloat16]),
+                    rng.randrange(1 << 30)))
+    return out
+
+
+@pytest.mark.parametrize("grid,C,B,dtype,seed", _small_cases(24, 7))
+def test_gn_film_silu_skip_resize_conv1_random(grid, C, B, dtype, seed):
+    """GroupNorm + FiLM + SiLU + residual, skip_and_resize (both gradients merged in the resize adjoint) and the
+    1x1 conv (two inputs + addend), forward and every gradient, against the same composition on stock torch
+    ops in fp32: random grids / channel counts / groups / dtypes."""
+    import torch.nn.functional as F
+
+    from turbdiff_amd import ops
+
+    rng = random.Random(seed)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    d = torch.device("cuda:0")
+    X, Y, Z = grid
+    G = rng.choice([k for k in (1, 2, 4, 8, C) if C % k == 0])
+    Co = rng.choice([8, 32, 64])
+    size = (rng.randint(1, 2 * X + 1), rng.randint(1, 2 * Y + 1), rng.randint(1, 2 * Z + 1))
+    rn = lambda *s: torch.randn(*s, device=d, generator=g)
+    leaf = lambda t: t.clone().requires_grad_()
+    x, res = rn(B, X, Y, Z, C), rn(B, X, Y, Z, C)
+    gamma, beta = 1 + 0.3 * rn(C), 0.2 * rn(C)
+    scale, shift = 0.5 * rn(B, C), 0.5 * rn(B, C)
+    w1, b1 = rn(Co, 2 * C) * (1.0 / (2 * C)) ** 0.5, rn(Co)
+    add = rn(B, *size, Co)
+    gy, gs = rn(B, *size, Co), rn(B, X, Y, Z, C)
+    rd = lambda t: t.to(dtype).float()  # what the kernels see when activations are stored in `dtype`
+
+    def torch_path(x, res, gamma, beta, scale, shift, w1, b1, add):
+        ncv = lambda t: t.permute(0, 4, 1, 2, 3)
+        nvc = lambda t: t.permute(0, 2, 3, 4, 1)
+        n = F.group_norm(ncv(x), G, gamma, beta, 1e-5)
+        n = n * (1 + scale)[:, :, None, None, None] + shift[:, :, None, None, None]
+        h = nvc(F.silu(n)) + res
+        r = nvc(F.interpolate(ncv(h), size=size, mode="trilinear", align_corners=True))
+        y = torch.cat((r, r * 0.5), dim=-1) @ w1.t() + b1 + add
+        return h, y
+
+    def hip_path(x, res, gamma, beta, scale, shift, w1, b1, add):
+        h = ops.gn_film_silu(x.to(dtype), gamma, beta, G, scale=scale, shift=shift, res=res.to(dtype))
+        skip, r = ops.skip_and_resize(h, size)
+        y = ops.conv1(r, w1, b1, x2=(r * 0.5).to(dtype), add=add.to(dtype))
+        return skip, y
+
+    ins = [x, res, gamma, beta, scale, shift, w1, b1, add]
+    ta = [leaf(rd(t) if i in (0, 1, 8) else t) for i, t in enumerate(ins)]
+    tb = [leaf(rd(t) if i in (0, 1, 8) else t) for i, t in enumerate(ins)]
+    ha, ya = torch_path(*ta)
+    hb, yb = hip_path(*tb)
+    ((ya * gy).sum() + (ha * gs).sum()).backward()
+    ((yb.float() * gy).sum() + (hb.float() * gs).sum()).backward()
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert rel_l2(yb.float().cpu(), ya.cpu()) < tol and rel_l2(hb.float().cpu(), ha.cpu()) < tol
+    for name, a, b in zip(["x", "res", "gamma", "beta", "scale", "shift", "w1", "b1", "add"], ta, tb):
+        assert b.grad is not None and torch.isfinite(b.grad).all(), name
+        if a.grad.norm() > 1e-6:
+            assert rel_l2(b.grad.float().cpu(), a.grad.cpu()) < (2e-3 if dtype == torch.float32 else 6e-2), (name, grid, C, G, size)
