@@ -420,7 +420,7 @@ def test_conv3_with_fused_gn_statistics(case, dtype):
     assert rel_l2(a.float(), a_ref.float()) < 1e-5
 
 
-@pytest.mark.parametrize("N", [256, 1000, 4096])
+@pytest.mark.parametrize("N", [256, 257, 319, 511, 1000, 1023, 4096])
 def test_attention_mfma_forward(N, monkeypatch):
     """bf16 MFMA flash attention (used for N >= 256) vs the oracle on the same bf16 inputs"""
     from turbdiff_amd import ops
