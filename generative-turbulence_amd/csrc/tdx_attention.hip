@@ -184,6 +184,9 @@ attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, const
 // tdx_attention_mfma.hip; TDX_ATTN_IMPL=vector forces the kernels of this file
 bool attn_mfma_supported(int N, int D);
 int attn_fwd_mfma_launch(const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t st);
+// tdx_attention_bwd_mfma.hip
+int attn_bwd_mfma_launch(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N,
+                         int H, hipStream_t st);
 
 extern "C" int tdx_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, int dtype,
                             void* stream) {
@@ -214,6 +217,15 @@ extern "C" int tdx_attn_bwd(const void* qkv, const void* out, const float* lse, 
     const int64_t total = (int64_t)B * N * H;
     dim3 grid(ceil_div(N, 64), B * H);
     hipStream_t st = as_stream(stream);
+    {
+        const char* e = getenv("TDX_ATTN_IMPL");
+        const bool force_vector = e && e[0] == 'v';
+        if (dtype == TDX_BF16 && !force_vector && attn_mfma_supported(N, D)) {  // long sequences: MFMA flash backward
+            hipLaunchKernelGGL((attn_delta_kernel<bf16, 32>), dim3(ceil_div(total, 256)), dim3(256), 0, st, (const bf16*)out,
+                               (const bf16*)dout, delta, N, H, total);
+            return attn_bwd_mfma_launch(qkv, dout, lse, delta, dqkv, B, N, H, st);
+        }
+    }
     TDX_DISPATCH_DTYPE(dtype, {
         hipLaunchKernelGGL((attn_delta_kernel<T, 32>), dim3(ceil_div(total, 256)), dim3(256), 0, st, (const T*)out,
                            (const T*)dout, delta, N, H, total);

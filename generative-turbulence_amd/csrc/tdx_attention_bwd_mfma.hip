@@ -1,0 +1,306 @@
+// bf16 MFMA flash attention, backward (long token sequences; BASELINE config 5 sizes).  gfx950.
+//
+// Same data layout and the same "swapped" MFMA orientation as the forward kernel
+// (tdx_attention_mfma.hip): a lane owns ONE row of the side its workgroup keeps resident, so every
+// per-row scalar (log-sum-exp, delta) is a per-lane register and the probability tile that comes out of
+// one MFMA is, converted to bf16 in registers, directly the B operand of the next.
+//
+// With P = softmax(Q K^T / sqrt(D)) (recomputed from the saved log-sum-exp), dP = dO V^T,
+// dS = P o (dP - delta), delta_i = dO_i . O_i:
+//
+//   dQ kernel   workgroup = 256 queries (a wave = 2 x 32), walks the keys in staged tiles of 64:
+//               S^T  = K Q^T            (Q resident, pre-scaled by log2(e)/sqrt(D))
+//               dP^T = V dO^T           (dO resident)
+//               dS^T = exp2(S^T - lse) o (dP^T - delta)          per-lane lse, delta
+//               dQ^T += K^T dS^T        (K^T fragments: transposed LDS reads of the row-major K tile)
+//   dK/dV kernel  workgroup = 256 keys, walks the queries in staged tiles of 64 (Q, dO, lse, delta):
+//               S  = Q K^T,  dP = dO V^T   (K pre-scaled and V resident as B operands)
+//               P  = exp2(S - lse_row),  dS = P o (dP - delta_row)     per-register lse, delta
+//               dV^T += dO^T P,  dK^T += Q^T dS   (dO^T / Q^T fragments: transposed LDS reads)
+//
+// 6 + 8 MFMAs per 32 x 32 tile against the forward's 4; no atomics, no running maximum.
+#include "tdx_common.h"
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+#define FB_D 32
+#define FB_T 64            // rows of the walked side per staged tile
+#define FB_RW 64           // resident rows per wave
+#define FB_RB (4 * FB_RW)  // resident rows per workgroup
+#define FB_LOG2E 1.4426950408889634f
+
+// 64-B rows: chunk c of row r at c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 fragments)
+__device__ __forceinline__ int fb_sw64(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ bf16x8 fb_tr_frag(const unsigned char* lo, const unsigned char* hi) {
+    s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo));
+    s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(hi));
+    s16x8 r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// accumulator registers 8 s .. 8 s + 7 of a 32 x 32 tile -> bf16 B operand of k step s
+__device__ __forceinline__ bf16x8 fb_as_b(const f32x16& t, int s) {
+    return __builtin_bit_cast(bf16x8, make_uint4(pack_bf16x2(t[8 * s], t[8 * s + 1]), pack_bf16x2(t[8 * s + 2], t[8 * s + 3]),
+                                                  pack_bf16x2(t[8 * s + 4], t[8 * s + 5]), pack_bf16x2(t[8 * s + 6], t[8 * s + 7])));
+}
+
+// resident-side fragment as a B operand (col = row r of the side, k = d), optionally scaled
+__device__ __forceinline__ bf16x8 fb_row_frag(const bf16* row, float scale) {
+    Vec8<bf16> v;
+    v.load(row);
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(v.v[2 * e] * scale, v.v[2 * e + 1] * scale);
+    return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+}
+
+// ------------------------------------------------------------------ dQ ---------------------------
+__global__ void __launch_bounds__(256, 2)
+attn_bwd_dq_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, const float* __restrict__ lse,
+                        const float* __restrict__ delta, bf16* __restrict__ dqkv, int N, int H) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * FB_T * 64];
+    unsigned char* sK = smem;                  // K tile, swizzled chunks (S^T = K Q^T: A operand rows = keys)
+    unsigned char* sKp = smem + FB_T * 64;     // K tile, plain rows (K^T fragments by transposed reads)
+    unsigned char* sV = smem + 2 * FB_T * 64;  // V tile, swizzled chunks (dP^T = V dO^T)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int ld = 3 * H * FB_D;
+    const bf16* base = qkv + (int64_t)b * N * ld;
+    const int q0 = blockIdx.x * FB_RB + wave * FB_RW;
+    const float sm_scale = rsqrtf((float)FB_D);
+
+    bf16x8 qf[2][2], gf[2][2];  // Q (pre-scaled) and dO as B operands: col = query r, k = d
+    float lse2[2], dl[2];
+    f32x16 dq[2];               // dQ^T[d][q]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = min(q0 + qt * 32 + r, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[qt][ks] = fb_row_frag(base + (int64_t)q * ld + h * FB_D + ks * 16 + hh * 8, FB_LOG2E * sm_scale);
+            gf[qt][ks] = fb_row_frag(dout + ((int64_t)b * N + q) * (H * FB_D) + h * FB_D + ks * 16 + hh * 8, 1.0f);
+        }
+        lse2[qt] = lse[((int64_t)b * H + h) * N + q] * FB_LOG2E;
+        dl[qt] = delta[((int64_t)b * H + h) * N + q];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[qt][i] = 0.f;
+    }
+
+    const int st_row = tid >> 2, st_c = tid & 3;
+    uint4 kreg, vreg;
+    auto load_tile = [&](int k0) {
+        const int key = min(k0 + st_row, N - 1);
+        const bf16* kp = base + (int64_t)key * ld + H * FB_D + h * FB_D + st_c * 8;
+        kreg = *reinterpret_cast<const uint4*>(kp);
+        vreg = *reinterpret_cast<const uint4*>(kp + H * FB_D);
+    };
+    const int g = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+    const int t_col = (16 * (g & 1) + 4 * tp) * 2;
+
+    load_tile(0);
+    for (int k0 = 0; k0 < N; k0 += FB_T) {
+        __syncthreads();
+        *reinterpret_cast<uint4*>(sK + fb_sw64(st_row, st_c)) = kreg;
+        *reinterpret_cast<uint4*>(sKp + st_row * 64 + st_c * 16) = kreg;
+        *reinterpret_cast<uint4*>(sV + fb_sw64(st_row, st_c)) = vreg;
+        __syncthreads();
+        if (k0 + FB_T < N) load_tile(k0 + FB_T);
+
+        auto key_block = [&](int kb, auto tail_c) {
+            constexpr bool TAIL = decltype(tail_c)::value;
+            bf16x8 kf[2], vf[2], ktf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                kf[ks] = *reinterpret_cast<const bf16x8*>(sK + fb_sw64(kb * 32 + r, 2 * ks + hh));
+                vf[ks] = *reinterpret_cast<const bf16x8*>(sV + fb_sw64(kb * 32 + r, 2 * ks + hh));
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {  // K^T: rows = d, k = key 16 s + 8 (j >> 2) + 4 hh + (j & 3)
+                const unsigned char* kp = sKp + (kb * 32 + 16 * s + 4 * (g >> 1) + tq) * 64 + t_col;
+                ktf[s] = fb_tr_frag(kp, kp + 8 * 64);
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x16 st, dp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[qt][0], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[qt][1], st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], gf[qt][0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], gf[qt][1], dp, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float p = __builtin_amdgcn_exp2f(st[i] - lse2[qt]);
+                    if (TAIL && k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= N) p = 0.f;  // keys beyond N
+                    st[i] = p * (dp[i] - dl[qt]);  // dS^T
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) dq[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[s], fb_as_b(st, s), dq[qt], 0, 0, 0);
+            }
+        };
+        if (k0 + FB_T <= N) {
+#pragma unroll
+            for (int kb = 0; kb < FB_T / 32; ++kb) key_block(kb, std::false_type{});
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < FB_T / 32; ++kb) key_block(kb, std::true_type{});
+        }
+    }
+    // dQ[q][h*D + d] = scale * dQ^T[d][q];  lane holds d = (i & 3) + 8 (i >> 2) + 4 hh
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 32 + r;
+        if (q < N) {
+            bf16* op = dqkv + ((int64_t)b * N + q) * ld + h * FB_D;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint2 v = make_uint2(pack_bf16x2(dq[qt][4 * j] * sm_scale, dq[qt][4 * j + 1] * sm_scale),
+                                           pack_bf16x2(dq[qt][4 * j + 2] * sm_scale, dq[qt][4 * j + 3] * sm_scale));
+                *reinterpret_cast<uint2*>(op + 8 * j + 4 * hh) = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ dK, dV -----------------------
+__global__ void __launch_bounds__(256, 2)
+attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, const float* __restrict__ lse,
+                         const float* __restrict__ delta, bf16* __restrict__ dqkv, int N, int H) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * FB_T * 64 + 2 * FB_T * 4];
+    unsigned char* sQ = smem;                   // Q tile, swizzled (S = Q K^T: A operand rows = queries)
+    unsigned char* sQp = smem + FB_T * 64;      // Q tile, plain rows (Q^T fragments)
+    unsigned char* sG = smem + 2 * FB_T * 64;   // dO tile, swizzled (dP = dO V^T)
+    unsigned char* sGp = smem + 3 * FB_T * 64;  // dO tile, plain rows (dO^T fragments)
+    float* sL = reinterpret_cast<float*>(smem + 4 * FB_T * 64);  // lse * log2(e) of the tile's queries (+inf beyond N)
+    float* sD = sL + FB_T;                                        // delta
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+    const int ld = 3 * H * FB_D;
+    const bf16* base = qkv + (int64_t)b * N * ld;
+    const int j0 = blockIdx.x * FB_RB + wave * FB_RW;
+    const float sm_scale = rsqrtf((float)FB_D);
+
+    bf16x8 kf[2][2], vf[2][2];  // K (pre-scaled) and V as B operands: col = key r, k = d
+    f32x16 dk[2], dv[2];        // dK^T[d][key], dV^T[d][key]
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = min(j0 + kt * 32 + r, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[kt][ks] = fb_row_frag(base + (int64_t)key * ld + H * FB_D + h * FB_D + ks * 16 + hh * 8, FB_LOG2E * sm_scale);
+            vf[kt][ks] = fb_row_frag(base + (int64_t)key * ld + 2 * H * FB_D + h * FB_D + ks * 16 + hh * 8, 1.0f);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dk[kt][i] = dv[kt][i] = 0.f;
+    }
+
+    const int st_row = tid >> 2, st_c = tid & 3;
+    uint4 qreg, greg;
+    float lreg = 0.f, dreg = 0.f;
+    auto load_tile = [&](int i0) {
+        const int q = min(i0 + st_row, N - 1);
+        qreg = *reinterpret_cast<const uint4*>(base + (int64_t)q * ld + h * FB_D + st_c * 8);
+        greg = *reinterpret_cast<const uint4*>(dout + ((int64_t)b * N + q) * (H * FB_D) + h * FB_D + st_c * 8);
+        if (tid < FB_T) {
+            const int qq = i0 + tid;
+            lreg = qq < N ? lse[((int64_t)b * H + h) * N + qq] * FB_LOG2E : INFINITY;  // exp2(s - inf) = 0: no query there
+            dreg = qq < N ? delta[((int64_t)b * H + h) * N + qq] : 0.f;
+        }
+    };
+    const int g = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+    const int t_col = (16 * (g & 1) + 4 * tp) * 2;
+
+    load_tile(0);
+    for (int i0 = 0; i0 < N; i0 += FB_T) {
+        __syncthreads();
+        *reinterpret_cast<uint4*>(sQ + fb_sw64(st_row, st_c)) = qreg;
+        *reinterpret_cast<uint4*>(sQp + st_row * 64 + st_c * 16) = qreg;
+        *reinterpret_cast<uint4*>(sG + fb_sw64(st_row, st_c)) = greg;
+        *reinterpret_cast<uint4*>(sGp + st_row * 64 + st_c * 16) = greg;
+        if (tid < FB_T) { sL[tid] = lreg; sD[tid] = dreg; }
+        __syncthreads();
+        if (i0 + FB_T < N) load_tile(i0 + FB_T);
+
+#pragma unroll
+        for (int qb = 0; qb < FB_T / 32; ++qb) {
+            bf16x8 qa[2], ga[2], qtf[2], gtf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {  // A operands: row = query r, k = d
+                qa[ks] = *reinterpret_cast<const bf16x8*>(sQ + fb_sw64(qb * 32 + r, 2 * ks + hh));
+                ga[ks] = *reinterpret_cast<const bf16x8*>(sG + fb_sw64(qb * 32 + r, 2 * ks + hh));
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {  // Q^T, dO^T: rows = d, k = query 16 s + 8 (j >> 2) + 4 hh + (j & 3)
+                const int off = (qb * 32 + 16 * s + 4 * (g >> 1) + tq) * 64 + t_col;
+                qtf[s] = fb_tr_frag(sQp + off, sQp + off + 8 * 64);
+                gtf[s] = fb_tr_frag(sGp + off, sGp + off + 8 * 64);
+            }
+            // per-register row scalars: register i <-> query row (i & 3) + 8 (i >> 2) + 4 hh of the block
+            float lrow[16], drow[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 l4 = *reinterpret_cast<const float4*>(sL + qb * 32 + 8 * c + 4 * hh);
+                const float4 d4 = *reinterpret_cast<const float4*>(sD + qb * 32 + 8 * c + 4 * hh);
+                lrow[4 * c] = l4.x; lrow[4 * c + 1] = l4.y; lrow[4 * c + 2] = l4.z; lrow[4 * c + 3] = l4.w;
+                drow[4 * c] = d4.x; drow[4 * c + 1] = d4.y; drow[4 * c + 2] = d4.z; drow[4 * c + 3] = d4.w;
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 st, dp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], kf[kt][0], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], kf[kt][1], st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], vf[kt][0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], vf[kt][1], dp, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    st[i] = __builtin_amdgcn_exp2f(st[i] - lrow[i]);  // P
+                    dp[i] = st[i] * (dp[i] - drow[i]);                 // dS
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    dv[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf[s], fb_as_b(st, s), dv[kt], 0, 0, 0);
+                    dk[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s], fb_as_b(dp, s), dk[kt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // dK[key][..] = scale * dK^T, dV[key][..] = dV^T;  lane holds d = (i & 3) + 8 (i >> 2) + 4 hh
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+        const int key = j0 + kt * 32 + r;
+        if (key < N) {
+            bf16* okp = dqkv + ((int64_t)b * N + key) * ld + H * FB_D + h * FB_D;
+            bf16* ovp = okp + H * FB_D;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<uint2*>(okp + 8 * j + 4 * hh) =
+                    make_uint2(pack_bf16x2(dk[kt][4 * j] * sm_scale, dk[kt][4 * j + 1] * sm_scale),
+                               pack_bf16x2(dk[kt][4 * j + 2] * sm_scale, dk[kt][4 * j + 3] * sm_scale));
+                *reinterpret_cast<uint2*>(ovp + 8 * j + 4 * hh) =
+                    make_uint2(pack_bf16x2(dv[kt][4 * j], dv[kt][4 * j + 1]), pack_bf16x2(dv[kt][4 * j + 2], dv[kt][4 * j + 3]));
+            }
+        }
+    }
+}
+
+int attn_bwd_mfma_launch(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N,
+                         int H, hipStream_t st) {
+    dim3 grid(ceil_div(N, FB_RB), B * H);
+    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse, delta,
+                       (bf16*)dqkv, N, H);
+    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse, delta,
+                       (bf16*)dqkv, N, H);
+    return tdx_launch_status();
+}

@@ -446,6 +446,13 @@ def test_attention_mfma_forward(N, monkeypatch):
         qg = qd.clone().requires_grad_()
         ops.attention(qg, H).backward(go.to(dev()).bfloat16())
         assert rel_l2(qg.grad.float().cpu(), refq.grad) < 3e-2
+        # the MFMA flash backward against the row-wise (exact fp32 softmax) kernels, per gradient
+        monkeypatch.setenv("TDX_ATTN_IMPL", "vector")
+        qv = qd.clone().requires_grad_()
+        ops.attention(qv, H).backward(go.to(dev()).bfloat16())
+        monkeypatch.delenv("TDX_ATTN_IMPL")
+        for name, a, b in zip("qkv", qg.grad.float().chunk(3, dim=-1), qv.grad.float().chunk(3, dim=-1)):
+            assert rel_l2(a, b) < 1.5e-2, (name, N)
 
 
 def test_attention_full_config5_size(monkeypatch):
@@ -474,6 +481,18 @@ def test_attention_full_config5_size(monkeypatch):
     assert rel_l2(op.float(), out.float()) < 5e-3
     # (3) exact vector kernel on the same input, first 4096 queries only would need a sliced API;
     #     instead compare full outputs at a reduced size inside test_attention_mfma_forward
+    # (4) MFMA flash backward at full size: softmax rows sum to one, so sum_keys dV = sum_queries dO per
+    #     (head, d); and the gradient is invariant under the same key/value permutation
+    qg = qkv.clone().requires_grad_()
+    go = torch.randn(B, N, H * D, device=d, generator=g).bfloat16()
+    ops.attention(qg, H).backward(go)
+    dq, dk, dv = qg.grad.float().chunk(3, dim=-1)
+    assert torch.isfinite(qg.grad.float()).all()
+    assert rel_l2(dv.sum(1), go.float().sum(1)) < 5e-3
+    qpg = qp.clone().requires_grad_()
+    ops.attention(qpg, H).backward(go)
+    dqp, dkp, dvp = qpg.grad.float().chunk(3, dim=-1)
+    assert rel_l2(dqp, dq) < 1.5e-2 and rel_l2(dkp, dk[:, perm]) < 1.5e-2 and rel_l2(dvp, dv[:, perm]) < 1.5e-2
 
 
 @pytest.mark.parametrize("grid", [(18, 10, 10), (10, 18, 9), (9, 10, 18), (14, 18, 18), (6, 9, 10)])

@@ -22,5 +22,15 @@ e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / n
 flops = 4.0 * N * N * D * H * B
 byts = 4.0 * N * H * D * 2 * B
+qg = qkv.clone().requires_grad_()
+out = ops.attention(qg, H)
+go = torch.randn_like(out)
+for _ in range(2): out.backward(go, retain_graph=True)
+torch.cuda.synchronize()
+s.record()
+for _ in range(n): out.backward(go, retain_graph=True)
+e.record(); torch.cuda.synchronize()
+msb = s.elapsed_time(e) / n
+print(f"attention bwd N={N} B={B}: {msb:.3f} ms  {3.5 * flops/msb/1e9:.0f} TFLOP/s executed (14 N^2 d h: dQ pass 6, dK/dV pass 8)")
 print(f"attention fwd N={N} B={B}: {ms:.3f} ms  {flops/ms/1e9:.0f} TFLOP/s ({flops/ms/1e9/2500*100:.1f}% of 2.5 PF)  "
       f"algorithmic Q/K/V/O traffic {byts/ms/1e6:.1f} GB/s ({byts/ms/1e6/8000*100:.2f}% of 8 TB/s)")
