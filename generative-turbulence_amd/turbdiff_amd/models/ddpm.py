@@ -369,19 +369,22 @@ class DenoisingModel(nn.Module):
             ex[: self.in_features, :, 0, 0, 0] = torch.eye(self.in_features, device=dev)
             ec[: self.c_local_features, :, 0, 0, 0] = torch.eye(self.c_local_features, device=dev)
             Co_ = first.block1.conv.out_channels
-            eye = self._raw_eye = (ex, ec, torch.zeros(P, device=dev),
-                                   torch.zeros(Co_, P - self.in_features, 3, 3, 3, device=dev),
-                                   torch.zeros(Co_, P - self.c_local_features, 3, 3, 3, device=dev))
+            nx, nc = self.in_features, self.c_local_features
+            # column gather [x .. | zero pad | c .. | zero pad]: index nx + nc is the appended zero column
+            idx = list(range(nx)) + [nx + nc] * (P - nx) + list(range(nx, nx + nc)) + [nx + nc] * (P - nc)
+            eye = self._raw_eye = (ex, ec, torch.zeros(P, device=dev), torch.zeros(Co_, 1, 3, 3, 3, device=dev),
+                                   torch.tensor(idx, dtype=torch.long, device=dev))
         if not ops.encode_supported(x, c_local, eye[0]):
             return None
         raw = ops.encode(x, c_local, eye[0], eye[2], eye[1], eye[2], self.compute_dtype)  # [x | 0 | c | 0]
         W1, b1 = first.block1.conv.weight, first.block1.conv.bias
-        Wx, Wc = self.encode_x.weight.flatten(1), self.encode_c_local.weight.flatten(1)  # (D, 4)
-        wex = torch.einsum("octuv,ck->oktuv", W1[:, :D], Wx)
-        wec = torch.einsum("octuv,ck->oktuv", W1[:, D:], Wc)
-        w_eff = torch.cat((wex, eye[3], wec, eye[4]), dim=1)  # zero weights on the padding channels
-        b_eff = b1 + torch.einsum("octuv,c->o", W1[:, :D], self.encode_x.bias) \
-            + torch.einsum("octuv,c->o", W1[:, D:], self.encode_c_local.bias)
+        # one contraction of the full weight with the block-diagonal encoder matrix (few autograd nodes on
+        # the 3x3x3 weight), then the raw channels are spread to their padded positions by a constant gather
+        w_enc = torch.block_diag(self.encode_x.weight.flatten(1), self.encode_c_local.weight.flatten(1))  # (2D, Fx + Fc)
+        b_enc = torch.cat((self.encode_x.bias, self.encode_c_local.bias))
+        w8 = torch.einsum("octuv,ck->oktuv", W1, w_enc)
+        w_eff = torch.cat((w8, eye[3]), dim=1).index_select(1, eye[4])
+        b_eff = b1 + torch.einsum("octuv,c->o", W1, b_enc)
         return raw, w_eff, b_eff
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
