@@ -70,6 +70,7 @@ def miopen_table(a):
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=6); ap.add_argument("--only", default="")
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights (switching-activity experiment)")
     ap.add_argument("--miopen", action="store_true", help="time the same layers through F.conv3d (MIOpen) instead")
     ap.add_argument("--miopen-find", action="store_true", help="with --miopen: torch.backends.cudnn.benchmark = True")
     a = ap.parse_args()
@@ -81,11 +82,12 @@ def main():
     for name, C1, C2, Co, (X, Y, Z) in LAYERS:
         if a.only and a.only not in name: continue
         Ci = C1 + C2
-        x1 = torch.randn(B, X, Y, Z, C1, device=dev).bfloat16()
+        zf = 0.0 if a.zeros else 1.0
+        x1 = (torch.randn(B, X, Y, Z, C1, device=dev) * zf).bfloat16()
         x2 = torch.randn(B, X, Y, Z, C2, device=dev).bfloat16() if C2 else None
-        w = (torch.randn(Co, Ci, 3, 3, 3, device=dev) * 0.02)
+        w = (torch.randn(Co, Ci, 3, 3, 3, device=dev) * 0.02 * zf)
         bias = torch.zeros(Co, device=dev)
-        gy = torch.randn(B, X, Y, Z, Co, device=dev).bfloat16()
+        gy = (torch.randn(B, X, Y, Z, Co, device=dev) * zf).bfloat16()
         wf, wb = ops._packed_conv3(w, torch.bfloat16)
         y = torch.empty(B, X, Y, Z, Co, device=dev, dtype=torch.bfloat16)
         st = L.stream()
