@@ -14,11 +14,20 @@ struct Conv3Geom {
 // Packed-operand layouts (element index of weight (tap, k, n); K = input channels of the
 // conv being evaluated, N = its output channels):
 //   generic : (tap*K + k)*N + n                                   [27][K][N]
-//   mfma    : (((k/16)*27 + tap)*N + n)*16 + (k%16)               [K/16][27][N][16]
-// The mfma layout is used iff conv3_mfma_supported(K, 0, N) and dtype == bf16, so that
-// pack and consumers agree without carrying a flag through the ABI.
+//   mfma    : (((k/kc)*27 + tap)*N + n)*kc + (k%kc)               [K/kc][27][N][kc]
+// with kc = 16 for bf16 iff conv3_mfma_supported(K, 0, N), kc = 8 for fp32 iff
+// conv3_mfma_f32_supported(K, 0, N), else the generic layout (kc = 0) -- a function of (dtype, K, N)
+// only, so that pack and consumers agree without carrying a flag through the ABI.
 bool conv3_mfma_supported(int C1, int C2, int Cout);
+bool conv3_mfma_f32_supported(int C1, int C2, int Cout);
+static inline int conv3_layout_kc(int dtype, int K, int N) {
+    if (dtype == 1) return conv3_mfma_supported(K, 0, N) ? 16 : 0;
+    return conv3_mfma_f32_supported(K, 0, N) ? 8 : 0;
+}
 static inline bool conv3_uses_mfma_layout(int dtype, int K, int N) { return dtype == 1 && conv3_mfma_supported(K, 0, N); }
+// fp32 MFMA forward / zero-padded data gradient (tdx_conv3_mfma_f32.hip)
+int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
+                          const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st);
 
 // optional extras of the MFMA forward: input row strides (0: dense) and a tensor the accumulators
 // start from ([B][V][Cout] bf16, or [V][Cout] shared by the batch)

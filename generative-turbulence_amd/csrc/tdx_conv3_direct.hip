@@ -13,15 +13,15 @@
 
 // ------------------------------------------------------------------ weight packing -------
 // element index of operand (tap, k, n) for a conv with K input / N output channels
-__host__ __device__ __forceinline__ int64_t wp_index(bool mfma_layout, int tap, int k, int n, int K, int N) {
-    return mfma_layout ? ((((int64_t)(k >> 4) * 27 + tap) * N + n) * 16 + (k & 15)) : (((int64_t)tap * K + k) * N + n);
+__host__ __device__ __forceinline__ int64_t wp_index(int kc, int tap, int k, int n, int K, int N) {
+    return kc ? ((((int64_t)(k / kc) * 27 + tap) * N + n) * kc + (k % kc)) : (((int64_t)tap * K + k) * N + n);
 }
 
 // w (Cout, Cin, 27) f32 -> wf: forward operand (K = Cin, N = Cout);
 //                           wb: data-gradient operand (K = Cout, N = Cin, taps flipped)
 template <typename T>
 __global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wb, int Cin,
-                                  int Cout, bool lf, bool lb) {
+                                  int Cout, int lf, int lb) {
     const int64_t n = (int64_t)Cout * Cin * 27;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int tap = (int)(i % 27);
@@ -58,7 +58,7 @@ conv3_pack_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16
 extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream) {
     TDX_CHECK_ARG(w && (wf || wb) && Cin > 0 && Cout > 0);
     const int64_t n = (int64_t)Cout * Cin * 27;
-    const bool lf = conv3_uses_mfma_layout(dtype, Cin, Cout), lb = conv3_uses_mfma_layout(dtype, Cout, Cin);
+    const int lf = conv3_layout_kc(dtype, Cin, Cout), lb = conv3_layout_kc(dtype, Cout, Cin);
     if (dtype == TDX_BF16 && (lf || !wf) && (lb || !wb) && (Cin % 16) == 0 && (Cout % 16) == 0) {
         hipLaunchKernelGGL(conv3_pack_tiled_kernel, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
                            (bf16*)wf, (bf16*)wb, Cin, Cout);
@@ -116,7 +116,7 @@ conv3_unpack_wgrad_kernel(float* __restrict__ dwp, float* __restrict__ dw, float
 template <typename T, bool ZERO_PAD>
 __global__ void __launch_bounds__(256)
 conv3_direct_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2, const T* __restrict__ wp,
-                    const float* __restrict__ bias, T* __restrict__ y, Conv3Geom g, int Cout, bool mfma_layout) {
+                    const float* __restrict__ bias, T* __restrict__ y, Conv3Geom g, int Cout, int mfma_layout) {
     __shared__ float xs[D3_BK][D3_BM + 4];
     __shared__ float ws[D3_BK][D3_BN + 4];
     const int Cin = C1 + C2;
@@ -209,7 +209,7 @@ int conv3_direct_launch(const void* x1, int C1, const void* x2, int C2, const vo
     if ((C1 % 8) || (C2 % 8)) return TDX_ESHAPE;
     const int64_t nvox = (int64_t)g.B * g.Xo * g.Yo * g.Zo;
     dim3 grid(ceil_div(nvox, D3_BM), ceil_div(Cout, D3_BN));
-    const bool ml = conv3_uses_mfma_layout(dtype, C1 + C2, Cout);
+    const int ml = conv3_layout_kc(dtype, C1 + C2, Cout);
     TDX_DISPATCH_DTYPE(dtype, {
         if (zero_pad)
             hipLaunchKernelGGL((conv3_direct_kernel<T, true>), grid, dim3(256), 0, st, (const T*)x1, C1, (const T*)x2,
@@ -430,9 +430,11 @@ extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, con
     TDX_CHECK_ARG(x1 && wf && y && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && C2 >= 0 && Cout > 0);
     TDX_CHECK_ARG(C2 == 0 || x2);
     Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
+    if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT && conv3_mfma_f32_supported(C1, C2, Cout))
+        return conv3_mfma_f32_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));
     const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout));
     if (use_mfma) {
-        if (!mfma_ok(dtype, C1, C2, Cout)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
+        if (!mfma_ok(dtype, C1, C2, Cout)) return TDX_ESHAPE;
         return conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));
     }
     return conv3_direct_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, dtype, false, as_stream(stream));
@@ -445,7 +447,8 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     TDX_CHECK_ARG(Cout > 0 && G > 0 && (Cout % G) == 0 && (C2 == 0 || x2));
     const bool clean = (impl & TDX_WS_CLEAN) != 0;
     impl &= 0xff;
-    const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout));
+    const bool use_mfma =
+        dtype == TDX_BF16 && (impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout)));
     if (!use_mfma) {  // unfused: conv, then the streaming statistics pass
         int rc = tdx_conv3_fwd(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, dtype, impl, stream);
         if (rc != TDX_OK) return rc;
@@ -502,10 +505,10 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
     if ((C1 % 8) || (C2 % 8) || (Cout % 8)) return TDX_ESHAPE;
     // adjoint on the padded grid: dpad[p'] = sum_e wb[e] dy_zero[p' - 1 + e]
     Conv3Geom g = {B, X, Y, Z, X + 2, Y + 2, Z + 2, -1};
-    const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, Cout, 0, Cin));
+    const bool use_mfma = dtype == TDX_BF16 && (impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, Cout, 0, Cin)));
     int rc;
     if (use_mfma) {
-        if (!mfma_ok(dtype, Cout, 0, Cin)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
+        if (!mfma_ok(dtype, Cout, 0, Cin)) return TDX_ESHAPE;
         {
             // interior of dx written by the conv epilogue, halo shell into the workspace, then faces
             rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream), nullptr,
@@ -520,6 +523,8 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
                                    nface, total);
             return tdx_launch_status();
         }
+    } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT && conv3_mfma_f32_supported(Cout, 0, Cin)) {
+        rc = conv3_mfma_f32_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream));
     } else {
         rc = conv3_direct_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, dtype, true, as_stream(stream));
     }

@@ -1,0 +1,240 @@
+// fp32 MFMA implicit-GEMM 3x3x3 convolution (forward and, zero-padded on the padded grid, the data
+// gradient) for the fp32 parity mode.  gfx950, v_mfma_f32_32x32x2_f32 (256 FLOP/clk/CU: the same peak as
+// the packed-FMA vector ALU, but fed from an LDS halo brick with 27-fold reuse instead of a tile that is
+// re-fetched for every tap).
+//
+// Same structure as the bf16 kernel (tdx_conv3_mfma.hip), in its plainest form: a workgroup owns a
+// 4 x 8 x 8 brick of output voxels and BN = 32 * NT output channels; K = 27 taps x input channels is
+// walked in 8-channel slices.  Per slice the halo'd brick (6 x 10 x 10 voxels x 8 ch) and the slice's
+// weights of all 27 taps go to LDS as two half-planes of 16-B entries (4 fp32 channels each; the brick's z
+// stride is padded 10 -> 12 so that fragment reads are conflict-free with affine addresses); the next
+// slice's global loads are in flight during the MFMAs of the current one.  A lane reads one 16-B entry
+// per operand and tap and feeds its four floats to four MFMAs (lanes 0-31 carry k = 0, lanes 32-63
+// k = 1 of each 32x32x2 step: channel 4*(lane >> 5) + j for the j-th MFMA, on both operands).
+// The MFMA is issued transposed (weights as A), so a lane owns one voxel and 4 consecutive channels per
+// accumulator quad: 16-B writes into an LDS output tile, then full-row coalesced stores.
+// Products and sums are IEEE fp32 (no reduced-precision operands): the 1e-4 parity gate holds as with
+// the vector-ALU kernels; only the summation order differs.
+#include "tdx_common.h"
+#include "tdx_conv3.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define F3_KC 8
+
+bool conv3_mfma_f32_supported(int C1, int C2, int Cout) {
+    return C1 > 0 && (C1 % F3_KC) == 0 && (C2 % F3_KC) == 0 && (Cout % 32) == 0;
+}
+
+struct ConvViewF {
+    int B;
+    int Ei[3], Eo[3];  // input / output grid extents
+    int nb[3];         // bricks per axis
+    int off;           // output voxel o reads input voxel o + off + e
+};
+
+// output tile rows of BN floats; 16-B chunk c of row v at c ^ swizzle(v)
+template <int BN>
+__device__ __forceinline__ int outf_addr(int v, int c) {
+    return v * (BN * 4) + ((c ^ (v & (BN / 4 - 1))) << 4);
+}
+
+template <int NT, bool ZERO_PAD>
+__global__ void __launch_bounds__(256, 2)
+conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
+                      const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, ConvViewF g,
+                      int Cout) {
+    constexpr int BN = NT * 32;
+    constexpr int BX = 4, BY = 8, BZ = 8;
+    constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
+    constexpr int SZ = 12;
+    constexpr int NHALO = HX * HY * HZ;
+    constexpr int APLANE = HX * HY * SZ * 16 + 64;
+    constexpr int BRICK_BYTES = 2 * APLANE;
+    constexpr int B_PLANE = 27 * BN * 16 + 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + BRICK_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+
+    int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int b2 = bid % g.nb[2]; bid /= g.nb[2];
+    const int b1 = bid % g.nb[1]; bid /= g.nb[1];
+    const int b0 = bid % g.nb[0]; bid /= g.nb[0];
+    const int b = bid;
+    const int n0 = blockIdx.y * BN;
+    const int o0 = b0 * BX, o1 = b1 * BY, o2 = b2 * BZ;
+    const int Cin = C1 + C2;
+
+    // staging plan of the halo brick: 2 * NHALO 16-B pieces (voxel, half = channel group of 4)
+    constexpr int A_PIECES = NHALO * 2;
+    constexpr int A_PER_THREAD = (A_PIECES + 255) / 256;
+    constexpr int B_PIECES = 27 * BN * 2;
+    constexpr int B_PER_THREAD = (B_PIECES + 255) / 256;
+    int a_src[A_PER_THREAD], a_dst[A_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < A_PER_THREAD; ++i) {
+        const int p = tid + i * 256;
+        a_dst[i] = -1;
+        a_src[i] = -1;
+        if (p < A_PIECES) {
+            const int hv = ((p >> 3) << 2) + (p & 3), half = (p >> 2) & 1;
+            const int hx = hv / (HY * HZ), rem = hv - hx * (HY * HZ);
+            const int hy = rem / HZ, hz = rem - hy * HZ;
+            a_dst[i] = half * APLANE + ((hx * HY + hy) * SZ + hz) * 16;
+            int s0 = o0 + hx - 1 + g.off, s1 = o1 + hy - 1 + g.off, s2 = o2 + hz - 1 + g.off;
+            bool ok = true;
+            if (ZERO_PAD) {
+                ok = s0 >= 0 && s0 < g.Ei[0] && s1 >= 0 && s1 < g.Ei[1] && s2 >= 0 && s2 < g.Ei[2];
+            } else {
+                s0 = min(max(s0, 0), g.Ei[0] - 1); s1 = min(max(s1, 0), g.Ei[1] - 1); s2 = min(max(s2, 0), g.Ei[2] - 1);
+            }
+            if (ok) a_src[i] = ((s0 * g.Ei[1] + s1) * g.Ei[2] + s2) * 2 + half;
+        }
+    }
+    const int64_t batch_vox = (int64_t)b * g.Ei[0] * g.Ei[1] * g.Ei[2];
+
+    // weight staging role: (row = b_row0 + 128 i, half); packed layout [K/8][27][Cout][8]
+    const int b_half = (tid >> 2) & 1;
+    const int b_row0 = ((tid >> 3) << 2) + (tid & 3);
+    const int b_goff = ((b_row0 / BN) * Cout + (b_row0 % BN)) * F3_KC + b_half * 4;
+    const int b_dst = b_half * B_PLANE + b_row0 * 16;
+
+    float4 areg[A_PER_THREAD], breg[B_PER_THREAD];
+    auto load_slice = [&](int c) {
+        const int k0 = c * F3_KC;
+        const float* xs;
+        int Cs, kk;
+        if (k0 < C1) { xs = x1; Cs = C1; kk = k0; } else { xs = x2; Cs = C2; kk = k0 - C1; }
+        xs += batch_vox * Cs + kk;
+#pragma unroll
+        for (int i = 0; i < A_PER_THREAD; ++i) {
+            areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_src[i] >= 0)
+                areg[i] = *reinterpret_cast<const float4*>(xs + (int64_t)(a_src[i] >> 1) * Cs + (a_src[i] & 1) * 4);
+        }
+        const float* wc = wp + (int64_t)c * 27 * Cout * F3_KC + (int64_t)n0 * F3_KC + b_goff;
+#pragma unroll
+        for (int i = 0; i < B_PER_THREAD; ++i) {
+            breg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_row0 + 128 * i < 27 * BN)
+                breg[i] = *reinterpret_cast<const float4*>(wc + (int64_t)i * (128 / BN) * Cout * F3_KC);
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PER_THREAD; ++i)
+            if (a_dst[i] >= 0) *reinterpret_cast<float4*>(sA + a_dst[i]) = areg[i];
+#pragma unroll
+        for (int i = 0; i < B_PER_THREAD; ++i)
+            if (b_row0 + 128 * i < 27 * BN) *reinterpret_cast<float4*>(sB + b_dst + i * 2048) = breg[i];
+    };
+
+    // wave w owns brick plane w; M tile mt: y = 4 mt + (r & 3), z = r >> 2
+    int a_h[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) a_h[mt] = ((wave + 1) * HY + (4 * mt + (r & 3) + 1)) * SZ + ((r >> 2) + 1);
+    int b_off[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b_off[nt] = hh * B_PLANE + (nt * 32 + r) * 16;
+
+    f32x16 acc[NT][2];  // D[row = channel][col = voxel]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
+
+    const int nchunks = Cin / F3_KC;
+    load_slice(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        store_slice();
+        __syncthreads();
+        if (c + 1 < nchunks) load_slice(c + 1);
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
+            const int toff = (ex * HY + ey) * SZ + ez;
+            float4 xf[2], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) xf[mt] = *reinterpret_cast<const float4*>(sA + hh * APLANE + (a_h[mt] + toff) * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const float4*>(sB + tap * (BN * 16) + b_off[nt]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt].x, xf[mt].x, acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt].y, xf[mt].y, acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt].z, xf[mt].z, acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt].w, xf[mt].w, acc[nt][mt], 0, 0, 0);
+                }
+        }
+    }
+
+    // epilogue: lane (r, hh) holds voxel (wave, 4 mt + (r & 3), r >> 2) and channels nt*32 + 8 j + 4 hh + (0..3)
+    __syncthreads();
+    unsigned char* sO = smem;  // [256 voxels][BN] fp32
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = nt * 32 + 8 * j + 4 * hh;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) bv = *reinterpret_cast<const float4*>(bias + n0 + ch);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int v = (wave * BY + 4 * mt + (r & 3)) * 8 + (r >> 2);
+                *reinterpret_cast<float4*>(sO + outf_addr<BN>(v, ch >> 2)) =
+                    make_float4(acc[nt][mt][4 * j] + bv.x, acc[nt][mt][4 * j + 1] + bv.y, acc[nt][mt][4 * j + 2] + bv.z,
+                                acc[nt][mt][4 * j + 3] + bv.w);
+            }
+        }
+    __syncthreads();
+    constexpr int CHUNKS = BN / 4;  // 16-B chunks per voxel row
+#pragma unroll
+    for (int i = 0; i < CHUNKS; ++i) {
+        const int p = tid + i * 256;
+        const int v = p / CHUNKS, cidx = p % CHUNKS;
+        const int c0 = o0 + (v >> 3) / BY, c1 = o1 + (v >> 3) % BY, c2 = o2 + (v & 7);
+        if (c0 < g.Eo[0] && c1 < g.Eo[1] && c2 < g.Eo[2]) {
+            const int64_t ov = (((int64_t)b * g.Eo[0] + c0) * g.Eo[1] + c1) * g.Eo[2] + c2;
+            *reinterpret_cast<float4*>(y + ov * Cout + n0 + cidx * 4) = *reinterpret_cast<const float4*>(sO + outf_addr<BN>(v, cidx));
+        }
+    }
+}
+
+int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
+                          const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st) {
+    const int NT = (Cout % 64 == 0) ? 2 : 1;
+    if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
+    ConvViewF v;
+    v.B = g.B; v.off = g.off;
+    v.Ei[0] = g.Xi; v.Ei[1] = g.Yi; v.Ei[2] = g.Zi;
+    v.Eo[0] = g.Xo; v.Eo[1] = g.Yo; v.Eo[2] = g.Zo;
+    v.nb[0] = ceil_div(g.Xo, 4); v.nb[1] = ceil_div(g.Yo, 8); v.nb[2] = ceil_div(g.Zo, 8);
+    const int BN = NT * 32;
+    const size_t lds = (size_t)2 * (6 * 10 * 12 * 16 + 64) + (size_t)2 * (27 * BN * 16 + 64);
+    dim3 grid((unsigned)((int64_t)g.B * v.nb[0] * v.nb[1] * v.nb[2]), Cout / BN);
+#define F3_GO(NTV, ZP)                                                                                                  \
+    do {                                                                                                                \
+        auto kern = conv3_mfma_f32_kernel<NTV, ZP>;                                                                     \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return (int)e;                                                                         \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const float*)x1, C1, (const float*)x2, C2, (const float*)wp, \
+                           bias, (float*)y, v, Cout);                                                                   \
+    } while (0)
+    if (NT == 2) { if (zero_pad) F3_GO(2, true); else F3_GO(2, false); }
+    else { if (zero_pad) F3_GO(1, true); else F3_GO(1, false); }
+#undef F3_GO
+    return tdx_launch_status();
+}

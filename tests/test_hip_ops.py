@@ -84,7 +84,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("mode", ["f32-direct", "bf16-direct", "bf16-auto"])
+@pytest.mark.parametrize("mode", ["f32-direct", "f32-auto", "bf16-direct", "bf16-auto"])
 def test_conv3_fwd_bwd(case, mode, monkeypatch):
     from turbdiff_amd import ops
 
