@@ -42,6 +42,10 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
                       const void* a2 = nullptr, const Conv3Ext* ext = nullptr);
 
 bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout);
+bool conv3_wgrad_mfma_f32_supported(int C1, int C2, int Cout);
+int conv3_wgrad_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp,
+                                float* dbias, int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs,
+                                int max_slabs, int* nslab_out);
 // slabs / max_slabs: optional region of max_slabs x 27*Cin*Cout floats; when the launch uses at most
 // max_slabs K-splits every split stores its partial tiles there (no atomics) and *nslab_out tells the
 // caller how many slabs to add up (0: the result was accumulated into dwp)

@@ -2,7 +2,7 @@
 # kernel-time table of the bench step (stats pass only); usage on the GPU box: bash tools/quick_profile.sh <tag>
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-q}; OUT=$R/gpurun_out/prof_$TAG
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $OUT.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra $TDX_BENCH_ARGS > $OUT.log 2>&1
 python3 - <<PY
 import csv,glob,collections
 f=glob.glob("$OUT/**/*kernel_trace.csv",recursive=True)[0]
