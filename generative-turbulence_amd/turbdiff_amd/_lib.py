@@ -58,6 +58,11 @@ SIGNATURES = {
     "tdx_p_sample_step": (_i, [_vp] * 7 + [_i, _vp, _i, _i, _vp, _i, _i, _i64, _vp]),
     "tdx_masked_loss": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i64, _vp, _vp]),
     "tdx_masked_loss_workspace_bytes": (_sz, []),
+    "tdx_grid_embed": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
+    "tdx_grid_select": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i64, _i64, _vp]),
+    "tdx_cell_embed_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
+    "tdx_cell_embed_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "tdx_cell_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp]),
     "tdx_randn": (_i, [_vp, _i64, _u64, _u64, _vp, _vp]),
     "tdx_randn_batched": (_i, [_vp, _i, _i64, _u64, _vp, _vp, _vp]),
     "tdx_opt_chunk_elems": (_i64, []),

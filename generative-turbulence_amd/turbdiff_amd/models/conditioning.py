@@ -8,9 +8,37 @@ members work unchanged when this package is used as a drop-in.
 import enum
 
 import torch
+from torch import nn
 
 
-class Conditioning:
+class Conditioning(nn.Module):
+    """conditioning.py:14-83: builds the conditioning dictionary of a batch (cell-type embedding and / or
+    normalised cell positions)."""
+
+    def __init__(self, variables=(), cell_type_embedding=None, cell_pos: bool = False):
+        super().__init__()
+        self.variables = variables
+        self.cell_type_embedding = cell_type_embedding
+        self.cell_pos = cell_pos
+
+    def forward(self, data):
+        C = {}
+        if self.cell_type_embedding is not None:
+            C[Conditioning.Type.CELL_TYPE] = self.cell_type_embedding(data)
+        if self.cell_pos:
+            axes = [torch.linspace(0, 1, int(c), device=data.device) for c in data.metadata.cell_counts]
+            C[Conditioning.Type.CELL_POS] = torch.stack(torch.meshgrid(*axes, indexing="ij"))
+        return C
+
+    @property
+    def local_conditioning_dim(self):
+        dim = self.cell_type_embedding.out_dim if self.cell_type_embedding is not None else 0
+        return dim + (3 if self.cell_pos else 0)
+
+    @property
+    def global_conditioning_dim(self):
+        return 0
+
     class Type(enum.Enum):
         CELL_TYPE = enum.auto()
         CELL_POS = enum.auto()

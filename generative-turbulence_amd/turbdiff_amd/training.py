@@ -33,20 +33,14 @@ import numpy as np
 import torch
 from torch import nn
 
+from .data.ofles import Variable
+from .models.cell_type_embeddings import CellTypeEmbedding
 from .models.conditioning import Conditioning
 from .models.ddpm import DenoisingModel, GaussianDiffusion
+from .models.normalization import Normalization
 
 ACTFNS = {"silu": nn.SiLU, "gelu": nn.GELU, "relu": nn.ReLU, "softplus": nn.Softplus, "tanh": nn.Tanh}
 N_CELL_TYPES = 6  # inside, outside, walls, inlets, outlets, empties (cell_type_embeddings.py:30-38)
-
-
-class _CellTypeEmbedding(nn.Module):
-    def __init__(self, dim):
-        super().__init__()
-        self.embedding = nn.Embedding(N_CELL_TYPES, embedding_dim=dim)
-
-    def forward(self, cell_types):
-        return torch.movedim(self.embedding(cell_types), -1, 0)
 
 
 class _Holder(nn.Module):
@@ -78,11 +72,14 @@ class DiffusionTrainer(nn.Module):
                  loss: str = "l2", clip_denoised: bool = False, noise_bcs: bool = True, learned_variances: bool = False,
                  elbo_weight: float | None = None, detach_elbo_mean: bool = True, actfn: str = "silu",
                  optimizer: str = "radam", norm_type: str = "group", with_geometry_embedding: bool = False,
-                 gradient_clip_val: float = 0.1, u_net_levels: int = 4, compute_dtype: torch.dtype = torch.float32):
+                 gradient_clip_val: float = 0.1, u_net_levels: int = 4, compute_dtype: torch.dtype = torch.float32,
+                 variables=("u", "p"), normalization_mode: str = "mean-std"):
         super().__init__()
-        self.cell_type_embedding = _CellTypeEmbedding(cell_type_embedding_dim)
-        self.conditioning = _Holder()
-        self.conditioning.cell_type_embedding = self.cell_type_embedding  # alias, as in the reference
+        self.variables = tuple(v if isinstance(v, Variable) else Variable.from_str(v) for v in variables)
+        self.normalization = Normalization(self.variables, normalization_mode)
+        self.cell_type_embedding = CellTypeEmbedding.create("learned", cell_type_embedding_dim)
+        # holds the embedding a second time, as in the reference (diffusion.py:89-93) -> two state_dict aliases
+        self.conditioning = Conditioning(self.variables, self.cell_type_embedding, False)
         net = DenoisingModel(in_features=n_features, out_features=n_features * (2 if learned_variances else 1),
                              c_local_features=cell_type_embedding_dim, c_global_features=0, timesteps=timesteps, dim=dim,
                              u_net_levels=u_net_levels, actfn=ACTFNS[actfn], norm_type=norm_type,
@@ -111,21 +108,46 @@ class DiffusionTrainer(nn.Module):
     def denormalize_grid(x, mean, std):
         return torch.addcmul(mean.view(-1, 1, 1, 1), std.view(-1, 1, 1, 1), x)
 
+    @staticmethod
+    def _is_openfoam_batch(batch):
+        return hasattr(batch, "data") and hasattr(batch, "stats")
+
     def _model_input(self, batch):
+        """diffusion.py:237-242.  An ``OpenFOAMBatch`` (sparse cell lists + metadata + stats) goes through
+        the fused ingress kernels; a dense batch (``x``, ``cell_types``, ``mean``, ``std``) through torch glue."""
+        if self._is_openfoam_batch(batch):
+            x = self.normalization.normalized_grid_embedding(batch.data, batch.stats)
+            return x, self.conditioning(batch.data)
         x = self.normalize_grid(batch.x, batch.mean, batch.std)
-        C = {Conditioning.Type.CELL_TYPE: self.cell_type_embedding(batch.cell_types)}
+        C = {Conditioning.Type.CELL_TYPE: torch.movedim(self.cell_type_embedding.embedding(batch.cell_types), -1, 0)}
         return x, C
+
+    def _cell_idx(self, batch):
+        return batch.data.metadata.cell_idx if self._is_openfoam_batch(batch) else batch.cell_idx
 
     def training_step(self, batch):
         x, C = self._model_input(batch)
-        loss, _ = self.model(x, C, SimpleNamespace(cell_idx=batch.cell_idx), None)
+        loss, _ = self.model(x, C, SimpleNamespace(cell_idx=self._cell_idx(batch)), None)
         return loss
 
     @torch.no_grad()
     def sample(self, batch, start_from=None, noise_fn=None):
-        x, C = self._model_input(batch)
-        x = self.model.p_sample_loop(x, C, batch.cell_idx, pbar=False, start_from=start_from, noise_fn=noise_fn)
+        """diffusion.py:152-158: dense denormalised samples (B, F, X, Y, Z)."""
+        x = self._sample_normalized(batch, start_from, noise_fn)
+        if self._is_openfoam_batch(batch):
+            return self.normalization.denormalize_grid(x, batch.stats)
         return self.denormalize_grid(x, batch.mean, batch.std)
+
+    @torch.no_grad()
+    def sample_cells(self, batch, start_from=None, noise_fn=None):
+        """The samples as ``SampleStore.add_samples`` stores them (metrics.py:52-58): per variable the
+        denormalised in-domain values, channels-last (B, n_cells, dims) -- one fused egress kernel."""
+        x = self._sample_normalized(batch, start_from, noise_fn)
+        return self.normalization.denormalized_cells(x, batch.data.metadata, batch.stats)
+
+    def _sample_normalized(self, batch, start_from, noise_fn):
+        x, C = self._model_input(batch)
+        return self.model.p_sample_loop(x, C, self._cell_idx(batch), pbar=False, start_from=start_from, noise_fn=noise_fn)
 
     def configure_optimizers(self):
         klass = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "radam": torch.optim.RAdam}.get(self.optimizer)

@@ -228,6 +228,38 @@ int tdx_masked_loss(const float* eps_hat, const float* noise, const uint8_t* mas
                     float* loss, float* grad, int B, int F, int64_t V, void* workspace, void* stream);
 size_t tdx_masked_loss_workspace_bytes(void);
 
+/* ------------------------------------------------------------------ data ingress / egress */
+/* The callers either side of the path.  Samples are the HDF5 files' channels-last
+ * cell lists: variable i is a (B, n_cells, d_i) f32 array; up to four variables fill the slots from the
+ * left (unused: NULL, 0); F = sum d_i <= 32.  Dense tensors are the reference's (B, F, V) f32.
+ *
+ * tdx_grid_embed replaces OpenFOAMData.grid_embedding (ofles.py:220-240: zeros, one index_put per
+ * variable, one per FIXED_VALUE boundary condition) followed by Normalization.normalize_grid
+ * (normalization.py:19-23) with one pass that writes every element of x exactly once:
+ *   x[b, f, v] = shift[f] + scale[f] * raw,   raw = ovr_val[ovr_of[v], f]   if bit f of ovr_mask[ovr_of[v]]
+ *                                                 = sample_f[b, cell_of[v]]  else if cell_of[v] >= 0
+ *                                                 = 0                        otherwise
+ * cell_of (V int32: position in the cell list or -1) and the override table (ovr_of: V int32 row or -1,
+ * may be NULL; ovr_val: rows x F; ovr_mask: rows) are per-geometry constants the host derives once from
+ * cell_idx, boundaries and boundary conditions with the reference's write order.  shift = -mean/std and
+ * scale = 1/std (both NULL: no normalisation); one fused multiply-add per element, as ATen's CPU addcmul. */
+int tdx_grid_embed(const float* s0, int d0, const float* s1, int d1, const float* s2, int d2, const float* s3, int d3,
+                   const int32_t* cell_of, const int32_t* ovr_of, const float* ovr_val, const uint32_t* ovr_mask,
+                   const float* shift, const float* scale, float* x, int B, int64_t n_cells, int64_t V, void* stream);
+/* tdx_grid_select replaces Normalization.denormalize_grid (normalization.py:25-29) + select_cells
+ * (utils.py:14-15) + the channels-last split SampleStore.add_samples writes (metrics.py:52-58):
+ *   o_i[b, c, j] = mean[f] + std[f] * x[b, f, cell_idx[c]]   (mean = std = NULL: plain gather) */
+int tdx_grid_select(const float* x, const int64_t* cell_idx, const float* mean, const float* std, float* o0, int d0,
+                    float* o1, int d1, float* o2, int d2, float* o3, int d3, int B, int64_t n_cells, int64_t V,
+                    void* stream);
+/* CellTypeLearnedEmbedding.forward (cell_type_embeddings.py:69-70): out[d, v] = table[types[v], d] with
+ * types a uint8 [V] grid (values < n_types <= 8, D <= 16), and the table gradient
+ * dtable[k, d] (+)= sum over voxels of type k of dC[d, v] (fp64 partial sums, fixed order). */
+int tdx_cell_embed_fwd(const uint8_t* types, const float* table, float* out, int n_types, int D, int64_t V, void* stream);
+size_t tdx_cell_embed_bwd_workspace_bytes(int n_types, int D);
+int tdx_cell_embed_bwd(const uint8_t* types, const float* dC, float* dtable, int accumulate, int n_types, int D, int64_t V,
+                       void* workspace, void* stream);
+
 /* Counter-based N(0,1) generator (Philox4x32-10 + Box-Muller), graph-replay safe: the
  * 64-bit offset is read from device memory and advanced by the kernel itself.
  * Replaces torch.randn_like (ddpm.py:777,801,810,835) inside captured sampling graphs.

@@ -1,0 +1,267 @@
+"""Data ingress / egress: host logic on the CPU, HIP kernels on the GPU, both against the
+golden vectors of tests/golden/grid_io.npz (generated from the unmodified reference) and the oracle."""
+
+import numpy as np
+import pytest
+import torch
+
+from grid_cases import load_case
+from oracle import grid_oracle as G
+from turbdiff_amd import gridio
+from turbdiff_amd.data.ofles import (BoundaryCondition, OpenFOAMBatch, OpenFOAMData, OpenFOAMMetadata, OpenFOAMStats,
+                                     Variable)
+from turbdiff_amd.models.cell_type_embeddings import CellTypeEmbedding
+from turbdiff_amd.models.conditioning import Conditioning
+from turbdiff_amd.models.normalization import Normalization
+
+
+def build(case, device="cpu"):
+    """The case as turbdiff_amd.data.ofles objects (what an HDF5 reader would hand over)."""
+    vs = tuple(Variable.from_str(name) for name, _ in case.variables)
+    bcs = {}
+    for (name, _), v in zip(case.variables, vs):
+        conds = {"zero-gradient-somewhere": BoundaryCondition(BoundaryCondition.Type.ZERO_GRADIENT)}
+        for b, val in case.fixed.get(name, {}).items():
+            conds[b] = BoundaryCondition(BoundaryCondition.Type.FIXED_VALUE, torch.tensor(val))
+        bcs[v] = conds
+    boundaries = {k: {"type": "patch", "idx": torch.tensor(i, device=device)} for k, i in case.boundaries.items()}
+    boundaries_for_bc = dict(boundaries)
+    boundaries_for_bc["zero-gradient-somewhere"] = {"type": "patch", "idx": torch.zeros(0, dtype=torch.long, device=device)}
+    meta = OpenFOAMMetadata(cell_counts=np.array(case.cell_counts), cell_idx=torch.tensor(case.cell_idx, device=device),
+                            boundaries=boundaries, boundary_conditions=bcs, file=f"/data/case-{case.tag}/data.h5")
+    data = OpenFOAMData(meta, torch.zeros(1), {v: torch.tensor(case.samples[name], device=device)
+                                               for (name, _), v in zip(case.variables, vs)})
+    stats = OpenFOAMStats({k: {n: torch.tensor(a) for n, a in st.items()} for k, st in case.stats.items()})
+    return vs, meta, data, stats
+
+
+def emulate_embed(plan, fp, samples, shift=None, scale=None):
+    """tdx_grid_embed's formula (include/tdx.h) in numpy, from the plan's arrays."""
+    B = samples[0].shape[0]
+    cell_of = plan.cell_of.numpy()
+    x = np.zeros((B, fp.F, plan.V), dtype=np.float32)
+    f0 = 0
+    for s, d in zip(samples, fp.dims):
+        inside = cell_of >= 0
+        x[:, f0:f0 + d, inside] = np.transpose(s[:, cell_of[inside], :], (0, 2, 1))
+        f0 += d
+    if fp.ovr_of is not None:
+        rows = fp.ovr_of.numpy()
+        has = rows >= 0
+        mask = fp.ovr_mask.numpy().astype(np.int64) & 0xFFFFFFFF
+        for f in range(fp.F):
+            sel = np.zeros(plan.V, dtype=bool)
+            sel[has] = (mask[rows[has]] >> f) & 1 == 1
+            x[:, f, sel] = fp.ovr_val.numpy()[rows[sel], f]
+    if shift is not None:
+        # one fused multiply-add (exact in fp64 up to the final rounding)
+        x = (shift[None, :, None].astype(np.float64) + scale[None, :, None].astype(np.float64) * x).astype(np.float32)
+    return x.reshape(B, fp.F, *plan.counts)
+
+
+# ------------------------------------------------------------------------------------ CPU: host logic
+@pytest.fixture(scope="module", params=["A", "B"])
+def case(request):
+    return load_case(request.param)
+
+
+def test_plan_reproduces_the_reference_write_order(case):
+    vs, meta, data, _ = build(case)
+    plan = gridio.plan_for(meta)
+    assert gridio.plan_for(meta) is plan  # cached on the geometry
+    fp = plan.features(vs)
+    x = emulate_embed(plan, fp, [case.samples[n] for n, _ in case.variables])
+    assert np.array_equal(x, case.grid_embedding)
+    assert np.array_equal(plan.types.numpy().reshape(plan.counts), case.cell_types)
+    assert plan.cell_of.dtype == torch.int32 and int((plan.cell_of >= 0).sum()) == len(case.cell_idx)
+
+
+def test_stats_normalizers_match_the_reference(case):
+    vs, _, _, stats = build(case)
+    for mode, ref in case.modes.items():
+        mean, std = stats.normalizers(vs, mode)
+        assert np.array_equal(mean.numpy(), ref.mean) and np.array_equal(std.numpy(), ref.std), mode
+        norm = Normalization(vs, mode)
+        xn = norm.normalize_grid(torch.tensor(case.grid_embedding), stats)
+        assert np.array_equal(xn.numpy(), ref.normalized), mode
+        assert np.array_equal(norm.denormalize_grid(xn, stats).numpy(), ref.denormalized), mode
+        # the kernel's formula (one fused multiply-add) is the arithmetic of ATen's CPU addcmul
+        shift, scale = (-mean / std).numpy(), torch.reciprocal(std).numpy()
+        plan = gridio.plan_for(build(case)[1])
+        x = emulate_embed(plan, plan.features(vs), [case.samples[n] for n, _ in case.variables], shift, scale)
+        assert np.array_equal(x, ref.normalized), mode
+    with pytest.raises(RuntimeError):
+        stats.normalizers(vs, "no-such-mode")
+    with pytest.raises(KeyError):
+        stats.normalizers(vs, "u:std")  # a per-variable mode must name every variable
+
+
+def test_embedding_modules_surface(case):
+    vs, meta, data, _ = build(case)
+    onehot = CellTypeEmbedding.create("onehot", 0)
+    assert np.array_equal(onehot(data).numpy(), case.onehot) and onehot.out_dim == 6
+    learned = CellTypeEmbedding.create("learned", 4)
+    assert list(learned.state_dict()) == ["embedding.weight"] and learned.out_dim == 4
+    assert np.array_equal(learned.cell_types(data).numpy(), case.cell_types)
+    with pytest.raises(RuntimeError):
+        CellTypeEmbedding.create("nope", 1)
+    cond = Conditioning(vs, None, cell_pos=True)
+    C = cond(data)
+    assert list(C) == [Conditioning.Type.CELL_POS] and C[Conditioning.Type.CELL_POS].shape == (3, *case.cell_counts)
+    assert cond.local_conditioning_dim == 3 and cond.global_conditioning_dim == 0
+    assert Conditioning(vs, learned, False).local_conditioning_dim == 4
+
+
+def test_no_cpu_path():
+    case = load_case("A")
+    vs, meta, data, stats = build(case)
+    with pytest.raises(RuntimeError, match="device tensors"):
+        data.grid_embedding(vs)
+
+
+# ------------------------------------------------------------------------------------ GPU: the kernels
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_grid_embed_bit_exact(tag):
+    case = load_case(tag)
+    vs, meta, data, stats = build(case, dev())
+    assert np.array_equal(data.grid_embedding(vs).cpu().numpy(), case.grid_embedding)
+    for mode, ref in case.modes.items():
+        norm = Normalization(vs, mode)
+        x = norm.normalized_grid_embedding(data, stats)
+        assert np.array_equal(x.cpu().numpy(), ref.normalized), mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_grid_select_bit_exact(tag):
+    case = load_case(tag)
+    vs, meta, data, stats = build(case, dev())
+    out = gridio.grid_select(torch.tensor(case.egress_x, device=dev()), meta, vs)
+    for (name, _), v in zip(case.variables, vs):
+        assert np.array_equal(out[v].cpu().numpy(), case.egress[name])
+    for mode in case.modes:
+        mean, std = G.normalizers(case.stats, case.variables, mode)
+        want = G.select_cells_channels_last(G.denormalize_grid(case.egress_x, mean, std), case.cell_idx, case.variables)
+        got = Normalization(vs, mode).denormalized_cells(torch.tensor(case.egress_x, device=dev()), meta, stats)
+        for (name, _), v in zip(case.variables, vs):
+            assert np.array_equal(got[v].cpu().numpy(), want[name]), (mode, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["A", "B"])
+def test_cell_type_embedding_fwd_bwd(tag):
+    case = load_case(tag)
+    vs, meta, data, _ = build(case, dev())
+    emb = CellTypeEmbedding.create("learned", 4).to(dev())
+    with torch.no_grad():
+        emb.embedding.weight.copy_(torch.tensor(case.table))
+    C = emb(data)
+    assert np.array_equal(C.detach().cpu().numpy(), case.learned)
+    C.backward(torch.tensor(case.grad_out, device=dev()))
+    assert np.allclose(emb.embedding.weight.grad.cpu().numpy(), case.grad_table, rtol=1e-6, atol=1e-6)
+    want = G.cell_type_embedding_grad(case.cell_types, case.grad_out)
+    assert np.allclose(emb.embedding.weight.grad.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+
+
+def _full_size_batch(B=2, seed=0):
+    """BASELINE configs[1] geometry: 192 x 64 x 48, interior minus a 12 x 16 x 32 obstacle."""
+    g = torch.Generator().manual_seed(seed)
+    n = (192, 64, 48)
+    inside = torch.zeros(n, dtype=torch.bool)
+    inside[1:-1, 1:-1, 1:-1] = True
+    inside[13:25, 1:17, 1:33] = False
+    idx = torch.arange(inside.numel()).reshape(n)
+    cell_idx = idx[inside]
+    walls = torch.cat([idx[:, 0, :].flatten(), idx[:, -1, :].flatten(), idx[:, :, 0].flatten(), idx[:, :, -1].flatten(),
+                       idx[13:25, 1:17, 1:33].flatten()])
+    boundaries = {"walls": {"idx": walls.to(dev())}, "inlets": {"idx": idx[0].flatten().to(dev())},
+                  "outlets": {"idx": idx[-1].flatten().to(dev())}}
+    FV = BoundaryCondition.Type.FIXED_VALUE
+    bcs = {Variable.U: {"walls": BoundaryCondition(FV, torch.zeros(3)), "inlets": BoundaryCondition(FV, torch.tensor([1.0, 0.0, 0.0])),
+                        "outlets": BoundaryCondition(BoundaryCondition.Type.INLET_OUTLET)},
+           Variable.P: {"outlets": BoundaryCondition(FV, torch.tensor(0.0))}}
+    meta = OpenFOAMMetadata(np.array(n), cell_idx.to(dev()), boundaries, bcs)
+    samples = {Variable.U: torch.randn(B, len(cell_idx), 3, generator=g).to(dev()),
+               Variable.P: torch.randn(B, len(cell_idx), 1, generator=g).to(dev())}
+    stats = OpenFOAMStats({"u": {"mean": torch.tensor([0.3, 0.0, 0.1]), "std": torch.tensor([0.5, 0.2, 0.25]),
+                                 "min": -torch.ones(3), "max": torch.ones(3) * 2},
+                           "p": {"mean": torch.tensor(0.1), "std": torch.tensor(0.7), "min": torch.tensor(-1.0), "max": torch.tensor(3.0)},
+                           "norm(u)": {"mean": torch.tensor(0.9), "std": torch.tensor(0.4), "min": torch.tensor(0.0), "max": torch.tensor(2.5)}})
+    return OpenFOAMBatch(OpenFOAMData(meta, torch.zeros(B), samples), stats)
+
+
+@pytest.mark.gpu
+def test_full_size_properties():
+    batch = _full_size_batch()
+    vs = (Variable.U, Variable.P)
+    meta, data = batch.data.metadata, batch.data
+    x = data.grid_embedding(vs)
+    # against the reference's own op chain (stock torch on the device)
+    ref = torch.zeros_like(x).flatten(2)
+    ref[:, :3, meta.cell_idx] = data.samples[Variable.U].transpose(1, 2)
+    ref[:, 3:, meta.cell_idx] = data.samples[Variable.P].transpose(1, 2)
+    ref[:, :3, meta.boundaries["walls"]["idx"]] = 0.0
+    ref[:, :3, meta.boundaries["inlets"]["idx"]] = torch.tensor([1.0, 0.0, 0.0], device=dev())[:, None]
+    ref[:, 3:, meta.boundaries["outlets"]["idx"]] = 0.0
+    assert torch.equal(x.flatten(2), ref)
+    # round trip: the in-domain cells come back bit-exactly (no boundary lies inside the domain)
+    back = gridio.grid_select(x, meta, vs)
+    assert torch.equal(back[Variable.U], data.samples[Variable.U]) and torch.equal(back[Variable.P], data.samples[Variable.P])
+    # normalise -> denormalise returns the samples to rounding
+    for mode in ("u:norm-max;p:abs-max", "mean-std"):
+        norm = Normalization(vs, mode)
+        xn = norm.normalized_grid_embedding(data, batch.stats)
+        assert torch.allclose(xn, norm.normalize_grid(x, batch.stats), rtol=0, atol=1e-6)
+        cells = norm.denormalized_cells(xn, meta, batch.stats)
+        assert torch.allclose(cells[Variable.U], data.samples[Variable.U], atol=1e-5)
+    # linearity of the table gradient, and agreement with torch's embedding backward
+    emb = CellTypeEmbedding.create("learned", 4).to(dev())
+    C = emb(data)
+    ref_C = torch.movedim(emb.embedding(emb.cell_types(data)), -1, 0)
+    assert torch.equal(C, ref_C)
+    g = torch.randn_like(C)
+    (grad,) = torch.autograd.grad(C, emb.embedding.weight, g)
+    (ref_grad,) = torch.autograd.grad(ref_C, emb.embedding.weight, g)
+    assert torch.allclose(grad, ref_grad, rtol=1e-4, atol=1e-3)
+    (grad2,) = torch.autograd.grad(emb(data), emb.embedding.weight, 2 * g)
+    assert torch.allclose(grad2, 2 * grad, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_trainer_takes_openfoam_batches():
+    """DiffusionTrainer on the sparse batch == on the equivalent dense batch (same loss, same grads)."""
+    from types import SimpleNamespace
+
+    from turbdiff_amd.training import DiffusionTrainer
+
+    case = load_case("A")
+    vs, meta, data, stats = build(case, dev())
+    torch.manual_seed(0)
+    tr = DiffusionTrainer(dim=8, timesteps=10, u_net_levels=2, variables=("u", "p"),
+                          normalization_mode="u:norm-max;p:abs-max").to(dev())
+    batch = OpenFOAMBatch(data, stats)
+    mean, std = stats.normalizers(vs, "u:norm-max;p:abs-max")
+    dense = SimpleNamespace(x=torch.tensor(case.grid_embedding, device=dev()), mean=mean.to(dev()), std=std.to(dev()),
+                            cell_idx=meta.cell_idx, cell_types=torch.tensor(case.cell_types, device=dev()))
+    losses, grads = [], []
+    for b in (batch, dense):
+        torch.manual_seed(5)
+        tr.zero_grad(set_to_none=True)
+        loss = tr.training_step(b)
+        loss.backward()
+        losses.append(loss.item())
+        grads.append(tr.cell_type_embedding.embedding.weight.grad.clone())
+    assert losses[0] == losses[1]
+    assert torch.allclose(grads[0], grads[1], rtol=1e-4, atol=1e-6)
+    torch.manual_seed(9)
+    cells = tr.sample_cells(batch)
+    torch.manual_seed(9)
+    full = tr.sample(batch)
+    want = G.select_cells_channels_last(full.cpu().numpy(), case.cell_idx, case.variables)
+    for (name, _), v in zip(case.variables, vs):
+        assert np.allclose(cells[v].cpu().numpy(), want[name], rtol=1e-6, atol=1e-6)
