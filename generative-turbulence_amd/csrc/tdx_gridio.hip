@@ -108,6 +108,8 @@ extern "C" int tdx_grid_embed(const float* s0, int d0, const float* s1, int d1, 
     int rc = fill_vars(gv, ptrs, dims, nvar, &F);
     if (rc != TDX_OK) return rc;
     if (B > 65535) return TDX_ESHAPE;
+    // (a 4-voxels-per-thread variant with 16-B stores measured slower: 31.8 vs 26.7 us at 192x64x48, B = 6 --
+    // the sample gathers lose their coalescing)
     dim3 grid((unsigned)ceil_div(V, (int64_t)256), B);
     hipLaunchKernelGGL(grid_embed_kernel, grid, dim3(256), 0, as_stream(stream), gv, cell_of, ovr_of, ovr_val, ovr_mask, shift,
                        scale, x, F, n_cells, V);
@@ -183,13 +185,18 @@ cell_embed_bwd_partial_kernel(const uint8_t* __restrict__ types, const float* __
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void cell_embed_bwd_final_kernel(const double* __restrict__ partial, float* __restrict__ dtable, int nk, int nblk,
-                                            int accumulate) {
-    const int kd = threadIdx.x;
-    if (kd >= nk) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[(int64_t)b * nk + kd];
-    dtable[kd] = accumulate ? dtable[kd] + (float)s : (float)s;
+// one block per (type, d): the partials are added by a fixed LDS tree
+__global__ void __launch_bounds__(CE_BLOCKS)
+cell_embed_bwd_final_kernel(const double* __restrict__ partial, float* __restrict__ dtable, int nk, int nblk, int accumulate) {
+    __shared__ double red[CE_BLOCKS];
+    const int kd = blockIdx.x;
+    red[threadIdx.x] = (int)threadIdx.x < nblk ? partial[(int64_t)threadIdx.x * nk + kd] : 0.0;
+    __syncthreads();
+    for (int w = CE_BLOCKS / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dtable[kd] = accumulate ? dtable[kd] + (float)red[0] : (float)red[0];
 }
 
 extern "C" int tdx_cell_embed_fwd(const uint8_t* types, const float* table, float* out, int n_types, int D, int64_t V,
@@ -212,7 +219,7 @@ extern "C" int tdx_cell_embed_bwd(const uint8_t* types, const float* dC, float* 
     const int nblk = (int)(ceil_div(V, (int64_t)256) < CE_BLOCKS ? ceil_div(V, (int64_t)256) : CE_BLOCKS);
     hipLaunchKernelGGL(cell_embed_bwd_partial_kernel, dim3(nblk, D), dim3(256), 0, as_stream(stream), types, dC,
                        (double*)workspace, n_types, D, V);
-    hipLaunchKernelGGL(cell_embed_bwd_final_kernel, dim3(1), dim3(128), 0, as_stream(stream), (const double*)workspace, dtable,
-                       n_types * D, nblk, accumulate);
+    hipLaunchKernelGGL(cell_embed_bwd_final_kernel, dim3(n_types * D), dim3(CE_BLOCKS), 0, as_stream(stream),
+                       (const double*)workspace, dtable, n_types * D, nblk, accumulate);
     return tdx_launch_status();
 }

@@ -122,6 +122,27 @@ def _slots(tensors, dims):
     return args
 
 
+_AFFINE: dict = {}
+
+
+def _shift_scale(mean, std, device):
+    """(-mean/std, 1/std) on the device, cached per (mean, std) tensor pair (OpenFOAMStats caches those)."""
+    key = (id(mean), id(std), str(device))
+    hit = _AFFINE.get(key)
+    if hit is None or hit[0] is not mean or hit[1] is not std:
+        m, s = mean.to(device, torch.float32), std.to(device, torch.float32)
+        if len(_AFFINE) > 64:
+            _AFFINE.clear()
+        hit = _AFFINE[key] = (mean, std, (-m / s).contiguous(), torch.reciprocal(s).contiguous(), m.contiguous(), s.contiguous())
+    return hit[2], hit[3]
+
+
+def _mean_std(mean, std, device):
+    _shift_scale(mean, std, device)
+    hit = _AFFINE[(id(mean), id(std), str(device))]
+    return hit[4], hit[5]
+
+
 def grid_embed(data, variables, mean=None, std=None):
     """Dense (B, F, X, Y, Z) fp32 grid of a batch; with ``mean`` / ``std`` (F,) also normalised as
     ``Normalization.normalize_grid`` does: addcmul(-mean/std, 1/std, x)."""
@@ -137,8 +158,7 @@ def grid_embed(data, variables, mean=None, std=None):
     x = torch.empty((B, fp.F, *plan.counts), dtype=torch.float32, device=samples[0].device)
     shift = scale = None
     if mean is not None:
-        mean, std = mean.to(x.device, torch.float32), std.to(x.device, torch.float32)
-        shift, scale = (-mean / std).contiguous(), torch.reciprocal(std).contiguous()
+        shift, scale = _shift_scale(mean, std, x.device)
     L.call("tdx_grid_embed", *_slots(samples, fp.dims), L.ptr(plan.cell_of), L.ptr(fp.ovr_of), L.ptr(fp.ovr_val),
            L.ptr(fp.ovr_mask), L.ptr(shift), L.ptr(scale), L.ptr(x), B, plan.n_cells, plan.V, L.stream())
     return x
@@ -155,7 +175,7 @@ def grid_select(x, metadata, variables, mean=None, std=None):
     B = x.shape[0]
     outs = [torch.empty((B, plan.n_cells, d), dtype=torch.float32, device=x.device) for d in dims]
     if mean is not None:
-        mean, std = mean.to(x.device, torch.float32).contiguous(), std.to(x.device, torch.float32).contiguous()
+        mean, std = _mean_std(mean, std, x.device)
     L.call("tdx_grid_select", L.ptr(x), L.ptr(plan.cell_idx), L.ptr(mean), L.ptr(std), *_slots(outs, dims), B,
            plan.n_cells, plan.V, L.stream())
     return dict(zip(variables, outs))
