@@ -7,9 +7,10 @@
   loss, noise_bcs, learned_variances, clip_denoised, norm_type, actfn, optimizer, learning_rate,
   min_learning_rate, lr_decay, cell_type_embedding_dim, ...) -- u_net_levels = 4 is hard-coded
   there (diffusion.py:120) and here;
-* ``_model_input``: per-feature normalisation ``addcmul(-mean/std, 1/std, x)``
-  (normalization.py:20-24) and the learned cell-type embedding as local conditioning
-  (cell_type_embeddings.py:72-79, conditioning.py:48-51);
+* ``_model_input`` (diffusion.py:237-242): for an ``OpenFOAMBatch`` (sparse cell lists, metadata, stats) the
+  fused ingress kernels -- grid embedding + normalisation in one pass, cell-type embedding
+  (``turbdiff_amd.gridio``; ofles.py:220-240, normalization.py:19-23, cell_type_embeddings.py:62-70); for a
+  dense batch the same arithmetic as torch glue;
 * ``training_step`` = ``GaussianDiffusion.forward``; ``sample`` = ``p_sample_loop`` + denormalise
   (diffusion.py:152-165); ``configure_optimizers`` = RAdam + per-step exponential LambdaLR
   (diffusion.py:210-235); ``fit_step`` adds the trainer's clip-by-norm 0.1 (train.yaml:30-31);
@@ -18,9 +19,9 @@
 
 The ``state_dict`` has the reference task's 149 keys (``model.model.*``, the two aliases of the
 cell-type embedding, and the 8 metric buffers as placeholders), so the reference's checkpoints load
-with ``strict=True``.  A batch is any object with ``x`` (B, F, X, Y, Z) in physical units,
-``cell_idx`` (flat in-domain cell indices), ``cell_types`` (X, Y, Z) int64 in [0, 6), and the
-per-feature ``mean`` / ``std`` of the active normalisation mode.
+with ``strict=True``.  A batch is an ``OpenFOAMBatch`` (``turbdiff_amd.data.ofles`` or the reference's own,
+on the device) or any object with ``x`` (B, F, X, Y, Z) in physical units, ``cell_idx`` (flat in-domain
+cell indices), ``cell_types`` (X, Y, Z) int64 in [0, 6), and the per-feature ``mean`` / ``std``.
 """
 
 from __future__ import annotations
