@@ -87,3 +87,63 @@ def test_module_surface_matches_reference():
     (LinearAttention, pad_to_multiple_of, unpad, expand_as) agree with it numerically."""
     out = subprocess.run([sys.executable, "-c", SURFACE.format(root=ROOT)], capture_output=True, text=True, timeout=300)
     assert "SURFACE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+GRIDIO = r'''
+import sys, inspect
+sys.path.insert(0, "{root}/tests/golden"); sys.path.insert(0, "{root}/tests"); sys.path.insert(0, "{root}/generative-turbulence_amd")
+import make_golden
+make_golden.install_stubs()
+sys.path.insert(0, "/root/reference")
+import numpy as np, torch
+from pathlib import Path
+from turbdiff.data.ofles import BoundaryCondition as BC, OpenFOAMData, OpenFOAMMetadata, OpenFOAMStats, Variable as V
+import turbdiff.models.normalization as RN, turbdiff.models.cell_type_embeddings as RC, turbdiff.models.conditioning as RCo
+import turbdiff_amd.models.normalization as MN, turbdiff_amd.models.cell_type_embeddings as MC, turbdiff_amd.models.conditioning as MCo
+import turbdiff_amd.data.ofles as MO, turbdiff.data.ofles as RO
+from turbdiff_amd import gridio
+from grid_cases import load_case
+from test_gridio import emulate_embed
+
+# 1. public names of the reference modules exist here (classes / functions defined in those modules)
+for R, M in ((RN, MN), (RC, MC), (RCo, MCo)):
+    missing = [n for n, v in vars(R).items() if (inspect.isclass(v) or inspect.isfunction(v))
+               and getattr(v, "__module__", "") == R.__name__ and not hasattr(M, n)]
+    assert not missing, (R.__name__, missing)
+for n in ("Variable", "BoundaryCondition", "split_channels", "OpenFOAMMetadata", "OpenFOAMData", "OpenFOAMStats", "OpenFOAMBatch"):
+    assert hasattr(MO, n) and hasattr(RO, n), n
+assert [v.name for v in MO.Variable] == [v.name for v in RO.Variable]
+assert all(MO.Variable[v.name].dims == v.dims and MO.Variable[v.name].value == v.value for v in RO.Variable)
+
+# 2. the reference's OWN batch objects go through the plan (attribute names only)
+for tag in "AB":
+    c = load_case(tag)
+    vs = tuple(V.from_str(n) for n, _ in c.variables)
+    bcs = {{v: {{b: BC(BC.Type.FIXED_VALUE, torch.tensor(val)) for b, val in c.fixed.get(n, {{}}).items()}} for (n, _), v in zip(c.variables, vs)}}
+    meta = OpenFOAMMetadata(file=Path("/tmp/x/data.h5"), nu=0.0, h=np.ones(3), cell_counts=np.array(c.cell_counts),
+                            cell_idx=torch.tensor(c.cell_idx), boundaries={{k: {{"type": "patch", "idx": torch.tensor(i)}} for k, i in c.boundaries.items()}},
+                            boundary_conditions=bcs, holes=[])
+    data = OpenFOAMData(meta, torch.zeros(1), {{v: torch.tensor(c.samples[n]) for (n, _), v in zip(c.variables, vs)}})
+    ref = data.grid_embedding(vs).numpy()
+    plan = gridio.plan_for(data.metadata)
+    ours = emulate_embed(plan, plan.features(vs), [c.samples[n] for n, _ in c.variables])
+    assert np.array_equal(ours, ref) and np.array_equal(ref, c.grid_embedding)
+    emb = RC.CellTypeEmbedding.create("learned", 4)
+    assert np.array_equal(emb.cell_types(data).numpy(), plan.types.numpy().reshape(plan.counts))
+    # the reference's stats object through OUR Normalization (dense methods) and vice versa
+    stats = OpenFOAMStats({{k: {{n: torch.tensor(a) for n, a in st.items()}} for k, st in c.stats.items()}})
+    mine = MO.OpenFOAMStats({{k: {{n: torch.tensor(a) for n, a in st.items()}} for k, st in c.stats.items()}})
+    mvs = tuple(MO.Variable[v.name] for v in vs)
+    for mode in c.modes:
+        a = RN.Normalization(vs, mode).normalize_grid(torch.tensor(ref), stats)
+        b = MN.Normalization(vs, mode).normalize_grid(torch.tensor(ref), stats)
+        m1, s1 = stats.normalizers(vs, mode); m2, s2 = mine.normalizers(mvs, mode)
+        assert torch.equal(a, b) and torch.equal(m1, m2) and torch.equal(s1, s2), mode
+print("GRIDIO_OK")
+'''
+
+
+@pytest.mark.skipif(not REF.exists(), reason="reference checkout not present")
+def test_reference_batch_objects_flow_through_gridio():
+    out = subprocess.run([sys.executable, "-c", GRIDIO.format(root=ROOT)], capture_output=True, text=True, timeout=300)
+    assert "GRIDIO_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
