@@ -63,6 +63,8 @@ SIGNATURES = {
     "tdx_cell_embed_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp]),
     "tdx_cell_embed_bwd_workspace_bytes": (_sz, [_i, _i]),
     "tdx_cell_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp]),
+    "tdx_tke_energy": (_i, [_vp, _vp, _i, _i64, _vp]),
+    "tdx_tke_sphere": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_randn": (_i, [_vp, _i64, _u64, _u64, _vp, _vp]),
     "tdx_randn_batched": (_i, [_vp, _i, _i64, _u64, _vp, _vp, _vp]),
     "tdx_opt_chunk_elems": (_i64, []),

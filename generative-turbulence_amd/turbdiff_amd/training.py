@@ -51,17 +51,17 @@ class _Holder(nn.Module):
 def _metric_placeholders():
     """`{val,test}_sample_metrics.metrics.0.distance.*` buffers of the reference task
     (models/metrics.py); evaluation metrics are out of scope, the buffers only keep checkpoints
-    strict-loadable (legendre_* hold the real Gauss-Legendre rule, the Lebedev grid is zero-filled
-    and overwritten by a checkpoint)."""
+    strict-loadable (legendre_* hold the real Gauss-Legendre rule, tke_spectrum the device implementation of
+    the reference's TurbulentKineticEnergySpectrum with the same Lebedev rule)."""
     nodes, weights = np.polynomial.legendre.leggauss(64)
     coll = _Holder()
     coll.metrics = nn.ModuleList([_Holder()])
     dist = _Holder()
     dist.register_buffer("legendre_nodes", torch.tensor(nodes, dtype=torch.float32))
     dist.register_buffer("legendre_weights", torch.tensor(weights, dtype=torch.float32))
-    dist.tke_spectrum = _Holder()
-    dist.tke_spectrum.register_buffer("p", torch.zeros(5810, 3))
-    dist.tke_spectrum.register_buffer("w", torch.zeros(5810))
+    from .models.metrics import TurbulentKineticEnergySpectrum
+
+    dist.tke_spectrum = TurbulentKineticEnergySpectrum()  # 5810-node Lebedev rule, the device spectrum (§8 f3)
     coll.metrics[0].distance = dist
     return coll
 

@@ -260,6 +260,18 @@ size_t tdx_cell_embed_bwd_workspace_bytes(int n_types, int D);
 int tdx_cell_embed_bwd(const uint8_t* types, const float* dC, float* dtable, int accumulate, int n_types, int D, int64_t V,
                        void* workspace, void* stream);
 
+/* ------------------------------------------------------------------ sample metrics ------ */
+/* TurbulentKineticEnergySpectrum.forward (turbdiff/models/metrics.py:289-316) around the FFT (section 8 f3).
+ * tdx_tke_energy: tke[b, v] = 0.5 * sum_c u[b, c, v]^2 for u (B, 3, V) f32 (metrics.py:291).
+ * tdx_tke_sphere: fft is the UNSHIFTED complex64 fftn of tke, (B, X, Y, Z) interleaved (re, im); p (N, 3) and
+ * w (N) a quadrature rule on the unit sphere, k (K) radii:
+ *   E[b, k] = 4 pi k^2 sum_n w[n] exp(interp3(log |fftshift(F)|^2, k p[n] + (X/2, Y/2, Z/2)))
+ * with interp3 of metrics.py:220-268 (corners clamped into the grid, weights relative to the clamped lower
+ * corner). */
+int tdx_tke_energy(const float* u, float* tke, int B, int64_t V, void* stream);
+int tdx_tke_sphere(const float* fft, const float* p, const float* w, const float* k, float* E, int B, int X, int Y, int Z,
+                   int N, int K, void* stream);
+
 /* Counter-based N(0,1) generator (Philox4x32-10 + Box-Muller), graph-replay safe: the
  * 64-bit offset is read from device memory and advanced by the kernel itself.
  * Replaces torch.randn_like (ddpm.py:777,801,810,835) inside captured sampling graphs.
