@@ -25,6 +25,10 @@ static inline int conv3_layout_kc(int dtype, int K, int N) {
     return conv3_mfma_f32_supported(K, 0, N) ? 8 : 0;
 }
 static inline bool conv3_uses_mfma_layout(int dtype, int K, int N) { return dtype == 1 && conv3_mfma_supported(K, 0, N); }
+// split-precision (bf16 hi + lo) MFMA forward / zero-padded data gradient for fp32 tensors (tdx_conv3_mfma_split.hip)
+bool conv3_mfma_split_supported(int C1, int C2, int Cout);
+int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
+                            const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st);
 // fp32 MFMA forward / zero-padded data gradient (tdx_conv3_mfma_f32.hip)
 int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                           const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st);

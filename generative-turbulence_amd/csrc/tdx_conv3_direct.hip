@@ -55,9 +55,49 @@ conv3_pack_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16
     }
 }
 
+// split-precision operands (tdx_conv3_mfma_split.hip): hi = bf16(v), lo = bf16(v - hi), two MFMA-layout images
+// [2][K/16][27][N][16] bf16 in a buffer of the fp32 operand's size
+__global__ void conv3_pack_split_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wb, int Cin,
+                                        int Cout) {
+    const int64_t n = (int64_t)Cout * Cin * 27;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 27);
+        const int64_t r = i / 27;
+        const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        const float v = w[i];
+        const bf16 hi = __float2bfloat16(v);
+        const bf16 lo = __float2bfloat16(v - __bfloat162float(hi));
+        if (wf) {
+            const int64_t j = wp_index(16, tap, ci, co, Cin, Cout);
+            wf[j] = hi;
+            wf[n + j] = lo;
+        }
+        if (wb) {
+            const int64_t j = wp_index(16, 26 - tap, co, ci, Cout, Cin);
+            wb[j] = hi;
+            wb[n + j] = lo;
+        }
+    }
+}
+
 extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream) {
     TDX_CHECK_ARG(w && (wf || wb) && Cin > 0 && Cout > 0);
     const int64_t n = (int64_t)Cout * Cin * 27;
+    if (dtype == TDX_F32_SPLIT) {
+        // per operand: the split images where the split kernel can run (a function of (K, N) only, like every
+        // layout decision here), else the plain fp32 operand
+        void* sf = (wf && conv3_mfma_split_supported(Cin, 0, Cout)) ? wf : nullptr;
+        void* sb = (wb && conv3_mfma_split_supported(Cout, 0, Cin)) ? wb : nullptr;
+        if (sf || sb) {
+            int grid = (int)min((int64_t)1024, (n + 255) / 256);
+            hipLaunchKernelGGL(conv3_pack_split_kernel, dim3(grid), dim3(256), 0, as_stream(stream), w, (bf16*)sf, (bf16*)sb,
+                               Cin, Cout);
+        }
+        void* pf = sf ? nullptr : wf;
+        void* pb = sb ? nullptr : wb;
+        if (pf || pb) return tdx_conv3_pack_weight(w, pf, pb, Cin, Cout, TDX_F32, stream);
+        return tdx_launch_status();
+    }
     const int lf = conv3_layout_kc(dtype, Cin, Cout), lb = conv3_layout_kc(dtype, Cout, Cin);
     if (dtype == TDX_BF16 && (lf || !wf) && (lb || !wb) && (Cin % 16) == 0 && (Cout % 16) == 0) {
         hipLaunchKernelGGL(conv3_pack_tiled_kernel, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
@@ -430,6 +470,11 @@ extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, con
     TDX_CHECK_ARG(x1 && wf && y && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && C2 >= 0 && Cout > 0);
     TDX_CHECK_ARG(C2 == 0 || x2);
     Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
+    if (dtype == TDX_F32 && impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(C1 + C2, 0, Cout)) {
+        // the operand was packed as split images (layout is a function of (K, N)); both inputs must be sliceable
+        if (!conv3_mfma_split_supported(C1, C2, Cout)) return TDX_ESHAPE;
+        return conv3_mfma_split_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));
+    }
     if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT && conv3_mfma_f32_supported(C1, C2, Cout))
         return conv3_mfma_f32_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));
     const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout));
@@ -523,6 +568,8 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
                                    nface, total);
             return tdx_launch_status();
         }
+    } else if (dtype == TDX_F32 && impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin)) {
+        rc = conv3_mfma_split_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream));
     } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT && conv3_mfma_f32_supported(Cout, 0, Cin)) {
         rc = conv3_mfma_f32_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream));
     } else {

@@ -17,7 +17,8 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("TDX_LIB", _HERE / "libtdx_hip.so"))  # TDX_LIB: kernel-development builds
 
 F32, BF16 = 0, 1
-CONV_AUTO, CONV_DIRECT, CONV_MFMA = 0, 1, 2
+CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_SPLIT = 0, 1, 2, 3
+F32_SPLIT = 2  # TDX_F32_SPLIT: pack code of fp32 weights for CONV_SPLIT
 WS_CLEAN = 0x100  # TDX_WS_CLEAN (include/tdx.h)
 
 _vp, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
@@ -105,7 +106,15 @@ def dtype_code(dt: torch.dtype) -> int:
 
 
 def conv_impl() -> int:
-    return {"auto": CONV_AUTO, "direct": CONV_DIRECT, "mfma": CONV_MFMA}[os.environ.get("TDX_CONV_IMPL", "auto")]
+    return {"auto": CONV_AUTO, "direct": CONV_DIRECT, "mfma": CONV_MFMA, "split": CONV_SPLIT}[os.environ.get("TDX_CONV_IMPL", "auto")]
+
+
+def pack_code(dt: torch.dtype) -> int:
+    """dtype code for tdx_conv3_pack_weight: fp32 weights are packed as bf16 hi + lo images under
+    TDX_CONV_IMPL=split (split-precision MFMA convs for fp32 tensors)."""
+    if dt == torch.float32 and conv_impl() == CONV_SPLIT:
+        return F32_SPLIT
+    return dtype_code(dt)
 
 
 def ptr(t: torch.Tensor | None):

@@ -210,7 +210,8 @@ _pack_cache: dict = {}
 
 
 def _packed_conv3(weight: torch.Tensor, dtype: torch.dtype):
-    key = (id(weight), dtype)
+    code = L.pack_code(dtype)
+    key = (id(weight), dtype, code)
     hit = _pack_cache.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
         return hit[3], hit[4]
@@ -218,7 +219,7 @@ def _packed_conv3(weight: torch.Tensor, dtype: torch.dtype):
     w = weight.detach().contiguous()
     wf = torch.empty(27 * Cin * Cout, dtype=dtype, device=w.device)
     wb = torch.empty(27 * Cin * Cout, dtype=dtype, device=w.device)
-    L.call("tdx_conv3_pack_weight", L.ptr(w), L.ptr(wf), L.ptr(wb), Cin, Cout, L.dtype_code(dtype), L.stream())
+    L.call("tdx_conv3_pack_weight", L.ptr(w), L.ptr(wf), L.ptr(wb), Cin, Cout, code, L.stream())
     if len(_pack_cache) > 4096:
         _pack_cache.clear()
     _pack_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wf, wb)
@@ -228,14 +229,15 @@ def _packed_conv3(weight: torch.Tensor, dtype: torch.dtype):
 def _packed_conv3_cin_slice(weight: torch.Tensor, lo: int, hi: int, dtype: torch.dtype):
     """Forward operand of conv3 restricted to input channels [lo, hi) of `weight`, cached like
     _packed_conv3 (keyed on the full parameter's version)."""
-    key = (id(weight), dtype, lo, hi)
+    code = L.pack_code(dtype)
+    key = (id(weight), dtype, lo, hi, code)
     hit = _pack_cache.get(key)
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr():
         return hit[3]
     Cout, Cin = weight.shape[0], hi - lo
     w = weight.detach()[:, lo:hi].contiguous()
     wf = torch.empty(27 * Cin * Cout, dtype=dtype, device=w.device)
-    L.call("tdx_conv3_pack_weight", L.ptr(w), L.ptr(wf), None, Cin, Cout, L.dtype_code(dtype), L.stream())
+    L.call("tdx_conv3_pack_weight", L.ptr(w), L.ptr(wf), None, Cin, Cout, code, L.stream())
     _pack_cache[key] = (weakref.ref(weight), weight._version, weight.data_ptr(), wf, None)
     return wf
 

@@ -42,7 +42,14 @@ extern "C" {
 /* conv3 implementation selector (tdx_conv3_*'s `impl` argument) */
 #define TDX_CONV_AUTO 0    /* MFMA implicit GEMM when dtype/shape allow, else direct     */
 #define TDX_CONV_DIRECT 1  /* vector-ALU reference kernels (any dtype)                    */
-#define TDX_CONV_MFMA 2    /* MFMA implicit GEMM (bf16 only); TDX_ESHAPE if unsupported  */
+#define TDX_CONV_MFMA 2    /* MFMA implicit GEMM; TDX_ESHAPE if unsupported               */
+#define TDX_CONV_SPLIT 3   /* fp32 tensors only: split-precision MFMA -- every operand as bf16 hi + lo,
+                              x*w ~= xh*wh + xl*wh + xh*wl with fp32 accumulation (~4e-6 rel-L2 per layer
+                              instead of ~3e-7; inside the 1e-4 gate, 2-3x faster than the fp32 MFMA).
+                              Operands must come from tdx_conv3_pack_weight(dtype = TDX_F32_SPLIT); shapes the
+                              split kernel does not cover run as TDX_CONV_AUTO                */
+/* dtype code accepted by tdx_conv3_pack_weight only: fp32 weights packed for TDX_CONV_SPLIT */
+#define TDX_F32_SPLIT 2
 /* OR-able into `impl` of tdx_conv3_fwd_gn and tdx_conv3_bwd_weight: the caller guarantees that the
  * workspace is all-zero on entry; the call skips its memsets and, as always, leaves the workspace
  * all-zero on exit (the kernels that read the accumulators clear them).  Lets a host keep one

@@ -84,13 +84,13 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("mode", ["f32-direct", "f32-auto", "bf16-direct", "bf16-auto"])
+@pytest.mark.parametrize("mode", ["f32-direct", "f32-auto", "f32-split", "bf16-direct", "bf16-auto"])
 def test_conv3_fwd_bwd(case, mode, monkeypatch):
     from turbdiff_amd import ops
 
     B, C1, C2, Cout, X, Y, Z = case
     dtype = torch.float32 if mode.startswith("f32") else torch.bfloat16
-    monkeypatch.setenv("TDX_CONV_IMPL", "direct" if mode.endswith("direct") else "auto")
+    monkeypatch.setenv("TDX_CONV_IMPL", mode.split("-")[1])
     Cin = C1 + C2
     x = q(rnd(B, Cin, X, Y, Z, seed=1), dtype)
     w = q(rnd(Cout, Cin, 3, 3, 3, seed=2, scale=1 / math.sqrt(27 * Cin)), dtype)
@@ -108,7 +108,8 @@ def test_conv3_fwd_bwd(case, mode, monkeypatch):
     bd = b.to(dev()).requires_grad_()
     y = ops.conv3(x1, wd, bd, x2=x2)
     y.backward(nvc(gy).to(dev()).to(dtype))
-    tol = tol_for(dtype)
+    # split-precision MFMA (bf16 hi + lo operands): ~4e-6 per layer, gated at 2e-5
+    tol = 2e-5 if mode == "f32-split" else tol_for(dtype)
     assert rel_l2(ncv(y.float().cpu()), yr) < tol
     gx = torch.cat([x1.grad] + ([x2.grad] if C2 else []), dim=-1)
     assert rel_l2(ncv(gx.float().cpu()), xr.grad) < tol

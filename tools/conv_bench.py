@@ -74,11 +74,13 @@ def main():
     ap.add_argument("--miopen", action="store_true", help="time the same layers through F.conv3d (MIOpen) instead")
     ap.add_argument("--miopen-find", action="store_true", help="with --miopen: torch.backends.cudnn.benchmark = True")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--impl", default="auto", choices=["auto", "direct", "mfma", "split"])
     a = ap.parse_args()
     if a.miopen:
         return miopen_table(a)
     dev = torch.device("cuda:0"); B = a.batch
     tdt, dc = (torch.bfloat16, 1) if a.dtype == "bf16" else (torch.float32, 0)
+    os.environ["TDX_CONV_IMPL"] = a.impl; im = L.conv_impl()
     tot = {"fwd": 0, "dgrad": 0, "wgrad": 0}; totf = 0
     print(f"{'layer':12s} {'Cin':>5s} {'Cout':>5s} {'grid':>12s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
     for name, C1, C2, Co, (X, Y, Z) in LAYERS:
@@ -93,13 +95,13 @@ def main():
         wf, wb = ops._packed_conv3(w, tdt)
         y = torch.empty(B, X, Y, Z, Co, device=dev, dtype=tdt)
         st = L.stream()
-        f = lambda: L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Co, dc, 0, st)
+        f = lambda: L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Co, dc, im, st)
         gx1 = torch.empty_like(x1); gx2 = torch.empty_like(x2) if C2 else None
         ws = torch.empty(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, Ci, dc, 0), dtype=torch.uint8, device=dev)
-        d = lambda: L.call("tdx_conv3_bwd_data", L.ptr(gy), L.ptr(wb), L.ptr(gx1), C1, L.ptr(gx2), C2, 0, B, X, Y, Z, Co, dc, 0, L.ptr(ws), st)
+        d = lambda: L.call("tdx_conv3_bwd_data", L.ptr(gy), L.ptr(wb), L.ptr(gx1), C1, L.ptr(gx2), C2, 0, B, X, Y, Z, Co, dc, im, L.ptr(ws), st)
         gw = torch.empty_like(w); gb = torch.empty(Co, device=dev)
         ws2 = torch.empty(L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, 0), dtype=torch.uint8, device=dev)
-        wg = lambda: L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z, Co, dc, 0, L.ptr(ws2), st)
+        wg = lambda: L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z, Co, dc, im, L.ptr(ws2), st)
         fl = 54.0 * Ci * Co * B * X * Y * Z
         tf, td, tw = (timeit(f, 10), 1e9, 1e9) if a.fwd_only else (timeit(f), timeit(d), timeit(wg))
         mult = 4 if name == "center" else (2 if name in ("down.0.b1",) else 1)  # center x4; down.0.b1 == down.0.b2
