@@ -46,6 +46,10 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
                       const void* a2 = nullptr, const Conv3Ext* ext = nullptr);
 
 bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout);
+bool conv3_wgrad_mfma_split_supported(int C1, int C2, int Cout);
+int conv3_wgrad_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
+                                  int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs,
+                                  int* nslab_out);
 bool conv3_wgrad_mfma_f32_supported(int C1, int C2, int Cout);
 int conv3_wgrad_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp,
                                 float* dbias, int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs,

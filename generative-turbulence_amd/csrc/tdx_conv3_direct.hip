@@ -624,7 +624,13 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
                                                      conv3_wgrad_mfma_supported(C1, C2, Cout));
     int nslab = 0;
     const float* slab_ptr = nullptr;
-    if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT && conv3_wgrad_mfma_f32_supported(C1, C2, Cout)) {
+    if (dtype == TDX_F32 && impl == TDX_CONV_SPLIT && conv3_wgrad_mfma_split_supported(C1, C2, Cout)) {
+        float* slabs = dbw + ((Cout + 63) / 64) * 64;
+        int rc = conv3_wgrad_mfma_split_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs,
+                                               W3_MAX_SLABS, &nslab);
+        slab_ptr = slabs;
+        if (rc != TDX_OK) return rc;
+    } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT && conv3_wgrad_mfma_f32_supported(C1, C2, Cout)) {
         float* slabs = dbw + ((Cout + 63) / 64) * 64;
         int rc = conv3_wgrad_mfma_f32_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs,
                                              W3_MAX_SLABS, &nslab);

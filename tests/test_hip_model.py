@@ -143,7 +143,7 @@ def test_three_training_steps_golden(golden, fused):
         assert rel_l2(v.cpu(), g[f"final_sd/{k}"]) < 1e-5, k
 
 
-def test_full_size_forward_matches_oracle_fp32():
+def test_full_size_forward_matches_oracle_fp32(monkeypatch):
     """BASELINE config 2 geometry (192x64x48, dim 32, 4 levels, GN(8)), B = 1, fp32 mode,
     default-initialised weights (seed 0) vs the CPU oracle: the 1e-4 rel-L2 gate."""
     from turbdiff_amd.models.ddpm import DenoisingModel
@@ -161,10 +161,48 @@ def test_full_size_forward_matches_oracle_fp32():
         net.to(dev())
         y = net(x.to(dev()), t.to(dev()), cond(c_local))
     assert rel_l2(y.cpu(), ref) < 1e-4
+    # fp32 tensors with split-precision (bf16 hi + lo, 3 MFMAs per product) convs: same 1e-4 gate
+    monkeypatch.setenv("TDX_CONV_IMPL", "split")
+    with torch.no_grad():
+        ys = net(x.to(dev()), t.to(dev()), cond(c_local))
+    monkeypatch.delenv("TDX_CONV_IMPL")
+    assert rel_l2(ys.cpu(), ref) < 1e-4 and not torch.equal(ys, y)
     net.set_compute_dtype(torch.bfloat16)
     with torch.no_grad():
         yb = net(x.to(dev()), t.to(dev()), cond(c_local))
     assert rel_l2(yb.cpu(), ref) < 3e-2
+
+
+def test_split_precision_training_step_vs_oracle(monkeypatch):
+    """dim 32, 3 levels, 48x32x24, B = 2: loss and every parameter gradient of p_losses with
+    TDX_CONV_IMPL=split (fp32 tensors, bf16 hi + lo MFMA convs) against the CPU oracle."""
+    from turbdiff_amd.models.ddpm import DenoisingModel, GaussianDiffusion
+
+    torch.manual_seed(1)
+    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=10, dim=32,
+                         u_net_levels=3, norm_type="group")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 4, 48, 32, 24, generator=gen)
+    c_local = torch.randn(4, 48, 32, 24, generator=gen)
+    noise = torch.randn(2, 4, 48, 32, 24, generator=gen)
+    t = torch.tensor([3, 8])
+    inside = torch.zeros(48, 32, 24, dtype=torch.bool)
+    inside[1:-1, 1:-1, 1:-1] = True
+    cell_idx = inside.flatten().nonzero().flatten()
+    # oracle with autograd on leaf copies of the parameters
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    buf = O.schedule_buffers("log-snr-linear", 10)
+    ref_loss, _ = O.p_losses(leaves, buf, x, t, c_local, cell_idx, noise, timesteps=10, noise_bcs=True)
+    ref_loss.backward()
+    monkeypatch.setenv("TDX_CONV_IMPL", "split")
+    diff = GaussianDiffusion(net, timesteps=10, beta_schedule="log-snr-linear", noise_bcs=True).to(dev())
+    loss, _ = diff.p_losses(x.to(dev()), t.to(dev()), cond(c_local), SimpleNamespace(cell_idx=cell_idx.to(dev())), None,
+                            noise=noise.to(dev()))
+    loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item())
+    for name, p in net.named_parameters():
+        assert_grad_close(name, p.grad.cpu(), leaves[name].grad, 1e-3)
 
 
 def test_sampling_is_linear_in_boundary_values_property():

@@ -16,7 +16,11 @@ with torch.no_grad():
     ref = O.denoiser(sd, x, t, c, timesteps=500)
     net.to(d)
     y32 = net(x.to(d), t.to(d), C)
+    import os
+    os.environ["TDX_CONV_IMPL"] = "split"   # fp32 tensors, split-precision (bf16 hi + lo) MFMA convs
+    y32s = net(x.to(d), t.to(d), C)
+    del os.environ["TDX_CONV_IMPL"]
     net.set_compute_dtype(torch.bfloat16)
     y16 = net(x.to(d), t.to(d), C)
     y16c = net(x.to(d), t.to(d), C, encoded_local=net.encode_local(C))
-print("rel-L2 vs CPU oracle at 192x64x48: fp32 mode %.2e, bf16 mode %.2e, bf16 + cached conditioning conv %.2e" % (rel_l2(y32.cpu(), ref), rel_l2(y16.cpu(), ref), rel_l2(y16c.cpu(), ref)))
+print("rel-L2 vs CPU oracle at 192x64x48: fp32 mode %.2e, fp32 tensors + split-precision convs %.2e, bf16 mode %.2e, bf16 + cached conditioning conv %.2e" % (rel_l2(y32.cpu(), ref), rel_l2(y32s.cpu(), ref), rel_l2(y16.cpu(), ref), rel_l2(y16c.cpu(), ref)))
