@@ -14,6 +14,13 @@ int conv1_mfma_fwd_launch(const void* x1, int C1, const void* x2, int C2, const 
 bool conv1_wgrad_mfma_supported(int Cin, int Cout);
 int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
                             int64_t rows, hipStream_t st);
+// fp32 MFMA versions (tdx_conv1_mfma_f32.hip)
+bool conv1_mfma_f32_supported(int C1, int C2, int Cout, const float* w, int ldw);
+int conv1_mfma_f32_fwd_launch(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
+                              const void* add, void* y, int64_t rows, int Cout, hipStream_t st);
+bool conv1_wgrad_mfma_f32_supported(int Cin, int Cout, int ldw);
+int conv1_wgrad_mfma_f32_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
+                                int64_t rows, hipStream_t st);
 static bool conv1_force_direct() {
     const char* e = getenv("TDX_CONV1_IMPL");
     return e && e[0] == 'd';
@@ -99,6 +106,8 @@ extern "C" int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, con
     TDX_CHECK_ARG(C2 == 0 || x2);
     if (dtype == TDX_BF16 && !conv1_force_direct() && conv1_mfma_supported(C1, C2, Cout))
         return conv1_mfma_fwd_launch(x1, C1, x2, C2, w, ldw, bias, add, y, rows, Cout, as_stream(stream));
+    if (dtype == TDX_F32 && !conv1_force_direct() && conv1_mfma_f32_supported(C1, C2, Cout, w, ldw))
+        return conv1_mfma_f32_fwd_launch(x1, C1, x2, C2, w, ldw, bias, add, y, rows, Cout, as_stream(stream));
     dim3 grid(ceil_div(rows, C1_BM), ceil_div(Cout, C1_BN));
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_fwd_kernel<T>), grid, dim3(256), 0, as_stream(stream),
                                                   (const T*)x1, C1, (const T*)x2, C2, w, ldw, bias, (const T*)add,
@@ -181,6 +190,8 @@ extern "C" int tdx_conv1_bwd_weight(const void* x, int Cin, const void* dy, int 
     }
     if (dtype == TDX_BF16 && !conv1_force_direct() && conv1_wgrad_mfma_supported(Cin, Cout))
         return conv1_wgrad_mfma_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, st);
+    if (dtype == TDX_F32 && !conv1_force_direct() && conv1_wgrad_mfma_f32_supported(Cin, Cout, ldw))
+        return conv1_wgrad_mfma_f32_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, st);
     dim3 grid(ceil_div(rows, C1W_ROWS), ceil_div(Cin, C1_BM), ceil_div(Cout, C1_BN));
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_wgrad_kernel<T>), grid, dim3(256), 0, st, (const T*)x, Cin,
                                                   (const T*)dy, Cout, dw, ldw, dbias, rows));

@@ -80,6 +80,38 @@ __global__ void conv3_pack_split_kernel(const float* __restrict__ w, bf16* __res
     }
 }
 
+// tiled variant of the split pack (both operands split, Cin % 16 == 0 and Cout % 16 == 0): as
+// conv3_pack_tiled_kernel, writing a hi and a lo image
+__global__ void __launch_bounds__(256)
+conv3_pack_split_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wb, int Cin, int Cout) {
+    __shared__ float t[16][16 * 27 + 1];  // [co][ci*27 + tap]
+    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
+    const int tid = threadIdx.x;
+    const int64_t n = (int64_t)Cout * Cin * 27;
+    for (int i = tid; i < 16 * 432; i += 256) {
+        const int co = i / 432, r = i - co * 432;
+        t[co][r] = w[((int64_t)(co0 + co) * Cin + ci0) * 27 + r];
+    }
+    __syncthreads();
+    const int row = tid >> 4, k = tid & 15;
+    for (int tap = 0; tap < 27; ++tap) {
+        {   // wf: row = co, k = ci
+            const float v = t[row][k * 27 + tap];
+            const bf16 hi = __float2bfloat16(v);
+            const int64_t j = ((((int64_t)(ci0 >> 4) * 27 + tap) * Cout + co0 + row) << 4) + k;
+            wf[j] = hi;
+            wf[n + j] = __float2bfloat16(v - __bfloat162float(hi));
+        }
+        {   // wb: row = ci, k = co
+            const float v = t[k][row * 27 + tap];
+            const bf16 hi = __float2bfloat16(v);
+            const int64_t j = ((((int64_t)(co0 >> 4) * 27 + (26 - tap)) * Cin + ci0 + row) << 4) + k;
+            wb[j] = hi;
+            wb[n + j] = __float2bfloat16(v - __bfloat162float(hi));
+        }
+    }
+}
+
 extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream) {
     TDX_CHECK_ARG(w && (wf || wb) && Cin > 0 && Cout > 0);
     const int64_t n = (int64_t)Cout * Cin * 27;
@@ -88,7 +120,10 @@ extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin
         // layout decision here), else the plain fp32 operand
         void* sf = (wf && conv3_mfma_split_supported(Cin, 0, Cout)) ? wf : nullptr;
         void* sb = (wb && conv3_mfma_split_supported(Cout, 0, Cin)) ? wb : nullptr;
-        if (sf || sb) {
+        if (sf && sb) {
+            hipLaunchKernelGGL(conv3_pack_split_tiled_kernel, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
+                               (bf16*)sf, (bf16*)sb, Cin, Cout);
+        } else if (sf || sb) {
             int grid = (int)min((int64_t)1024, (n + 255) / 256);
             hipLaunchKernelGGL(conv3_pack_split_kernel, dim3(grid), dim3(256), 0, as_stream(stream), w, (bf16*)sf, (bf16*)sb,
                                Cin, Cout);
