@@ -89,6 +89,56 @@ def test_conv3_mfma_vs_direct_random(grid, C1, C2, Co, B, extras, seed):
         assert rel_l2(a.float().cpu(), b.float().cpu()) < tols[n], (n, grid, C1, C2, Co, B)
 
 
+@pytest.mark.parametrize("impl_name", ["auto", "split"])
+@pytest.mark.parametrize("grid,C1,C2,Co,B,extras,seed", _cases(14, 4321))
+def test_conv3_fp32_mfma_and_split_vs_direct_random(grid, C1, C2, Co, B, extras, seed, impl_name, monkeypatch):
+    """fp32 tensors: the IEEE-fp32 MFMA kernels (auto) and the split-precision kernels (split) against the
+    vector-ALU kernels on random ragged / thin / tiny grids and channel mixes (two inputs, partly filled tiles)."""
+    from turbdiff_amd import _lib as L, ops
+
+    monkeypatch.setenv("TDX_CONV_IMPL", impl_name)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    d = torch.device("cuda:0")
+    X, Y, Z = grid
+    Ci = C1 + C2
+    rn = lambda *s: torch.randn(*s, device=d, generator=g)
+    x1, x2 = rn(B, X, Y, Z, C1), (rn(B, X, Y, Z, C2) if C2 else None)
+    w = rn(Co, Ci, 3, 3, 3) * (2.0 / (27 * Ci)) ** 0.5
+    bias, gy = rn(Co), rn(B, X, Y, Z, Co)
+    st = L.stream()
+
+    def run(impl):
+        monkeypatch.setenv("TDX_CONV_IMPL", {L.CONV_DIRECT: "direct", L.CONV_AUTO: "auto", L.CONV_SPLIT: "split"}[impl])
+        wf, wb = ops._packed_conv3(w, torch.float32)  # layout follows the mode (split images / kc = 8 / generic)
+        y = torch.empty(B, X, Y, Z, Co, device=d)
+        L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Co, L.F32, impl, st)
+        gx1, gx2 = torch.empty_like(x1), (torch.empty_like(x2) if C2 else None)
+        dws = torch.empty(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, Ci, L.F32, impl), dtype=torch.uint8, device=d)
+        if extras:
+            L.call("tdx_conv3_bwd_data_add", L.ptr(gy), L.ptr(wb), L.ptr(gx1), C1, L.ptr(gx2), C2, L.ptr(x1), L.ptr(x2), B, X, Y, Z,
+                   Co, L.F32, impl, L.ptr(dws), st)
+        else:
+            L.call("tdx_conv3_bwd_data", L.ptr(gy), L.ptr(wb), L.ptr(gx1), C1, L.ptr(gx2), C2, 0, B, X, Y, Z, Co, L.F32, impl,
+                   L.ptr(dws), st)
+        gw, gb = torch.empty_like(w), torch.empty(Co, device=d)
+        wws = torch.zeros(L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, impl), dtype=torch.uint8, device=d)
+        L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z, Co, L.F32,
+               impl | (L.WS_CLEAN if extras else 0), L.ptr(wws), st)
+        if extras:
+            assert int(wws[: 27 * Ci * Co * 4 + Co * 4].count_nonzero()) == 0  # accumulators left clean
+        return y, gx1, gx2, gw, gb
+
+    ref = run(L.CONV_DIRECT)
+    got = run(L.CONV_SPLIT if impl_name == "split" else L.CONV_AUTO)
+    tol = 2e-5 if impl_name == "split" else 3e-6
+    for n, a, b in zip(["y", "gx1", "gx2", "gw", "gb"], got, ref):
+        if a is None:
+            assert b is None
+            continue
+        assert torch.isfinite(a).all(), n
+        assert rel_l2(a.cpu(), b.cpu()) < (1e-5 if n == "gb" else tol), (n, grid, C1, C2, Co, B)
+
+
 def _small_cases(n, seed):
     rng = random.Random(seed)
     out = []
