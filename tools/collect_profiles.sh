@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
+BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra ${TDX_BENCH_ARGS:-}"
 # (1) per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 # (2)+(3) HBM traffic counters, one pass each (FETCH_SIZE and WRITE_SIZE do not fit one pass)

@@ -10,6 +10,7 @@ from pathlib import Path
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4  # 1 warm-up + 3 timed
+mode = sys.argv[3] if len(sys.argv) > 3 else "bf16"   # what TDX_BENCH_ARGS selected in collect_profiles.sh
 root = Path(__file__).resolve().parent.parent
 src = root / "gpurun_out" / f"prof_{tag}"
 dst = root / "profiles"
@@ -35,7 +36,7 @@ def counter_avgs(pattern):
 
 fetch, write, sq = counter_avgs("fetch/*/*counter_collection.csv"), counter_avgs("write/*/*counter_collection.csv"), counter_avgs("sq/*/*counter_collection.csv")
 mean = lambda v: sum(v) / max(len(v), 1)
-lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra` (B = 6, bf16, 192x64x48)", "",
+lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra` (B = 6, {mode}, 192x64x48)", "",
          f"Total kernel time {tot/1e6/steps:.2f} ms per step ({steps} steps incl. warm-up in the trace).", "",
          "| kernel | calls/step | ms/step | avg µs | % |", "|---|---|---|---|---|"]
 for r in rows[:28]:
@@ -45,7 +46,7 @@ lines += ["", "## HBM traffic and SQ counters of the matrix-core conv kernels (a
 traffic = {}
 durs = {r["Name"]: float(r["AverageNs"]) for r in rows}
 for k in sorted(set(list(fetch) + list(write))):
-    if "conv3_mfma_kernel" not in k and "wgrad_mfma" not in k:
+    if not any(t in k for t in ("conv3_mfma_kernel", "wgrad_mfma", "conv3_mfma_split", "conv3_mfma_f32", "conv1_f32_mfma")):
         continue
     f_kb = mean(fetch[k].get("FETCH_SIZE", [0])); w_kb = mean(write[k].get("WRITE_SIZE", [0]))
     rd, wr = 2 * f_kb * 1024, w_kb * 1024
