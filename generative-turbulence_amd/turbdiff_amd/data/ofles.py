@@ -192,3 +192,135 @@ class OpenFOAMBatch:
 
     data: OpenFOAMData
     stats: OpenFOAMStats
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Dataset and samplers (ofles.py:424-540).  The repository is any object with `times` (one array of sample
+# times per case file), `n_cases` and `read(file_idx, steps) -> OpenFOAMData`; the reference's HDF5-backed
+# OpenFOAMDataRepository (ofles.py:312-421) satisfies it, and so does InMemoryRepository below.  h5py is not
+# part of this package's requirements, so no file reader is provided.
+import math
+import random
+
+
+def _chunked(seq, n):
+    return [seq[i:i + n] for i in range(0, len(seq), n)]
+
+
+class InMemoryRepository:
+    """Cases held in memory: `cases[i]` = (OpenFOAMMetadata, times (T,), {Variable: (T, n_cells, dims) tensor})."""
+
+    def __init__(self, cases):
+        self.cases = cases
+        self.times = [np.asarray(c[1]) for c in cases]
+
+    @property
+    def n_cases(self):
+        return len(self.cases)
+
+    def reset_caches(self):
+        pass
+
+    def read(self, file_idx: int, samples):
+        meta, times, fields = self.cases[file_idx]
+        idx = torch.as_tensor(np.asarray(samples), dtype=torch.long)
+        return OpenFOAMData(meta, torch.as_tensor(np.asarray(times))[idx], {v: f[idx] for v, f in fields.items()})
+
+
+class OpenFOAMDataset(torch.utils.data.Dataset):
+    """ofles.py:424-479: flat sample index over all cases; a batch is a list of indices of ONE case."""
+
+    def __init__(self, repo, stats, discard_first_seconds: float):
+        super().__init__()
+        self.repo, self.stats, self.discard_first_seconds = repo, stats, discard_first_seconds
+        self.reset_caches()
+
+    def reset_caches(self):
+        self.repo.reset_caches()
+        self.valid_steps = [np.nonzero(np.asarray(t) > self.discard_first_seconds)[0] for t in self.repo.times]
+
+    def sample_idxs_by_file(self):
+        out, i = [], 0
+        for steps in self.valid_steps:
+            out.append(list(range(i, i + len(steps))))
+            i += len(steps)
+        return out
+
+    def __len__(self):
+        return sum(len(v) for v in self.valid_steps)
+
+    def __getitem__(self, index):
+        index = np.array([index] if isinstance(index, int) else index)
+        file_idx = 0
+        while index.min() >= len(self.valid_steps[file_idx]):
+            index = index - len(self.valid_steps[file_idx])
+            file_idx += 1
+        assert index.max() < len(self.valid_steps[file_idx]), "All samples have to be from the same geometry"
+        return OpenFOAMBatch(self.repo.read(file_idx, [self.valid_steps[file_idx][i] for i in index]), self.stats)
+
+    def get_times(self, file_idx: int, times):
+        t = np.round(np.asarray(self.repo.times[file_idx]) * 10_000).astype(int).tolist()  # tenths of milliseconds
+        return OpenFOAMBatch(self.repo.read(file_idx, [t.index(round(x * 10_000)) for x in times]), self.stats)
+
+
+class OpenFOAMSampler(torch.utils.data.Sampler):
+    """ofles.py:482-511, plus data-parallel sharding (shard at batch-list granularity).
+
+    With ``world_size == 1`` and ``seed is None`` it is the reference's sampler, draw for draw (it uses the
+    global ``random`` state).  With ``seed`` set, epoch e shuffles with ``random.Random(seed + e)`` -- the same
+    order on every rank -- and rank r takes batches r, r + W, ... of it; the list is extended by wrapping
+    around so that every rank gets the same number of batches (the gradient all-reduce needs lock-step)."""
+
+    def __init__(self, dataset, *, batch_size: int, shuffle: bool, rank: int = 0, world_size: int = 1, seed=None):
+        self.dataset, self.batch_size, self.shuffle = dataset, batch_size, shuffle
+        self.rank, self.world_size, self.seed, self.epoch = rank, world_size, seed, 0
+        if world_size > 1 and shuffle and seed is None:
+            raise ValueError("sharded shuffling needs a seed shared by all ranks")
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def _n_total(self):
+        return sum(math.ceil(len(s) / self.batch_size) for s in self.dataset.valid_steps)
+
+    def __len__(self):
+        return math.ceil(self._n_total() / self.world_size)
+
+    def __iter__(self):
+        rng = random if self.seed is None else random.Random(self.seed + self.epoch)
+        indices = self.dataset.sample_idxs_by_file()
+        if self.shuffle:
+            for idxs in indices:
+                rng.shuffle(idxs)
+        batches = []
+        for idxs in indices:
+            batches.extend(_chunked(idxs, self.batch_size))
+        if self.shuffle:
+            rng.shuffle(batches)
+        if self.world_size > 1:
+            n = len(self) * self.world_size
+            batches = (batches * math.ceil(n / len(batches)))[:n][self.rank::self.world_size]
+        yield from batches
+
+
+class OpenFOAMEvaluationSampler(torch.utils.data.Sampler):
+    """ofles.py:514-545: evenly spaced samples of every case; optionally sharded (whole batches per rank,
+    no padding: evaluation has no collective)."""
+
+    def __init__(self, dataset, *, batch_size: int, samples_per_file: int, rank: int = 0, world_size: int = 1):
+        self.dataset, self.batch_size, self.samples_per_file = dataset, batch_size, samples_per_file
+        self.rank, self.world_size = rank, world_size
+
+    def _batches(self):
+        batches = []
+        for idxs in self.dataset.sample_idxs_by_file():
+            pick = np.round(np.linspace(0, len(idxs) - 1, num=self.samples_per_file)).astype(int)
+            batches.extend(_chunked([idxs[i] for i in pick], self.batch_size))
+        return batches
+
+    def __len__(self):
+        n = self.dataset.repo.n_cases * math.ceil(self.samples_per_file / self.batch_size)
+        return len(range(self.rank, n, self.world_size))
+
+    def __iter__(self):
+        yield from self._batches()[self.rank::self.world_size]

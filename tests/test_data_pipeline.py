@@ -1,0 +1,171 @@
+"""Dataset / samplers / device staging (the part that does not need h5py): host logic against
+golden vectors from the reference's own classes (tests/golden/make_golden_sampler.py), sharding properties,
+and the staged batches on the GPU."""
+
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from turbdiff_amd.data.ofles import (InMemoryRepository, OpenFOAMBatch, OpenFOAMDataset, OpenFOAMEvaluationSampler,
+                                     OpenFOAMMetadata, OpenFOAMSampler, OpenFOAMStats, Variable)
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(GOLDEN / "samplers.npz")
+
+
+class FakeRepo:
+    def __init__(self, g):
+        self.times = [g[f"times/{i}"] for i in range(3)]
+        self.n_cases = 3
+
+    def reset_caches(self):
+        pass
+
+    def read(self, file_idx, samples):
+        return ("case", file_idx, [int(s) for s in samples])
+
+
+def unflat(sizes, idx):
+    out, i = [], 0
+    for n in sizes:
+        out.append([int(v) for v in idx[i:i + n]])
+        i += n
+    return out
+
+
+def test_dataset_matches_reference(g):
+    ds = OpenFOAMDataset(FakeRepo(g), "STATS", float(g["discard"]))
+    assert len(ds) == int(g["len"])
+    for i in range(3):
+        assert np.array_equal(ds.valid_steps[i], g[f"valid_steps/{i}"])
+    for i, batch in enumerate(([0], [3, 1, 2], [29 + 2, 29 + 0], [29 + 7 + 5])):
+        b = ds[list(batch)]
+        assert b.stats == "STATS" and b.data[1] == int(g["getitem/files"][i]) and b.data[2] == list(g[f"getitem/steps/{i}"])
+    assert ds.get_times(2, [0.1, 0.3]).data[2] == list(g["get_times/steps"])
+    with pytest.raises(AssertionError, match="same geometry"):
+        ds[[28, 29]]  # last sample of case 0 and first of case 1
+
+
+@pytest.mark.parametrize("bs", [1, 4, 6])
+def test_train_sampler_is_the_reference_sampler(g, bs):
+    ds = OpenFOAMDataset(FakeRepo(g), None, float(g["discard"]))
+    s = OpenFOAMSampler(ds, batch_size=bs, shuffle=False)
+    assert len(s) == int(g[f"train/bs{bs}/len"])
+    assert list(s) == unflat(g[f"train/bs{bs}/plain/sizes"], g[f"train/bs{bs}/plain/idx"])
+    random.seed(1000 + bs)  # the reference shuffles with the global RNG
+    s = OpenFOAMSampler(ds, batch_size=bs, shuffle=True)
+    assert list(s) == unflat(g[f"train/bs{bs}/shuffled/sizes"], g[f"train/bs{bs}/shuffled/idx"])
+
+
+@pytest.mark.parametrize("bs,spf", [(8, 8), (3, 5)])
+def test_eval_sampler_is_the_reference_sampler(g, bs, spf):
+    ds = OpenFOAMDataset(FakeRepo(g), None, float(g["discard"]))
+    s = OpenFOAMEvaluationSampler(ds, batch_size=bs, samples_per_file=spf)
+    assert len(s) == int(g[f"eval/bs{bs}_spf{spf}/len"])
+    assert list(s) == unflat(g[f"eval/bs{bs}_spf{spf}/sizes"], g[f"eval/bs{bs}_spf{spf}/idx"])
+    parts = [list(OpenFOAMEvaluationSampler(ds, batch_size=bs, samples_per_file=spf, rank=r, world_size=3)) for r in range(3)]
+    assert sorted(map(tuple, sum(parts, []))) == sorted(map(tuple, s)) and [len(p) for p in parts] == [
+        len(OpenFOAMEvaluationSampler(ds, batch_size=bs, samples_per_file=spf, rank=r, world_size=3)) for r in range(3)]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_train_sampler_properties(g, world):
+    ds = OpenFOAMDataset(FakeRepo(g), None, float(g["discard"]))
+    full = OpenFOAMSampler(ds, batch_size=4, shuffle=True, seed=11)
+    full.set_epoch(3)
+    ref = list(full)
+    shards = []
+    for r in range(world):
+        s = OpenFOAMSampler(ds, batch_size=4, shuffle=True, rank=r, world_size=world, seed=11)
+        s.set_epoch(3)
+        shards.append(list(s))
+        assert len(shards[-1]) == len(s)
+    assert len({len(s) for s in shards}) == 1                       # lock-step: same number of batches per rank
+    merged = [b for i in range(len(shards[0])) for b in (s[i] for s in shards)]
+    assert merged[: len(ref)] == ref                                # the ranks interleave the single-process order
+    assert all(b in ref for b in merged[len(ref):])                 # padding wraps around
+    assert all(len({i >= 29 for i in b}) == 1 for b in merged)      # every batch stays inside one case
+    other = OpenFOAMSampler(ds, batch_size=4, shuffle=True, seed=11)
+    other.set_epoch(4)
+    assert list(other) != ref                                       # epochs reshuffle
+    with pytest.raises(ValueError):
+        OpenFOAMSampler(ds, batch_size=4, shuffle=True, rank=0, world_size=2)
+
+
+def _cases():
+    gen = torch.Generator().manual_seed(0)
+    cases = []
+    for n, counts in ((5, (6, 5, 4)), (3, (5, 5, 5))):
+        inside = torch.zeros(counts, dtype=torch.bool)
+        inside[1:-1, 1:-1, 1:-1] = True
+        cell_idx = inside.flatten().nonzero().flatten()
+        meta = OpenFOAMMetadata(np.array(counts), cell_idx, {"walls": {"idx": torch.tensor([0, 1])}}, {})
+        cases.append((meta, np.arange(n) * 0.1, {Variable.U: torch.randn(n, len(cell_idx), 3, generator=gen),
+                                                 Variable.P: torch.randn(n, len(cell_idx), 1, generator=gen)}))
+    return cases
+
+
+def test_in_memory_repository_feeds_the_dataset():
+    stats = OpenFOAMStats({"u": {"mean": torch.zeros(3), "std": torch.ones(3)}, "p": {"mean": torch.tensor(0.0), "std": torch.tensor(1.0)}})
+    cases = _cases()
+    ds = OpenFOAMDataset(InMemoryRepository(cases), stats, discard_first_seconds=0.05)
+    assert len(ds) == 4 + 2
+    b = ds[[1, 3]]
+    assert isinstance(b, OpenFOAMBatch) and b.data.n_samples == 2 and b.data.metadata is cases[0][0]
+    assert torch.equal(b.data.samples[Variable.U], cases[0][2][Variable.U][[2, 4]])
+    assert torch.allclose(b.data.t, torch.tensor([0.2, 0.4], dtype=b.data.t.dtype))
+
+
+@pytest.mark.gpu
+def test_device_stager_delivers_the_batches_in_order():
+    from turbdiff_amd.data.staging import DeviceStager
+
+    stats = OpenFOAMStats({"u": {"mean": torch.zeros(3), "std": torch.ones(3)}, "p": {"mean": torch.tensor(0.0), "std": torch.tensor(1.0)}})
+    ds = OpenFOAMDataset(InMemoryRepository(_cases()), stats, discard_first_seconds=-1.0)
+    order = list(OpenFOAMSampler(ds, batch_size=2, shuffle=False)) * 3
+    want = [ds[b] for b in order]
+    got = list(DeviceStager((ds[b] for b in order), "cuda:0"))
+    assert len(got) == len(want)
+    metas = set()
+    for a, b in zip(got, want):
+        for v in (Variable.U, Variable.P):
+            assert a.data.samples[v].is_cuda and torch.equal(a.data.samples[v].cpu(), b.data.samples[v])
+        assert a.data.metadata.cell_idx.is_cuda and torch.equal(a.data.metadata.cell_idx.cpu(), b.data.metadata.cell_idx)
+        metas.add(id(a.data.metadata))
+        x = a.data.grid_embedding((Variable.U, Variable.P))  # the staged batch feeds the ingress kernel
+        assert x.shape[0] == a.data.n_samples and torch.isfinite(x).all()
+    assert len(metas) == 2  # each geometry moved to the device once
+
+
+@pytest.mark.gpu
+def test_trainer_runs_from_dataset_sampler_and_stager():
+    """The whole caller chain on the device: repository -> dataset -> (sharded) sampler -> pinned staging ->
+    DiffusionTrainer.fit_step (fused ingress, U-Net step, ClipRAdam)."""
+    from turbdiff_amd.data.staging import DeviceStager
+    from turbdiff_amd.training import DiffusionTrainer
+
+    gen = torch.Generator().manual_seed(1)
+    counts = (12, 10, 9)
+    inside = torch.zeros(counts, dtype=torch.bool)
+    inside[1:-1, 1:-1, 1:-1] = True
+    cell_idx = inside.flatten().nonzero().flatten()
+    idx = torch.arange(inside.numel()).reshape(counts)
+    from turbdiff_amd.data.ofles import BoundaryCondition as BC
+
+    meta = OpenFOAMMetadata(np.array(counts), cell_idx, {"walls": {"idx": idx[:, 0].flatten()}, "inlets": {"idx": idx[0].flatten()}},
+                            {Variable.U: {"inlets": BC(BC.Type.FIXED_VALUE, torch.tensor([1.0, 0.0, 0.0]))}})
+    fields = {Variable.U: torch.randn(8, len(cell_idx), 3, generator=gen), Variable.P: torch.randn(8, len(cell_idx), 1, generator=gen)}
+    stats = OpenFOAMStats({"u": {"mean": torch.zeros(3), "std": torch.ones(3) * 1.5}, "p": {"mean": torch.tensor(0.1), "std": torch.tensor(0.8)}})
+    ds = OpenFOAMDataset(InMemoryRepository([(meta, np.arange(8) * 0.1, fields)]), stats, discard_first_seconds=-1.0)
+    sampler = OpenFOAMSampler(ds, batch_size=2, shuffle=True, rank=1, world_size=2, seed=5)
+    torch.manual_seed(0)
+    tr = DiffusionTrainer(dim=8, timesteps=10, u_net_levels=2, variables=("u", "p"), normalization_mode="mean-std",
+                          max_train_steps=10).to("cuda:0")
+    losses = [tr.fit_step(b).item() for b in DeviceStager((ds[i] for i in sampler), "cuda:0")]
+    assert len(losses) == len(sampler) == 2 and all(np.isfinite(losses))
+    assert tr.cell_type_embedding.embedding.weight.grad is None or torch.isfinite(tr.cell_type_embedding.embedding.weight).all()
