@@ -529,6 +529,22 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     impl &= 0xff;
     const bool use_mfma =
         dtype == TDX_BF16 && (impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout)));
+    const bool f32_split = dtype == TDX_F32 && impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(C1 + C2, 0, Cout);
+    const bool f32_mfma = dtype == TDX_F32 && !f32_split && impl != TDX_CONV_DIRECT && conv3_mfma_f32_supported(C1, C2, Cout);
+    if (f32_split || f32_mfma) {  // fp32 tensors: the MFMA kernels accumulate the moments in their store loop too
+        if (f32_split && !conv3_mfma_split_supported(C1, C2, Cout)) return TDX_ESHAPE;
+        hipStream_t st = as_stream(stream);
+        double* acc = (double*)gn_workspace;
+        if (!clean) {
+            hipError_t e = hipMemsetAsync(acc, 0, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
+            if (e != hipSuccess) return (int)e;
+        }
+        Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
+        int rc = f32_split ? conv3_mfma_split_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, st, acc)
+                           : conv3_mfma_f32_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, st, acc);
+        if (rc != TDX_OK) return rc;
+        return gn_finalize_launch(acc, stats, B, Cout, G, (int64_t)X * Y * Z, eps, TDX_GN_REPLICAS, st);
+    }
     if (!use_mfma) {  // unfused: conv, then the streaming statistics pass
         int rc = tdx_conv3_fwd(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, dtype, impl, stream);
         if (rc != TDX_OK) return rc;

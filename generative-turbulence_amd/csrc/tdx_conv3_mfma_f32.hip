@@ -43,7 +43,7 @@ template <int NT, bool ZERO_PAD>
 __global__ void __launch_bounds__(256, 2)
 conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
                       const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, ConvViewF g,
-                      int Cout) {
+                      int Cout, double* __restrict__ gn_acc) {
     constexpr int BN = NT * 32;
     constexpr int BX = 4, BY = 8, BZ = 8;
     constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
@@ -196,7 +196,8 @@ conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restr
             }
         }
     __syncthreads();
-    constexpr int CHUNKS = BN / 4;  // 16-B chunks per voxel row
+    constexpr int CHUNKS = BN / 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};  // GroupNorm moments of this thread's 4 channels  // 16-B chunks per voxel row
 #pragma unroll
     for (int i = 0; i < CHUNKS; ++i) {
         const int p = tid + i * 256;
@@ -204,13 +205,39 @@ conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restr
         const int c0 = o0 + (v >> 3) / BY, c1 = o1 + (v >> 3) % BY, c2 = o2 + (v & 7);
         if (c0 < g.Eo[0] && c1 < g.Eo[1] && c2 < g.Eo[2]) {
             const int64_t ov = (((int64_t)b * g.Eo[0] + c0) * g.Eo[1] + c1) * g.Eo[2] + c2;
-            *reinterpret_cast<float4*>(y + ov * Cout + n0 + cidx * 4) = *reinterpret_cast<const float4*>(sO + outf_addr<BN>(v, cidx));
+            const float4 val = *reinterpret_cast<const float4*>(sO + outf_addr<BN>(v, cidx));
+            *reinterpret_cast<float4*>(y + ov * Cout + n0 + cidx * 4) = val;
+            if (gn_acc != nullptr) {
+                s1[0] += val.x; s2[0] += val.x * val.x; s1[1] += val.y; s2[1] += val.y * val.y;
+                s1[2] += val.z; s2[2] += val.z * val.z; s1[3] += val.w; s2[3] += val.w * val.w;
+            }
+        }
+    }
+    if (gn_acc != nullptr) {
+        // per-channel moments of the tile (tdx_conv3_fwd_gn): threads with equal tid % CHUNKS hold the same 4
+        // channels; LDS reduce behind the output tile, then one f64 atomic per channel and moment into one of
+        // TDX_GN_REPLICAS tables (as the bf16 kernel)
+        constexpr int NP = 256 / CHUNKS;
+        float* red = reinterpret_cast<float*>(smem + 256 * BN * 4);  // [NP][BN][2]
+        const int cidx = tid % CHUNKS, part = tid / CHUNKS;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[(part * BN + cidx * 4 + e) * 2] = s1[e];
+            red[(part * BN + cidx * 4 + e) * 2 + 1] = s2[e];
+        }
+        __syncthreads();
+        if (tid < BN * 2) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int pp = 0; pp < NP; ++pp) t += red[pp * BN * 2 + tid];
+            const int rep = blockIdx.x & (TDX_GN_REPLICAS - 1);
+            atomicAdd(&gn_acc[(((size_t)rep * g.B + b) * Cout + n0) * 2 + tid], (double)t);
         }
     }
 }
 
 int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
-                          const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st) {
+                          const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
     ConvViewF v;
@@ -231,7 +258,7 @@ int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const 
             attr_set = true;                                                                                            \
         }                                                                                                               \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const float*)x1, C1, (const float*)x2, C2, (const float*)wp, \
-                           bias, (float*)y, v, Cout);                                                                   \
+                           bias, (float*)y, v, Cout, gn_acc);                                                                   \
     } while (0)
     if (NT == 2) { if (zero_pad) F3_GO(2, true); else F3_GO(2, false); }
     else { if (zero_pad) F3_GO(1, true); else F3_GO(1, false); }

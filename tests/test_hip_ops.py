@@ -396,14 +396,15 @@ def test_encode_decode_fused(dtype, with_c, D):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 0, 64, 9, 10, 7, 8), (1, 32, 32, 32, 8, 8, 8, 8), (2, 16, 0, 96, 5, 4, 3, 1), (1, 8, 0, 16, 6, 5, 4, 8)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_conv3_with_fused_gn_statistics(case, dtype):
+@pytest.mark.parametrize("dtype,impl", [(torch.float32, "auto"), (torch.float32, "split"), (torch.bfloat16, "auto")])
+def test_conv3_with_fused_gn_statistics(case, dtype, impl, monkeypatch):
     """tdx_conv3_fwd_gn: statistics accumulated in the conv epilogue == the streaming
     statistics pass over the stored conv output (ragged bricks included)."""
     from turbdiff_amd import ops
 
     B, C1, C2, Cout, X, Y, Z, G = case
     d = dev()
+    monkeypatch.setenv("TDX_CONV_IMPL", impl)
     x1 = rnd(B, X, Y, Z, C1, seed=1).to(d).to(dtype)
     x2 = rnd(B, X, Y, Z, C2, seed=2).to(d).to(dtype) if C2 else None
     w = rnd(Cout, C1 + C2, 3, 3, 3, seed=3, scale=0.05).to(d)
