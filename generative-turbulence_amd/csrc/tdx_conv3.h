@@ -28,10 +28,12 @@ static inline bool conv3_uses_mfma_layout(int dtype, int K, int N) { return dtyp
 // split-precision (bf16 hi + lo) MFMA forward / zero-padded data gradient for fp32 tensors (tdx_conv3_mfma_split.hip)
 bool conv3_mfma_split_supported(int C1, int C2, int Cout);
 int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
-                            const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr);
+                            const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr,
+                            void* d1 = nullptr, int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr, const void* a2 = nullptr);
 // fp32 MFMA forward / zero-padded data gradient (tdx_conv3_mfma_f32.hip)
 int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
-                          const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr);
+                          const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr,
+                          void* d1 = nullptr, int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr, const void* a2 = nullptr);
 
 // optional extras of the MFMA forward: input row strides (0: dense) and a tensor the accumulators
 // start from ([B][V][Cout] bf16, or [V][Cout] shared by the batch)

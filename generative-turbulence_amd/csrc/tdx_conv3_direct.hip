@@ -619,10 +619,22 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
                                    nface, total);
             return tdx_launch_status();
         }
-    } else if (dtype == TDX_F32 && impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin)) {
-        rc = conv3_mfma_split_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream));
-    } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT && conv3_mfma_f32_supported(Cout, 0, Cin)) {
-        rc = conv3_mfma_f32_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream));
+    } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT &&
+               ((impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin)) || conv3_mfma_f32_supported(Cout, 0, Cin))) {
+        // as the bf16 path: dx from the conv epilogue, the halo shell into the workspace, then the faces
+        const bool split = impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin);
+        rc = split ? conv3_mfma_split_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream), nullptr,
+                                             dx1, C1, dx2, add1, add2)
+                   : conv3_mfma_f32_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream), nullptr,
+                                           dx1, C1, dx2, add1, add2);
+        if (rc != TDX_OK) return rc;
+        const int nx = (X > 1) ? 2 : 1, ny = (Y > 1) ? 2 : 1, nz = (Z > 1) ? 2 : 1;
+        const int64_t nface = (int64_t)nx * Y * Z + (int64_t)ny * (X - nx) * Z + (int64_t)nz * (X - nx) * (Y - ny);
+        const int64_t total = (int64_t)B * nface * (Cin / 8);
+        if (total > 0)
+            hipLaunchKernelGGL((conv3_fold_faces_kernel<float>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
+                               (const float*)workspace, (float*)dx1, C1, (float*)dx2, C2, B, X, Y, Z, nface, total);
+        return tdx_launch_status();
     } else {
         rc = conv3_direct_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, dtype, true, as_stream(stream));
     }

@@ -60,7 +60,8 @@ template <int NT, bool ZERO_PAD>
 __global__ void __launch_bounds__(256, 1)
 conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
                         const bf16* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, ConvViewS g,
-                        int Cout, int64_t lo_offset, double* __restrict__ gn_acc) {
+                        int Cout, int64_t lo_offset, double* __restrict__ gn_acc, float* __restrict__ d1, int D1,
+                        float* __restrict__ d2, const float* __restrict__ a1, const float* __restrict__ a2) {
     constexpr int BN = NT * 32;
     constexpr int BX = 4, BY = 8, BZ = 8;
     constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
@@ -257,8 +258,28 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
         const int c0 = o0 + (v >> 3) / BY, c1 = o1 + (v >> 3) % BY, c2 = o2 + (v & 7);
         if (c0 < g.Eo[0] && c1 < g.Eo[1] && c2 < g.Eo[2]) {
             const int64_t ov = (((int64_t)b * g.Eo[0] + c0) * g.Eo[1] + c1) * g.Eo[2] + c2;
-            const float4 val = *reinterpret_cast<const float4*>(sO + outs_addr<BN>(v, cidx));
-            *reinterpret_cast<float4*>(y + ov * Cout + n0 + cidx * 4) = val;
+            float4 val = *reinterpret_cast<const float4*>(sO + outs_addr<BN>(v, cidx));
+            bool direct = false;
+            if (ZERO_PAD && d1 != nullptr) {
+                // data gradient: padded position = original voxel + 1.  Positions inside the original grid go
+                // straight to dx (split over the two inputs of a concatenated conv, plus the optional addend);
+                // only the halo shell is written to the padded workspace for the face fix-up
+                const int u0 = c0 - 1, u1 = c1 - 1, u2 = c2 - 1;
+                if (u0 >= 0 && u0 < g.Ei[0] && u1 >= 0 && u1 < g.Ei[1] && u2 >= 0 && u2 < g.Ei[2]) {
+                    const int64_t u = (((int64_t)b * g.Ei[0] + u0) * g.Ei[1] + u1) * g.Ei[2] + u2;
+                    const int n = n0 + cidx * 4;
+                    const bool lo = n < D1;
+                    float* dst = lo ? d1 + u * D1 + n : d2 + u * (Cout - D1) + (n - D1);
+                    const float* asrc = lo ? (a1 ? a1 + u * D1 + n : nullptr) : (a2 ? a2 + u * (Cout - D1) + (n - D1) : nullptr);
+                    if (asrc) {
+                        const float4 av = *reinterpret_cast<const float4*>(asrc);
+                        val.x += av.x; val.y += av.y; val.z += av.z; val.w += av.w;
+                    }
+                    *reinterpret_cast<float4*>(dst) = val;
+                    direct = true;
+                }
+            }
+            if (!direct) *reinterpret_cast<float4*>(y + ov * Cout + n0 + cidx * 4) = val;
             if (gn_acc != nullptr) {
                 s1[0] += val.x; s2[0] += val.x * val.x; s1[1] += val.y; s2[1] += val.y * val.y;
                 s1[2] += val.z; s2[2] += val.z * val.z; s1[3] += val.w; s2[3] += val.w * val.w;
@@ -289,7 +310,8 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
 }
 
 int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
-                            const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc) {
+                            const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
+                            const void* a1, const void* a2) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
     ConvViewS v;
@@ -311,7 +333,7 @@ int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, cons
             attr_set = true;                                                                                            \
         }                                                                                                               \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const float*)x1, C1, (const float*)x2, C2, (const bf16*)wp, \
-                           bias, (float*)y, v, Cout, lo_offset, gn_acc);                                                        \
+                           bias, (float*)y, v, Cout, lo_offset, gn_acc, (float*)d1, D1, (float*)d2, (const float*)a1, (const float*)a2);                                                        \
     } while (0)
     if (NT == 2) { if (zero_pad) SP_GO(2, true); else SP_GO(2, false); }
     else { if (zero_pad) SP_GO(1, true); else SP_GO(1, false); }
