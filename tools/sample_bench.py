@@ -20,9 +20,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--trajectories", type=int, default=8)
 ap.add_argument("--timesteps", type=int, default=1000)
 ap.add_argument("--steps", type=int, default=0, help="time only this many reverse steps and extrapolate (0 = full loop)")
-ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32s"])
 ap.add_argument("--no-graph", action="store_true")
 a = ap.parse_args()
+if a.dtype == "f32s":  # fp32 tensors, split-precision convs
+    import os
+    os.environ["TDX_CONV_IMPL"] = "split"
 rank, world, local = parallel.init_from_env("nccl")
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
