@@ -177,7 +177,11 @@ def main():
 
     from turbdiff_amd import _lib, parallel
 
-    rank, world, local = parallel.init_from_env("nccl")
+    # TDX_BENCH_BACKEND=gloo + TDX_BENCH_ONE_DEVICE=1: all ranks on cuda:0 with gloo collectives -- only for
+    # exercising the N > 1 code path on a one-GPU box (tests/test_bench_multirank.py); never a measurement
+    rank, world, local = parallel.init_from_env(os.environ.get("TDX_BENCH_BACKEND", "nccl"))
+    if os.environ.get("TDX_BENCH_ONE_DEVICE") == "1":
+        local = 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)

@@ -1,0 +1,32 @@
+"""bench.py's N > 1 path (torch.distributed.run launch, barrier + max-over-ranks timing, rank-0 JSON line,
+bucketed gradient all-reduce on the full-size model) exercised with two ranks sharing the test box's one GPU
+over gloo.  The numbers are meaningless; the code path is the one the driver runs on 2 / 4 / 8 GPUs."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_bench_two_ranks_one_gpu():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, TDX_BENCH_BACKEND="gloo", TDX_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
+           "--no-extra", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 2 * 1 * 192 * 64 * 48 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6  # whole-job aggregate
