@@ -206,28 +206,37 @@ conv3_wgrad_mfma_split_kernel(const float* __restrict__ x1, int C1, const float*
         for (int s2 = 0; s2 < WS_NSTEPS / 2; ++s2) {
             const int so = 2 * s2 + 1, sn = min(2 * s2 + 2, WS_NSTEPS - 1);
             const int off_o = step_off(so), off_n = step_off(sn);
+            // term-major MFMA order: one wave per SIMD, so an MFMA that accumulates onto the result of the MFMA
+            // right before it stalls ~12 cycles (tools/micro/mfma_peak: 1785 vs 2437 TFLOP/s); the three terms of a
+            // tap are issued 7 MFMAs apart.  The next step's fragments are fetched during the first term.
 #pragma unroll
             for (int t = 0; t < WS_TAPS; ++t) {  // even step: compute set 0, fetch set 1
                 read_a(off_o, t, A1h[t], A1l[t]);
                 if (t == 0) read_b(so, B1h, B1l);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0h[t], B0h, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0l[t], B0h, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0h[t], B0l, acc[t], 0, 0, 0);
                 if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
+#pragma unroll
+            for (int t = 0; t < WS_TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0l[t], B0h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < WS_TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0h[t], B0l, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * WS_TAPS, 0);
 #pragma unroll
             for (int t = 0; t < WS_TAPS; ++t) {  // odd step: compute set 1, fetch set 0
                 read_a(off_n, t, A0h[t], A0l[t]);
                 if (t == 0) read_b(sn, B0h, B0l);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1h[t], B1h, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1l[t], B1h, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1h[t], B1l, acc[t], 0, 0, 0);
                 if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
                 else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
+#pragma unroll
+            for (int t = 0; t < WS_TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1l[t], B1h, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < WS_TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1h[t], B1l, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * WS_TAPS, 0);
         }
     }
 

@@ -148,6 +148,8 @@ int main() {
         run("32x32x16 8 acc, 2 waves/SIMD", k32<8>, 512, 1000, 8 * f32, reps);
         run("32x32x16 2 acc, 2 waves/SIMD", k32<2>, 512, 4000, 2 * f32, reps);
         run("32x32x16 1 acc (dependent), 2 waves/SIMD", k32<1>, 512, 8000, 1 * f32, reps);
+        run("32x32x16 1 acc (dependent), 1 wave/SIMD", k32<1>, 256, 16000, 1 * f32, reps);
+        run("32x32x16 2 acc, 1 wave/SIMD", k32<2>, 256, 8000, 2 * f32, reps);
         run("16x16x32 4 acc, 2 waves/SIMD", k16<4>, 512, 4000, 4 * f16, reps);
         run("16x16x32 8 acc, 2 waves/SIMD", k16<8>, 512, 2000, 8 * f16, reps);
         run("32x32x16 4 acc, 4 waves/SIMD (1024 WG)", k32<4>, 1024, 1000, 4 * f32, reps);
