@@ -20,6 +20,8 @@
 // its 6 NT MFMAs, and the next slice's global loads are in flight during the whole MFMA phase.
 #include "tdx_common.h"
 #include "tdx_conv3.h"
+#include "tdx_conv3_brick.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -29,13 +31,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 bool conv3_mfma_split_supported(int C1, int C2, int Cout) {
     return C1 > 0 && (C1 % SP_KC) == 0 && (C2 % SP_KC) == 0 && (Cout % 32) == 0;
 }
-
-struct ConvViewS {
-    int B;
-    int Ei[3], Eo[3];
-    int nb[3];
-    int off;
-};
 
 template <int BN>
 __device__ __forceinline__ int outs_addr(int v, int c) {
@@ -56,19 +51,18 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-template <int NT, bool ZERO_PAD>
+template <int NT, bool ZERO_PAD, bool THIN, bool PERM>
 __global__ void __launch_bounds__(256, 1)
 conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
-                        const bf16* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, ConvViewS g,
+                        const bf16* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, BrickRegions R,
                         int Cout, int64_t lo_offset, double* __restrict__ gn_acc, float* __restrict__ d1, int D1,
                         float* __restrict__ d2, const float* __restrict__ a1, const float* __restrict__ a2) {
+    using BR = Brick<THIN>;
     constexpr int BN = NT * 32;
-    constexpr int BX = 4, BY = 8, BZ = 8;
-    constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
-    constexpr int SZ = 12;
-    constexpr int NHALO = HX * HY * HZ;
-    constexpr int APLANE = HX * HY * SZ * 16 + 64;   // one half-plane of one part
-    constexpr int A_BYTES = 4 * APLANE;              // [part][half]
+    constexpr int HY = BR::HY, HZ = BR::HZ, SZ = BR::SZ;
+    constexpr int NHALO = BR::NHALO;
+    constexpr int APLANE = BR::ENTRIES * 16 + 64;   // one half-plane of one part
+    constexpr int A_BYTES = 4 * APLANE;             // [part][half]
     constexpr int B_PLANE = 27 * BN * 16 + 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;
@@ -78,13 +72,9 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
 
-    int bid = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    const int b2 = bid % g.nb[2]; bid /= g.nb[2];
-    const int b1 = bid % g.nb[1]; bid /= g.nb[1];
-    const int b0 = bid % g.nb[0]; bid /= g.nb[0];
-    const int b = bid;
+    int b, o[3];
+    const BrickView g = brick_decode<THIN>(R, xcd_contiguous((int)blockIdx.x, (int)gridDim.x), b, o);
     const int n0 = blockIdx.y * BN;
-    const int o0 = b0 * BX, o1 = b1 * BY, o2 = b2 * BZ;
     const int Cin = C1 + C2;
 
     // ---- staging plan of the halo brick: pieces (voxel, half) of 8 fp32 channels
@@ -101,14 +91,8 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
             const int hx = hv / (HY * HZ), rem = hv - hx * (HY * HZ);
             const int hy = rem / HZ, hz = rem - hy * HZ;
             a_dst[i] = half * APLANE + ((hx * HY + hy) * SZ + hz) * 16;
-            int s0 = o0 + hx - 1 + g.off, s1 = o1 + hy - 1 + g.off, s2 = o2 + hz - 1 + g.off;
-            bool ok = true;
-            if (ZERO_PAD) {
-                ok = s0 >= 0 && s0 < g.Ei[0] && s1 >= 0 && s1 < g.Ei[1] && s2 >= 0 && s2 < g.Ei[2];
-            } else {
-                s0 = min(max(s0, 0), g.Ei[0] - 1); s1 = min(max(s1, 0), g.Ei[1] - 1); s2 = min(max(s2, 0), g.Ei[2] - 1);
-            }
-            if (ok) a_src[i] = ((s0 * g.Ei[1] + s1) * g.Ei[2] + s2) * 2 + half;
+            const int src = brick_halo_source<ZERO_PAD, PERM>(g, o, hx, hy, hz);
+            if (src >= 0) a_src[i] = src * 2 + half;
         }
     }
     const int64_t batch_vox = (int64_t)b * g.Ei[0] * g.Ei[1] * g.Ei[2];
@@ -166,10 +150,17 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
         }
     };
 
-    // wave w owns brick plane w; M tile mt: y = 4 mt + (r & 3), z = r >> 2
+    // this lane's voxel of M tile mt (Brick<THIN>::lane_voxel)
     int a_h[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) a_h[mt] = hh * APLANE + (((wave + 1) * HY + (4 * mt + (r & 3) + 1)) * SZ + ((r >> 2) + 1)) * 16;
+    for (int mt = 0; mt < 2; ++mt) {
+        int lx, ly, lz;
+        BR::lane_voxel(wave, mt, r, lx, ly, lz);
+        a_h[mt] = hh * APLANE + (((lx + 1) * HY + (ly + 1)) * SZ + (lz + 1)) * 16;
+    }
+    int tap_row[27];  // weight-image row of every local tap (uniform; immediates when the axes are not permuted)
+#pragma unroll
+    for (int t = 0; t < 27; ++t) tap_row[t] = (PERM ? brick_tap(g, t / 9 - 1, (t / 3) % 3 - 1, t % 3 - 1) : t) * (BN * 16);
     const int b_off = hh * B_PLANE + r * 16;
 
     f32x16 acc[NT][2];
@@ -191,8 +182,8 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            f.wh[nt] = *reinterpret_cast<const bf16x8*>(sB + b_off + (tap * BN + nt * 32) * 16);
-            f.wl[nt] = *reinterpret_cast<const bf16x8*>(sB + 2 * B_PLANE + b_off + (tap * BN + nt * 32) * 16);
+            f.wh[nt] = *reinterpret_cast<const bf16x8*>(sB + b_off + tap_row[tap] + nt * 512);
+            f.wl[nt] = *reinterpret_cast<const bf16x8*>(sB + 2 * B_PLANE + b_off + tap_row[tap] + nt * 512);
         }
     };
     // term-major order: with one wave per SIMD nothing hides the ~12-cycle stall of an MFMA that accumulates
@@ -245,7 +236,9 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
             if (bias) bv = *reinterpret_cast<const float4*>(bias + n0 + ch);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
-                const int v = (wave * BY + 4 * mt + (r & 3)) * 8 + (r >> 2);
+                int lx, ly, lz;
+                BR::lane_voxel(wave, mt, r, lx, ly, lz);
+                const int v = BR::tile_index(lx, ly, lz);
                 *reinterpret_cast<float4*>(sO + outs_addr<BN>(v, ch >> 2)) =
                     make_float4(acc[nt][mt][4 * j] + bv.x, acc[nt][mt][4 * j + 1] + bv.y, acc[nt][mt][4 * j + 2] + bv.z,
                                 acc[nt][mt][4 * j + 3] + bv.w);
@@ -258,8 +251,10 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     for (int i = 0; i < CHUNKS; ++i) {
         const int p = tid + i * 256;
         const int v = p / CHUNKS, cidx = p % CHUNKS;
-        const int c0 = o0 + (v >> 3) / BY, c1 = o1 + (v >> 3) % BY, c2 = o2 + (v & 7);
-        if (c0 < g.Eo[0] && c1 < g.Eo[1] && c2 < g.Eo[2]) {
+        int lx, ly, lz, c[3];
+        BR::tile_voxel(v, lx, ly, lz);
+        if (brick_out_coords<PERM>(g, o, lx, ly, lz, c)) {
+            const int c0 = c[0], c1 = c[1], c2 = c[2];
             const int64_t ov = (((int64_t)b * g.Eo[0] + c0) * g.Eo[1] + c1) * g.Eo[2] + c2;
             float4 val = *reinterpret_cast<const float4*>(sO + outs_addr<BN>(v, cidx));
             bool direct = false;
@@ -267,7 +262,7 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
                 // data gradient: padded position = original voxel + 1.  Positions inside the original grid go
                 // straight to dx (split over the two inputs of a concatenated conv, plus the optional addend);
                 // only the halo shell is written to the padded workspace for the face fix-up
-                const int u0 = c0 - 1, u1 = c1 - 1, u2 = c2 - 1;
+                const int u0 = c0 + g.off, u1 = c1 + g.off, u2 = c2 + g.off;
                 if (u0 >= 0 && u0 < g.Ei[0] && u1 >= 0 && u1 < g.Ei[1] && u2 >= 0 && u2 < g.Ei[2]) {
                     const int64_t u = (((int64_t)b * g.Ei[0] + u0) * g.Ei[1] + u1) * g.Ei[2] + u2;
                     const int n = n0 + cidx * 4;
@@ -315,31 +310,39 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
 int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                             const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
                             const void* a1, const void* a2) {
-    const int NT = (Cout % 64 == 0) ? 2 : 1;
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
-    ConvViewS v;
-    v.B = g.B; v.off = g.off;
-    v.Ei[0] = g.Xi; v.Ei[1] = g.Yi; v.Ei[2] = g.Zi;
-    v.Eo[0] = g.Xo; v.Eo[1] = g.Yo; v.Eo[2] = g.Zo;
-    v.nb[0] = ceil_div(g.Xo, 4); v.nb[1] = ceil_div(g.Yo, 8); v.nb[2] = ceil_div(g.Zo, 8);
-    const int BN = NT * 32;
-    const size_t lds = (size_t)4 * (6 * 10 * 12 * 16 + 64) + (size_t)4 * (27 * BN * 16 + 64);
+    static const bool no_thin = getenv("TDX_CONV3_THIN") && atoi(getenv("TDX_CONV3_THIN")) == 0;  // A/B switch
+    BrickRegions main, thin;
+    brick_plan(g, zero_pad, !no_thin, main, thin);
     const int64_t lo_offset = (int64_t)27 * (C1 + C2) * Cout;  // elements between the hi and the lo weight image
-    dim3 grid((unsigned)((int64_t)g.B * v.nb[0] * v.nb[1] * v.nb[2]), Cout / BN);
-#define SP_GO(NTV, ZP)                                                                                                  \
+#define SP_GO(NTV, ZP, TH, PM, REG)                                                                                          \
     do {                                                                                                                \
-        auto kern = conv3_mfma_split_kernel<NTV, ZP>;                                                                   \
+        constexpr int BNV = NTV * 32;                                                                                   \
+        const size_t lds = (size_t)4 * (Brick<TH>::ENTRIES * 16 + 64) + (size_t)4 * (27 * BNV * 16 + 64);               \
+        auto kern = conv3_mfma_split_kernel<NTV, ZP, TH, PM>;                                                               \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return (int)e;                                                                         \
             attr_set = true;                                                                                            \
         }                                                                                                               \
+        dim3 grid((unsigned)(REG).start[(REG).n], Cout / BNV);                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const float*)x1, C1, (const float*)x2, C2, (const bf16*)wp, \
-                           bias, (float*)y, v, Cout, lo_offset, gn_acc, (float*)d1, D1, (float*)d2, (const float*)a1, (const float*)a2);                                                        \
+                           bias, (float*)y, REG, Cout, lo_offset, gn_acc, (float*)d1, D1, (float*)d2, (const float*)a1,  \
+                           (const float*)a2);                                                                           \
     } while (0)
-    if (NT == 2) { if (zero_pad) SP_GO(2, true); else SP_GO(2, false); }
-    else { if (zero_pad) SP_GO(1, true); else SP_GO(1, false); }
+    const int NT = (Cout % 64 == 0) ? 2 : 1;
+    const bool perm = main.v[0].perm[0] != 0;  // forward on ragged grids: the short brick edge on another axis
+    if (NT == 2) {
+        if (zero_pad) SP_GO(2, true, false, false, main);
+        else if (perm) SP_GO(2, false, false, true, main);
+        else SP_GO(2, false, false, false, main);
+    } else {
+        if (zero_pad) SP_GO(1, true, false, false, main);
+        else if (perm) SP_GO(1, false, false, true, main);
+        else SP_GO(1, false, false, false, main);
+    }
+    if (thin.n > 0) SP_GO(1, true, true, true, thin);  // remainder slabs of the padded grid: 2 x 16 x 8 bricks, 32-wide tiles
 #undef SP_GO
     return tdx_launch_status();
 }
