@@ -27,16 +27,25 @@ struct BrickRegions {
     int n;
 };
 
-template <bool THIN>
+// brick shapes: 0 = 4 x 8 x 8 (two 32-voxel M tiles per wave), 1 = thin 2 x 16 x 8 (remainder slabs),
+// 2 = big 8 x 8 x 8 (four M tiles per wave: for 32-channel output tiles, so that a weight fragment still
+// feeds four MFMAs and the weights are staged once per 512 voxels)
+#define BRICK_MAIN 0
+#define BRICK_THIN 1
+#define BRICK_BIG 2
+template <int SHAPE>
 struct Brick {
-    static constexpr int BX = THIN ? 2 : 4, BY = THIN ? 16 : 8, BZ = 8;
+    static constexpr int BX = SHAPE == BRICK_THIN ? 2 : (SHAPE == BRICK_BIG ? 8 : 4), BY = SHAPE == BRICK_THIN ? 16 : 8, BZ = 8;
+    static constexpr int MT = SHAPE == BRICK_BIG ? 4 : 2;  // M tiles (32 voxels) per wave
+    static constexpr int NVOX = BX * BY * BZ;
     static constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
     static constexpr int SZ = 12;  // padded z stride of the LDS image (conflict-free 16-B fragment reads)
     static constexpr int NHALO = HX * HY * HZ, ENTRIES = HX * HY * SZ;
 
     // wave w, M tile mt, lane row r -> local voxel inside the brick
     __device__ __forceinline__ static void lane_voxel(int wave, int mt, int r, int& lx, int& ly, int& lz) {
-        if (THIN) { lx = wave >> 1; ly = 8 * (wave & 1) + 4 * mt + (r & 3); }
+        if (SHAPE == BRICK_THIN) { lx = wave >> 1; ly = 8 * (wave & 1) + 4 * mt + (r & 3); }
+        else if (SHAPE == BRICK_BIG) { lx = 2 * wave + (mt >> 1); ly = 4 * (mt & 1) + (r & 3); }
         else { lx = wave; ly = 4 * mt + (r & 3); }
         lz = r >> 2;
     }
@@ -47,7 +56,7 @@ struct Brick {
 };
 
 // block id -> region, sample and brick origin (local output coordinates)
-template <bool THIN>
+template <int SHAPE>
 __device__ __forceinline__ BrickView brick_decode(const BrickRegions& R, int bid, int& b, int (&o)[3]) {
     // the view is selected by value (uniform selects): indexing R.v[] dynamically would push the struct to scratch
     BrickView g = R.v[0];
@@ -59,7 +68,7 @@ __device__ __forceinline__ BrickView brick_decode(const BrickRegions& R, int bid
     const int b1 = bid % g.nb[1]; bid /= g.nb[1];
     const int b0 = bid % g.nb[0]; bid /= g.nb[0];
     b = bid;
-    o[0] = g.org[0] + b0 * Brick<THIN>::BX; o[1] = g.org[1] + b1 * Brick<THIN>::BY; o[2] = g.org[2] + b2 * Brick<THIN>::BZ;
+    o[0] = g.org[0] + b0 * Brick<SHAPE>::BX; o[1] = g.org[1] + b1 * Brick<SHAPE>::BY; o[2] = g.org[2] + b2 * Brick<SHAPE>::BZ;
     return g;
 }
 
@@ -106,10 +115,15 @@ __device__ __forceinline__ int brick_tap(const BrickView& g, int ex, int ey, int
 }
 
 // ---------------------------------------------------------------------------------------------- host side
+static inline void brick_dims(int shape, int bd[3]) {
+    bd[0] = shape == BRICK_THIN ? 2 : (shape == BRICK_BIG ? 8 : 4); bd[1] = shape == BRICK_THIN ? 16 : 8; bd[2] = 8;
+}
+
 static inline void brick_fill_view(BrickView& v, const Conv3Geom& g, const int perm[3], const int org_g[3], const int ext_g[3],
-                                   bool thin) {
+                                   int shape) {
     static const int tapw[3] = {9, 3, 1};
-    const int bd[3] = {thin ? 2 : 4, thin ? 16 : 8, 8};
+    int bd[3];
+    brick_dims(shape, bd);
     v.B = g.B; v.off = g.off;
     v.Ei[0] = g.Xi; v.Ei[1] = g.Yi; v.Ei[2] = g.Zi;
     v.Eo[0] = g.Xo; v.Eo[1] = g.Yo; v.Eo[2] = g.Zo;
@@ -122,8 +136,9 @@ static inline void brick_fill_view(BrickView& v, const Conv3Geom& g, const int p
     }
 }
 
-static inline int64_t brick_count(const int ext_g[3], const int perm[3], bool thin) {
-    const int bd[3] = {thin ? 2 : 4, thin ? 16 : 8, 8};
+static inline int64_t brick_count(const int ext_g[3], const int perm[3], int shape) {
+    int bd[3];
+    brick_dims(shape, bd);
     int64_t n = 1;
     for (int k = 0; k < 3; ++k) n *= ceil_div(ext_g[perm[k]], bd[k]);
     return n;
@@ -132,10 +147,12 @@ static inline int64_t brick_count(const int ext_g[3], const int perm[3], bool th
 // Regions of one conv call: `main` (4 x 8 x 8 bricks, one region) and `thin` (2 x 16 x 8 bricks, 0-3 slab
 // regions).  Forward / replicate convs: the whole grid with the brick orientation that leaves the fewest
 // bricks.  Zero-padded data gradient: remainders of 1-2 voxels along an axis become thin slabs.
-static inline void brick_plan(const Conv3Geom& g, bool zero_pad, bool allow_thin, BrickRegions& main, BrickRegions& thin) {
+static inline void brick_plan(const Conv3Geom& g, bool zero_pad, bool allow_thin, BrickRegions& main, BrickRegions& thin,
+                              int main_shape = BRICK_MAIN) {
     static const int cand[3][3] = {{0, 1, 2}, {1, 0, 2}, {2, 0, 1}};  // which global axis gets the short (4 / 2) edge
     const int Eo[3] = {g.Xo, g.Yo, g.Zo};
-    const int bd[3] = {4, 8, 8};
+    int bd[3];
+    brick_dims(main_shape, bd);
     int Em[3] = {Eo[0], Eo[1], Eo[2]};  // extent of the main region
     bool slab[3] = {false, false, false};
     const int org0[3] = {0, 0, 0};
@@ -143,7 +160,7 @@ static inline void brick_plan(const Conv3Geom& g, bool zero_pad, bool allow_thin
     int mperm = 0;
     // thin slabs pay on big grids only (an extra, mostly empty launch costs more than ragged bricks on the
     // deep U-Net levels): at least 1024 main bricks
-    const int64_t full = (int64_t)g.B * ceil_div(Eo[0], 4) * ceil_div(Eo[1], 8) * ceil_div(Eo[2], 8);
+    const int64_t full = (int64_t)g.B * ceil_div(Eo[0], 4) * ceil_div(Eo[1], 8) * ceil_div(Eo[2], 8);  // in 256-voxel bricks
     if (zero_pad && allow_thin && full >= 1024) {
         for (int a = 0; a < 3; ++a) {
             const int rem = Eo[a] % bd[a];
@@ -152,12 +169,12 @@ static inline void brick_plan(const Conv3Geom& g, bool zero_pad, bool allow_thin
     } else if (!zero_pad) {
         int64_t best = -1;
         for (int c = 0; c < 3; ++c) {
-            const int64_t n = brick_count(Em, cand[c], false);
+            const int64_t n = brick_count(Em, cand[c], main_shape);
             if (best < 0 || n < best) { best = n; mperm = c; }
         }
     }
     main.n = 1;
-    brick_fill_view(main.v[0], g, cand[mperm], org0, Em, false);
+    brick_fill_view(main.v[0], g, cand[mperm], org0, Em, main_shape);
     main.start[0] = 0;
     main.start[1] = (int)((int64_t)g.B * main.v[0].nb[0] * main.v[0].nb[1] * main.v[0].nb[2]);
     int nblk = 0;
@@ -169,9 +186,9 @@ static inline void brick_plan(const Conv3Geom& g, bool zero_pad, bool allow_thin
         org[a] = Em[a]; ext[a] = Eo[a] - Em[a];
         const int p = (a + 1) % 3, q = (a + 2) % 3;
         const int perm1[3] = {a, p, q}, perm2[3] = {a, q, p};
-        const int* perm = brick_count(ext, perm1, true) <= brick_count(ext, perm2, true) ? perm1 : perm2;
+        const int* perm = brick_count(ext, perm1, BRICK_THIN) <= brick_count(ext, perm2, BRICK_THIN) ? perm1 : perm2;
         BrickView& v = thin.v[thin.n];
-        brick_fill_view(v, g, perm, org, ext, true);
+        brick_fill_view(v, g, perm, org, ext, BRICK_THIN);
         thin.start[thin.n] = nblk;
         nblk += (int)((int64_t)g.B * v.nb[0] * v.nb[1] * v.nb[2]);
         ++thin.n;

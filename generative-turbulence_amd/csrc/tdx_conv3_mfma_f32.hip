@@ -34,13 +34,13 @@ __device__ __forceinline__ int outf_addr(int v, int c) {
     return v * (BN * 4) + ((c ^ (v & (BN / 4 - 1))) << 4);
 }
 
-template <int NT, bool ZERO_PAD, bool THIN, bool PERM>
+template <int NT, bool ZERO_PAD, int SHAPE, bool PERM>
 __global__ void __launch_bounds__(256, 2)
 conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
                       const float* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, BrickRegions R,
                       int Cout, double* __restrict__ gn_acc, float* __restrict__ d1, int D1, float* __restrict__ d2,
                       const float* __restrict__ a1, const float* __restrict__ a2) {
-    using BR = Brick<THIN>;
+    using BR = Brick<SHAPE>;
     constexpr int BN = NT * 32;
     constexpr int HY = BR::HY, HZ = BR::HZ, SZ = BR::SZ;
     constexpr int NHALO = BR::NHALO;
@@ -56,7 +56,7 @@ conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restr
     const int r = lane & 31, hh = lane >> 5;
 
     int b, o[3];
-    const BrickView g = brick_decode<THIN>(R, xcd_contiguous((int)blockIdx.x, (int)gridDim.x), b, o);
+    const BrickView g = brick_decode<SHAPE>(R, xcd_contiguous((int)blockIdx.x, (int)gridDim.x), b, o);
     const int n0 = blockIdx.y * BN;
     const int Cin = C1 + C2;
 
@@ -278,16 +278,16 @@ int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const 
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const bool perm = main.v[0].perm[0] != 0;
     if (NT == 2) {
-        if (zero_pad) F3_GO(2, true, false, false, main);
-        else if (perm) F3_GO(2, false, false, true, main);
-        else F3_GO(2, false, false, false, main);
+        if (zero_pad) F3_GO(2, true, BRICK_MAIN, false, main);
+        else if (perm) F3_GO(2, false, BRICK_MAIN, true, main);
+        else F3_GO(2, false, BRICK_MAIN, false, main);
     } else {
-        if (zero_pad) F3_GO(1, true, false, false, main);
-        else if (perm) F3_GO(1, false, false, true, main);
-        else F3_GO(1, false, false, false, main);
+        if (zero_pad) F3_GO(1, true, BRICK_MAIN, false, main);
+        else if (perm) F3_GO(1, false, BRICK_MAIN, true, main);
+        else F3_GO(1, false, BRICK_MAIN, false, main);
     }
     if (thin.n > 0) {  // remainder slabs of the padded grid: 2 x 16 x 8 bricks
-        if (NT == 2) F3_GO(2, true, true, true, thin); else F3_GO(1, true, true, true, thin);
+        if (NT == 2) F3_GO(2, true, BRICK_THIN, true, thin); else F3_GO(1, true, BRICK_THIN, true, thin);
     }
 #undef F3_GO
     return tdx_launch_status();

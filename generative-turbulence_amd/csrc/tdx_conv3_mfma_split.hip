@@ -51,13 +51,14 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-template <int NT, bool ZERO_PAD, bool THIN, bool PERM>
+template <int NT, bool ZERO_PAD, int SHAPE, bool PERM>
 __global__ void __launch_bounds__(256, 1)
 conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
                         const bf16* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, BrickRegions R,
                         int Cout, int64_t lo_offset, double* __restrict__ gn_acc, float* __restrict__ d1, int D1,
                         float* __restrict__ d2, const float* __restrict__ a1, const float* __restrict__ a2) {
-    using BR = Brick<THIN>;
+    using BR = Brick<SHAPE>;
+    constexpr int MT = BR::MT;
     constexpr int BN = NT * 32;
     constexpr int HY = BR::HY, HZ = BR::HZ, SZ = BR::SZ;
     constexpr int NHALO = BR::NHALO;
@@ -73,7 +74,7 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     const int r = lane & 31, hh = lane >> 5;
 
     int b, o[3];
-    const BrickView g = brick_decode<THIN>(R, xcd_contiguous((int)blockIdx.x, (int)gridDim.x), b, o);
+    const BrickView g = brick_decode<SHAPE>(R, xcd_contiguous((int)blockIdx.x, (int)gridDim.x), b, o);
     const int n0 = blockIdx.y * BN;
     const int Cin = C1 + C2;
 
@@ -151,9 +152,9 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     };
 
     // this lane's voxel of M tile mt (Brick<THIN>::lane_voxel)
-    int a_h[2];
+    int a_h[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         int lx, ly, lz;
         BR::lane_voxel(wave, mt, r, lx, ly, lz);
         a_h[mt] = hh * APLANE + (((lx + 1) * HY + (ly + 1)) * SZ + (lz + 1)) * 16;
@@ -163,20 +164,20 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     for (int t = 0; t < 27; ++t) tap_row[t] = (PERM ? brick_tap(g, t / 9 - 1, (t / 3) % 3 - 1, t % 3 - 1) : t) * (BN * 16);
     const int b_off = hh * B_PLANE + r * 16;
 
-    f32x16 acc[NT][2];
+    f32x16 acc[NT][MT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
 
-    struct Frags { bf16x8 xh[2], xl[2], wh[NT], wl[NT]; };
+    struct Frags { bf16x8 xh[MT], xl[MT], wh[NT], wl[NT]; };
     auto read_frags = [&](int tap, Frags& f) {
         const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
         const int toff = ((ex * HY + ey) * SZ + ez) * 16;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             f.xh[mt] = *reinterpret_cast<const bf16x8*>(sA + a_h[mt] + toff);
             f.xl[mt] = *reinterpret_cast<const bf16x8*>(sA + 2 * APLANE + a_h[mt] + toff);
         }
@@ -195,7 +196,7 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 2 ? f.wl[nt] : f.wh[nt],
                                                                          term == 1 ? f.xl[mt] : f.xh[mt], acc[nt][mt], 0, 0, 0);
     };
@@ -213,20 +214,20 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
         for (int tap = 0; tap < 27; tap += 2) {
             if (tap + 1 < 27) read_frags(tap + 1, f1);
             mfmas(f0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NT, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 2 * NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NT, 0);
             if (tap + 1 < 27) {
                 if (tap + 2 < 27) read_frags(tap + 2, f0);
                 mfmas(f1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6 * NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 2 * NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NT, 0);
             }
         }
     }
 
     // ---- epilogue: as the fp32 kernel (lane (r, hh): voxel (wave, 4 mt + (r & 3), r >> 2), channels nt*32 + 8 j + 4 hh + 0..3)
     __syncthreads();
-    unsigned char* sO = smem;  // [256 voxels][BN] fp32
+    unsigned char* sO = smem;  // [NVOX voxels][BN] fp32
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -235,7 +236,7 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (bias) bv = *reinterpret_cast<const float4*>(bias + n0 + ch);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 int lx, ly, lz;
                 BR::lane_voxel(wave, mt, r, lx, ly, lz);
                 const int v = BR::tile_index(lx, ly, lz);
@@ -248,7 +249,7 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     constexpr int CHUNKS = BN / 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};  // GroupNorm moments of this thread's 4 channels
 #pragma unroll
-    for (int i = 0; i < CHUNKS; ++i) {
+    for (int i = 0; i < CHUNKS * (BR::NVOX / 256); ++i) {
         const int p = tid + i * 256;
         const int v = p / CHUNKS, cidx = p % CHUNKS;
         int lx, ly, lz, c[3];
@@ -289,7 +290,7 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
         // channels; LDS reduce behind the output tile, then one f64 atomic per channel and moment into one of
         // TDX_GN_REPLICAS tables (as the bf16 kernel)
         constexpr int NP = 256 / CHUNKS;
-        float* red = reinterpret_cast<float*>(smem + 256 * BN * 4);  // [NP][BN][2]
+        float* red = reinterpret_cast<float*>(smem + BR::NVOX * BN * 4);  // [NP][BN][2]
         const int cidx = tid % CHUNKS, part = tid / CHUNKS;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -312,14 +313,18 @@ int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, cons
                             const void* a1, const void* a2) {
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
     static const bool no_thin = getenv("TDX_CONV3_THIN") && atoi(getenv("TDX_CONV3_THIN")) == 0;  // A/B switch
+    const int NT = (Cout % 64 == 0) ? 2 : 1;
+    // 32-wide output tiles: 8 x 8 x 8 bricks (four M tiles per wave) where the grid is large enough to fill the chip
+    static const bool no_big = getenv("TDX_CONV3_BIG") && atoi(getenv("TDX_CONV3_BIG")) == 0;  // A/B switch
+    const bool big = NT == 1 && !no_big && (int64_t)g.B * ceil_div(g.Xo, 8) * ceil_div(g.Yo, 8) * ceil_div(g.Zo, 8) >= 1024;
     BrickRegions main, thin;
-    brick_plan(g, zero_pad, !no_thin, main, thin);
+    brick_plan(g, zero_pad, !no_thin, main, thin, big ? BRICK_BIG : BRICK_MAIN);
     const int64_t lo_offset = (int64_t)27 * (C1 + C2) * Cout;  // elements between the hi and the lo weight image
-#define SP_GO(NTV, ZP, TH, PM, REG)                                                                                          \
+#define SP_GO(NTV, ZP, TH, PM, REG)                                                                                     \
     do {                                                                                                                \
         constexpr int BNV = NTV * 32;                                                                                   \
         const size_t lds = (size_t)4 * (Brick<TH>::ENTRIES * 16 + 64) + (size_t)4 * (27 * BNV * 16 + 64);               \
-        auto kern = conv3_mfma_split_kernel<NTV, ZP, TH, PM>;                                                               \
+        auto kern = conv3_mfma_split_kernel<NTV, ZP, TH, PM>;                                                           \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -331,18 +336,21 @@ int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, cons
                            bias, (float*)y, REG, Cout, lo_offset, gn_acc, (float*)d1, D1, (float*)d2, (const float*)a1,  \
                            (const float*)a2);                                                                           \
     } while (0)
-    const int NT = (Cout % 64 == 0) ? 2 : 1;
     const bool perm = main.v[0].perm[0] != 0;  // forward on ragged grids: the short brick edge on another axis
     if (NT == 2) {
-        if (zero_pad) SP_GO(2, true, false, false, main);
-        else if (perm) SP_GO(2, false, false, true, main);
-        else SP_GO(2, false, false, false, main);
+        if (zero_pad) SP_GO(2, true, BRICK_MAIN, false, main);
+        else if (perm) SP_GO(2, false, BRICK_MAIN, true, main);
+        else SP_GO(2, false, BRICK_MAIN, false, main);
+    } else if (big) {
+        if (zero_pad) SP_GO(1, true, BRICK_BIG, false, main);
+        else if (perm) SP_GO(1, false, BRICK_BIG, true, main);
+        else SP_GO(1, false, BRICK_BIG, false, main);
     } else {
-        if (zero_pad) SP_GO(1, true, false, false, main);
-        else if (perm) SP_GO(1, false, false, true, main);
-        else SP_GO(1, false, false, false, main);
+        if (zero_pad) SP_GO(1, true, BRICK_MAIN, false, main);
+        else if (perm) SP_GO(1, false, BRICK_MAIN, true, main);
+        else SP_GO(1, false, BRICK_MAIN, false, main);
     }
-    if (thin.n > 0) SP_GO(1, true, true, true, thin);  // remainder slabs of the padded grid: 2 x 16 x 8 bricks, 32-wide tiles
+    if (thin.n > 0) SP_GO(1, true, BRICK_THIN, true, thin);  // remainder slabs of the padded grid: 2 x 16 x 8 bricks, 32-wide tiles
 #undef SP_GO
     return tdx_launch_status();
 }
