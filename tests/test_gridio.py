@@ -265,3 +265,63 @@ def test_trainer_takes_openfoam_batches():
     want = G.select_cells_channels_last(full.cpu().numpy(), case.cell_idx, case.variables)
     for (name, _), v in zip(case.variables, vs):
         assert np.allclose(cells[v].cpu().numpy(), want[name], rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ randomised geometries
+def _random_geometry(seed):
+    """Random grid, random (unsorted) cell set, overlapping boundary lists, a random mix of FIXED_VALUE /
+    other boundary conditions in random dict order, random variable tuple."""
+    rng = np.random.default_rng(seed)
+    counts = tuple(int(c) for c in rng.integers(2, 9, size=3))
+    V = int(np.prod(counts))
+    n_cells = int(rng.integers(1, V + 1))
+    cell_idx = rng.permutation(V)[:n_cells]
+    names = list(rng.permutation(["walls", "inlets", "outlets", "empties"]))[: int(rng.integers(1, 5))]
+    boundaries = {str(n): rng.permutation(V)[: int(rng.integers(0, max(2, V // 3)))] for n in names}
+    pool = [("u", 3), ("p", 1), ("k", 1), ("nut", 1)]
+    variables = tuple(pool[i] for i in rng.permutation(4)[: int(rng.integers(1, 5))])
+    fixed = {}
+    for name, d in variables:
+        conds = {}
+        for b in rng.permutation(list(boundaries)):
+            if rng.random() < 0.6:
+                conds[str(b)] = (rng.standard_normal(d) if d > 1 else np.array(rng.standard_normal())).astype(np.float32)
+        fixed[name] = conds
+    B = int(rng.integers(1, 4))
+    samples = {name: rng.standard_normal((B, n_cells, d)).astype(np.float32) for name, d in variables}
+    mean = rng.standard_normal(sum(d for _, d in variables)).astype(np.float32)
+    std = (np.abs(rng.standard_normal(sum(d for _, d in variables))) + 0.3).astype(np.float32)
+    from types import SimpleNamespace
+    return SimpleNamespace(tag=f"rnd{seed}", variables=variables, cell_counts=counts, cell_idx=cell_idx, boundaries=boundaries,
+                           fixed=fixed, samples=samples, stats={}, mean=mean, std=std)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_plan_on_random_geometries_matches_oracle(seed):
+    c = _random_geometry(seed)
+    vs, meta, data, _ = build(c)
+    plan = gridio.plan_for(meta)
+    x = emulate_embed(plan, plan.features(vs), [c.samples[n] for n, _ in c.variables])
+    want = G.grid_embedding(c.samples, c.variables, c.cell_idx, c.cell_counts, c.boundaries, c.fixed)
+    assert np.array_equal(x, want)
+    assert np.array_equal(plan.types.numpy().reshape(plan.counts), G.cell_types(c.cell_idx, c.cell_counts, c.boundaries))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(100, 124))
+def test_gridio_kernels_on_random_geometries(seed):
+    c = _random_geometry(seed)
+    vs, meta, data, _ = build(c, dev())
+    want = G.grid_embedding(c.samples, c.variables, c.cell_idx, c.cell_counts, c.boundaries, c.fixed)
+    assert np.array_equal(data.grid_embedding(vs).cpu().numpy(), want)
+    xn = gridio.grid_embed(data, vs, torch.tensor(c.mean), torch.tensor(c.std))
+    assert np.array_equal(xn.cpu().numpy(), G.normalize_grid(want, c.mean, c.std))
+    y = torch.randn(xn.shape, generator=torch.Generator().manual_seed(seed))
+    got = gridio.grid_select(y.to(dev()), meta, vs, torch.tensor(c.mean), torch.tensor(c.std))
+    ref = G.select_cells_channels_last(G.denormalize_grid(y.numpy(), c.mean, c.std), c.cell_idx, c.variables)
+    for (name, _), v in zip(c.variables, vs):
+        assert np.array_equal(got[v].cpu().numpy(), ref[name])
+    emb = CellTypeEmbedding.create("learned", 3).to(dev())
+    C = emb(data)
+    assert np.array_equal(C.detach().cpu().numpy(), G.cell_type_embedding(G.cell_types(c.cell_idx, c.cell_counts, c.boundaries),
+                                                                           emb.embedding.weight.detach().cpu().numpy()))
