@@ -41,6 +41,7 @@ conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restr
                       int Cout, double* __restrict__ gn_acc, float* __restrict__ d1, int D1, float* __restrict__ d2,
                       const float* __restrict__ a1, const float* __restrict__ a2) {
     using BR = Brick<SHAPE>;
+    constexpr int MT = BR::MT;
     constexpr int BN = NT * 32;
     constexpr int HY = BR::HY, HZ = BR::HZ, SZ = BR::SZ;
     constexpr int NHALO = BR::NHALO;
@@ -119,9 +120,9 @@ conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restr
     };
 
     // this lane's voxel of M tile mt (Brick<THIN>::lane_voxel)
-    int a_h[2];
+    int a_h[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         int lx, ly, lz;
         BR::lane_voxel(wave, mt, r, lx, ly, lz);
         a_h[mt] = ((lx + 1) * HY + (ly + 1)) * SZ + (lz + 1);
@@ -133,11 +134,11 @@ conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restr
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) b_off[nt] = hh * B_PLANE + (nt * 32 + r) * 16;
 
-    f32x16 acc[NT][2];  // D[row = channel][col = voxel]
+    f32x16 acc[NT][MT];  // D[row = channel][col = voxel]
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
 
@@ -152,15 +153,15 @@ conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restr
         for (int tap = 0; tap < 27; ++tap) {
             const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
             const int toff = (ex * HY + ey) * SZ + ez;
-            float4 xf[2], wf[NT];
+            float4 xf[MT], wf[NT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) xf[mt] = *reinterpret_cast<const float4*>(sA + hh * APLANE + (a_h[mt] + toff) * 16);
+            for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const float4*>(sA + hh * APLANE + (a_h[mt] + toff) * 16);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const float4*>(sB + tap_row[tap] + b_off[nt]);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt].x, xf[mt].x, acc[nt][mt], 0, 0, 0);
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt].y, xf[mt].y, acc[nt][mt], 0, 0, 0);
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[nt].z, xf[mt].z, acc[nt][mt], 0, 0, 0);
@@ -180,7 +181,7 @@ conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restr
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (bias) bv = *reinterpret_cast<const float4*>(bias + n0 + ch);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 int lx, ly, lz;
                 BR::lane_voxel(wave, mt, r, lx, ly, lz);
                 const int v = BR::tile_index(lx, ly, lz);
@@ -193,7 +194,7 @@ conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restr
     constexpr int CHUNKS = BN / 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};  // GroupNorm moments of this thread's 4 channels  // 16-B chunks per voxel row
 #pragma unroll
-    for (int i = 0; i < CHUNKS; ++i) {
+    for (int i = 0; i < CHUNKS * (BR::NVOX / 256); ++i) {
         const int p = tid + i * 256;
         const int v = p / CHUNKS, cidx = p % CHUNKS;
         int lx, ly, lz, c[3];
@@ -234,7 +235,7 @@ conv3_mfma_f32_kernel(const float* __restrict__ x1, int C1, const float* __restr
         // channels; LDS reduce behind the output tile, then one f64 atomic per channel and moment into one of
         // TDX_GN_REPLICAS tables (as the bf16 kernel)
         constexpr int NP = 256 / CHUNKS;
-        float* red = reinterpret_cast<float*>(smem + 256 * BN * 4);  // [NP][BN][2]
+        float* red = reinterpret_cast<float*>(smem + BR::NVOX * BN * 4);  // [NP][BN][2]
         const int cidx = tid % CHUNKS, part = tid / CHUNKS;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -257,12 +258,19 @@ int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const 
                           const void* a1, const void* a2) {
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
     static const bool no_thin = getenv("TDX_CONV3_THIN") && atoi(getenv("TDX_CONV3_THIN")) == 0;  // A/B switch
+    const int NT = (Cout % 64 == 0) ? 2 : 1;
+    // (8 x 8 x 8 bricks with four M tiles per wave, which pay in the split kernel, are 25-35 % SLOWER here: this
+    // kernel is MFMA-bound with two workgroups per CU already; opt-in with TDX_CONV3_BIG=1 for A/B runs)
+    static const bool want_big = getenv("TDX_CONV3_BIG") && atoi(getenv("TDX_CONV3_BIG")) == 1;
+    const bool big = NT == 1 && want_big && (int64_t)g.B * ceil_div(g.Xo, 8) * ceil_div(g.Yo, 8) * ceil_div(g.Zo, 8) >= 1024;
     BrickRegions main, thin;
-    brick_plan(g, zero_pad, !no_thin, main, thin);
+    brick_plan(g, zero_pad, !no_thin, main, thin, big ? BRICK_BIG : BRICK_MAIN);
 #define F3_GO(NTV, ZP, TH, PM, REG)                                                                                     \
     do {                                                                                                                \
         constexpr int BNV = NTV * 32;                                                                                   \
-        const size_t lds = (size_t)2 * (Brick<TH>::ENTRIES * 16 + 64) + (size_t)2 * (27 * BNV * 16 + 64);               \
+        size_t lds = (size_t)2 * (Brick<TH>::ENTRIES * 16 + 64) + (size_t)2 * (27 * BNV * 16 + 64);                     \
+        const size_t tile = (size_t)Brick<TH>::NVOX * BNV * 4 + 8192; /* epilogue: output tile + moment reduction */    \
+        if (tile > lds) lds = tile;                                                                                     \
         auto kern = conv3_mfma_f32_kernel<NTV, ZP, TH, PM>;                                                             \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
@@ -275,12 +283,15 @@ int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const 
                            bias, (float*)y, REG, Cout, gn_acc, (float*)d1, D1, (float*)d2, (const float*)a1,             \
                            (const float*)a2);                                                                           \
     } while (0)
-    const int NT = (Cout % 64 == 0) ? 2 : 1;
     const bool perm = main.v[0].perm[0] != 0;
     if (NT == 2) {
         if (zero_pad) F3_GO(2, true, BRICK_MAIN, false, main);
         else if (perm) F3_GO(2, false, BRICK_MAIN, true, main);
         else F3_GO(2, false, BRICK_MAIN, false, main);
+    } else if (big) {
+        if (zero_pad) F3_GO(1, true, BRICK_BIG, false, main);
+        else if (perm) F3_GO(1, false, BRICK_BIG, true, main);
+        else F3_GO(1, false, BRICK_BIG, false, main);
     } else {
         if (zero_pad) F3_GO(1, true, BRICK_MAIN, false, main);
         else if (perm) F3_GO(1, false, BRICK_MAIN, true, main);
