@@ -139,20 +139,26 @@ def torch_rocm_baseline(B, dev, amp, steps=2):
     return res
 
 
-def measured_traffic():
-    """HBM bytes per launch of the forward conv kernel from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json, produced by tools/collect_profiles.sh at B = 6); None if absent."""
-    files = sorted((ROOT / "profiles").glob("*_traffic.json"))
-    if not files:
-        return None, None
-    data = json.loads(files[-1].read_text())
-    num = den = 0.0
-    for name, k in data["kernels"].items():
-        if "conv3_mfma_kernel" in name and "false>" in name:  # forward instantiations
-            n = k["launches_sampled"]
-            num += n * (k["read_bytes_per_launch"] + k["write_bytes_per_launch"])
-            den += n
-    return (num / den if den else None), f"profiles/{files[-1].name}"
+def measured_traffic(mode="bf16"):
+    """HBM bytes per launch of the mode's forward conv kernel from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, produced by tools/collect_profiles.sh at B = 6): the newest file that holds
+    launches of that kernel; (None, None) if there is none."""
+    import re
+
+    # forward instantiations = ZERO_PAD template argument false
+    pat = {"bf16": r"conv3_mfma_kernel<\d, false, (true|false), (true|false), false>",
+           "f32": r"conv3_mfma_f32_kernel<\d, false,", "f32s": r"conv3_mfma_split_kernel<\d, false,"}[mode]
+    for f in sorted((ROOT / "profiles").glob("*_traffic.json"), reverse=True):  # rNN tags: newest round first
+        data = json.loads(f.read_text())
+        num = den = 0.0
+        for name, k in data["kernels"].items():
+            if re.search(pat, name):
+                n = k["launches_sampled"]
+                num += n * (k["read_bytes_per_launch"] + k["write_bytes_per_launch"])
+                den += n
+        if den:
+            return num / den, f"profiles/{f.name}"
+    return None, None
 
 
 def main():
@@ -275,7 +281,7 @@ def main():
         kf = kern.get("tdx_conv3_fwd")
         if kf and kf["ms"] > 0:
             ach = kf["work"] / (kf["ms"] * 1e-3) / 1e12
-            traffic, tsrc = measured_traffic()
+            traffic, tsrc = measured_traffic(args.dtype)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
                                "traffic_source": tsrc, "algorithmic_bytes_per_launch": 1417.6e6 * B / 22,
