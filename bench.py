@@ -146,7 +146,7 @@ def measured_traffic(mode="bf16"):
     import re
 
     # forward instantiations = ZERO_PAD template argument false
-    pat = {"bf16": r"conv3_mfma_kernel<\d, false, (true|false), (true|false), false>",
+    pat = {"bf16": r"conv3_mfma_kernel<\d, (true|false), false,",  # <NT, XT, ZERO_PAD, PERM, EXT>
            "f32": r"conv3_mfma_f32_kernel<\d, false,", "f32s": r"conv3_mfma_split_kernel<\d, false,"}[mode]
     for f in sorted((ROOT / "profiles").glob("*_traffic.json"), reverse=True):  # rNN tags: newest round first
         data = json.loads(f.read_text())
@@ -284,7 +284,8 @@ def main():
             traffic, tsrc = measured_traffic(args.dtype)
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                               "traffic_source": tsrc, "algorithmic_bytes_per_launch": 1417.6e6 * B / 22,
+                               "traffic_source": tsrc,
+                               "algorithmic_bytes_per_launch": (1417.6e6 if dtype == torch.bfloat16 else 2835.2e6) * B / 22,
                                "kernel": {"bf16": "conv3_mfma_kernel", "f32": "conv3_mfma_f32_kernel",
                                           "f32s": "conv3_mfma_split_kernel"}[args.dtype] + " (all tdx_conv3_fwd launches)",
                                "launches": kf["launches"], "avg_launch_ms": kf["ms"] / kf["launches"],
