@@ -89,8 +89,13 @@ def test_conv3_mfma_vs_direct_random(grid, C1, C2, Co, B, extras, seed):
         assert rel_l2(a.float().cpu(), b.float().cpu()) < tols[n], (n, grid, C1, C2, Co, B)
 
 
+# big grids with 32-wide output tiles: 8 x 8 x 8 bricks (split kernel) and thin remainder slabs of the padded
+# data-gradient grid in one call
+_BIG_CASES = [((98, 66, 50), 32, 0, 32, 4, True, 777), ((100, 64, 48), 32, 32, 32, 4, False, 778), ((192, 64, 48), 64, 0, 32, 1, True, 779)]
+
+
 @pytest.mark.parametrize("impl_name", ["auto", "split"])
-@pytest.mark.parametrize("grid,C1,C2,Co,B,extras,seed", _cases(14, 4321))
+@pytest.mark.parametrize("grid,C1,C2,Co,B,extras,seed", _cases(14, 4321) + _BIG_CASES)
 def test_conv3_fp32_mfma_and_split_vs_direct_random(grid, C1, C2, Co, B, extras, seed, impl_name, monkeypatch):
     """fp32 tensors: the IEEE-fp32 MFMA kernels (auto) and the split-precision kernels (split) against the
     vector-ALU kernels on random ragged / thin / tiny grids and channel mixes (two inputs, partly filled tiles)."""
