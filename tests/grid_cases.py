@@ -3,6 +3,7 @@ from pathlib import Path
 from types import SimpleNamespace
 
 import numpy as np
+import torch
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
@@ -37,3 +38,35 @@ def load_case(tag):
         table=z[f"{tag}/embedding/table"], learned=z[f"{tag}/embedding/learned"], onehot=z[f"{tag}/embedding/onehot"],
         grad_out=z[f"{tag}/embedding/grad_out"], grad_table=z[f"{tag}/embedding/grad_table"],
         egress_x=z[f"{tag}/egress/x"], egress={name: z[f"{tag}/egress/{name}"] for name, _ in variables})
+
+
+def full_size_batch(B=2, seed=0):
+    """BASELINE configs[1] geometry: 192 x 64 x 48, interior minus a 12 x 16 x 32 obstacle."""
+    from turbdiff_amd.data.ofles import (BoundaryCondition, OpenFOAMBatch, OpenFOAMData, OpenFOAMMetadata, OpenFOAMStats,
+                                         Variable)
+
+    g = torch.Generator().manual_seed(seed)
+    n = (192, 64, 48)
+    inside = torch.zeros(n, dtype=torch.bool)
+    inside[1:-1, 1:-1, 1:-1] = True
+    inside[13:25, 1:17, 1:33] = False
+    idx = torch.arange(inside.numel()).reshape(n)
+    cell_idx = idx[inside]
+    walls = torch.cat([idx[:, 0, :].flatten(), idx[:, -1, :].flatten(), idx[:, :, 0].flatten(), idx[:, :, -1].flatten(),
+                       idx[13:25, 1:17, 1:33].flatten()])
+    boundaries = {"walls": {"idx": walls.to("cuda:0")}, "inlets": {"idx": idx[0].flatten().to("cuda:0")},
+                  "outlets": {"idx": idx[-1].flatten().to("cuda:0")}}
+    FV = BoundaryCondition.Type.FIXED_VALUE
+    bcs = {Variable.U: {"walls": BoundaryCondition(FV, torch.zeros(3)), "inlets": BoundaryCondition(FV, torch.tensor([1.0, 0.0, 0.0])),
+                        "outlets": BoundaryCondition(BoundaryCondition.Type.INLET_OUTLET)},
+           Variable.P: {"outlets": BoundaryCondition(FV, torch.tensor(0.0))}}
+    meta = OpenFOAMMetadata(np.array(n), cell_idx.to("cuda:0"), boundaries, bcs)
+    samples = {Variable.U: torch.randn(B, len(cell_idx), 3, generator=g).to("cuda:0"),
+               Variable.P: torch.randn(B, len(cell_idx), 1, generator=g).to("cuda:0")}
+    stats = OpenFOAMStats({"u": {"mean": torch.tensor([0.3, 0.0, 0.1]), "std": torch.tensor([0.5, 0.2, 0.25]),
+                                 "min": -torch.ones(3), "max": torch.ones(3) * 2},
+                           "p": {"mean": torch.tensor(0.1), "std": torch.tensor(0.7), "min": torch.tensor(-1.0), "max": torch.tensor(3.0)},
+                           "norm(u)": {"mean": torch.tensor(0.9), "std": torch.tensor(0.4), "min": torch.tensor(0.0), "max": torch.tensor(2.5)}})
+    return OpenFOAMBatch(OpenFOAMData(meta, torch.zeros(B), samples), stats)
+
+

@@ -1,5 +1,11 @@
+"""Accuracy report at BASELINE configs[1] size (a checker script, kept under tests/ because it runs the CPU oracle):
+rel-L2 of the HIP forward against the oracle at 192x64x48 in the fp32 / split-precision / bf16 modes.
+GPU box:  python tests/report_accuracy.py
+"""
 import sys, torch
-sys.path.insert(0, "."); sys.path.insert(0, "generative-turbulence_amd"); sys.path.insert(0, "tests")
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "generative-turbulence_amd")); sys.path.insert(0, str(ROOT / "tests"))
 from oracle import turbdiff_oracle as O
 from turbdiff_amd.models.ddpm import DenoisingModel
 from turbdiff_amd.models.conditioning import Conditioning

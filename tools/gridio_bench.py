@@ -12,7 +12,7 @@ from turbdiff_amd import gridio
 from turbdiff_amd.data.ofles import Variable
 from turbdiff_amd.models.cell_type_embeddings import CellTypeEmbedding
 from turbdiff_amd.models.normalization import Normalization
-from test_gridio import _full_size_batch
+from grid_cases import full_size_batch as _full_size_batch
 
 HBM = 8e12
 
@@ -74,15 +74,6 @@ def main():
     for name, ours, ref, nbytes in rows:
         t, tr = timeit(ours), timeit(ref)
         print(f"{name:52s} {t*1e6:8.1f} {nbytes/t/1e9:7.0f} {100*nbytes/t/HBM:6.1f} {tr*1e6:14.1f} {tr/t:8.1f}x")
-    # CPU leg: the oracle (numpy restatement of the reference) on this host, one pass
-    from oracle import grid_oracle as G
-    s = {"u": data.samples[Variable.U].cpu().numpy(), "p": data.samples[Variable.P].cpu().numpy()}
-    bnd = {k: meta.boundaries[k]["idx"].cpu().numpy() for k in ("walls", "inlets", "outlets")}
-    fixed = {"u": {"walls": np.zeros(3, np.float32), "inlets": np.array([1, 0, 0], np.float32)}, "p": {"outlets": np.array(0.0, np.float32)}}
-    t0 = time.perf_counter()
-    x = G.grid_embedding(s, (("u", 3), ("p", 1)), meta.cell_idx.cpu().numpy(), plan.counts, bnd, fixed)
-    G.normalize_grid(x, mean.cpu().numpy(), std.cpu().numpy())
-    print(f"CPU oracle (numpy + torch-CPU addcmul, 1 process) ingress: {(time.perf_counter() - t0)*1e3:.1f} ms")
 
 
 if __name__ == "__main__":

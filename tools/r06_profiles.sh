@@ -7,7 +7,7 @@ python bench.py --dtype f32 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_f3
 python bench.py --dtype f32s --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_f32s.log 2>&1; tail -1 $O/bench_f32s.log > $O/r06_bench_f32s.json
 python tools/conv_bench.py --dtype f32 > $O/r06_conv3_f32_table.txt 2>&1
 python tools/conv_bench.py --dtype f32 --impl split > $O/r06_conv3_f32s_table.txt 2>&1
-python tools/accuracy_report.py > $O/r06_accuracy.txt 2>&1
+python tests/report_accuracy.py > $O/r06_accuracy.txt 2>&1
 python tools/metrics_bench.py > $O/r06_metrics.txt 2>&1
 python tools/gridio_bench.py > $O/r06_gridio.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
