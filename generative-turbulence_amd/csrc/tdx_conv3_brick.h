@@ -1,12 +1,12 @@
 // Brick geometry shared by the fp32-tensor MFMA conv kernels (tdx_conv3_mfma_f32.hip, tdx_conv3_mfma_split.hip).
 //
 // A workgroup owns one brick of 256 output voxels: 4 x 8 x 8, or the "thin" 2 x 16 x 8 used for the 1-2 voxel
-// remainder slabs that a (padded) grid leaves next to the exactly tiled main region -- the zero-padded data
-// gradient runs on (X+2)(Y+2)(Z+2) grids, which never divide the main brick (194 x 66 x 50: 3087 main bricks
+// remainder slabs that a grid leaves next to the exactly tiled main region (194 x 66 x 50: 3087 main bricks
 // against 2304 + 215 with thin slabs).  Bricks live in LOCAL axes: local axis k is global axis perm[k], so the
 // short brick edge can be laid along whichever grid axis leaves the fewest bricks, and the thin edge along a
 // slab's thin axis; weight taps are re-indexed through ws[].  One launch carries up to three regions (the
-// three slabs of a grid go out together).
+// three slabs of a grid go out together).  Since the data gradient runs on the ORIGINAL grid (its halo-shell term
+// is tdx_conv3_shell.hip) the slabs only occur on grids like the reference's real 194 x 50 x 50.
 #pragma once
 #include "tdx_common.h"
 #include "tdx_conv3.h"
@@ -145,8 +145,8 @@ static inline int64_t brick_count(const int ext_g[3], const int perm[3], int sha
 }
 
 // Regions of one conv call: `main` (4 x 8 x 8 bricks, one region) and `thin` (2 x 16 x 8 bricks, 0-3 slab
-// regions).  Forward / replicate convs: the whole grid with the brick orientation that leaves the fewest
-// bricks.  Zero-padded data gradient: remainders of 1-2 voxels along an axis become thin slabs.
+// regions).  Zero-padded data gradient on big grids: remainders of 1-2 voxels along an axis become thin slabs.
+// Otherwise the whole grid with the brick orientation that leaves the fewest bricks.
 static inline void brick_plan(const Conv3Geom& g, bool zero_pad, bool allow_thin, BrickRegions& main, BrickRegions& thin,
                               int main_shape = BRICK_MAIN) {
     static const int cand[3][3] = {{0, 1, 2}, {1, 0, 2}, {2, 0, 1}};  // which global axis gets the short (4 / 2) edge
@@ -166,7 +166,8 @@ static inline void brick_plan(const Conv3Geom& g, bool zero_pad, bool allow_thin
             const int rem = Eo[a] % bd[a];
             if ((rem == 1 || rem == 2) && Eo[a] > bd[a]) { slab[a] = true; Em[a] = Eo[a] - rem; }
         }
-    } else if (!zero_pad) {
+    }
+    if (!slab[0] && !slab[1] && !slab[2]) {
         int64_t best = -1;
         for (int c = 0; c < 3; ++c) {
             const int64_t n = brick_count(Em, cand[c], main_shape);

@@ -350,70 +350,6 @@ conv3_fold_kernel(const T* __restrict__ dpad, T* __restrict__ dx1, int C1, T* __
     o.store(dst);
 }
 
-// Face fix-up of the MFMA data gradient: the conv kernel has already written the interior term
-// dpad[u + 1] into dx; boundary voxels additionally receive the halo-shell positions that clamp
-// onto them.  One thread per (boundary voxel, 8-channel vector); the boundary set is enumerated
-// without duplicates as  x-faces | y-faces minus x-faces | z-faces minus x- and y-faces.
-template <typename T>
-__global__ void __launch_bounds__(256)
-conv3_fold_faces_kernel(const T* __restrict__ dpad, T* __restrict__ dx1, int C1, T* __restrict__ dx2, int C2, int B,
-                        int X, int Y, int Z, int64_t nface, int64_t total) {
-    const int C = C1 + C2;
-    const int L = C >> 3;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int lc = (int)(i % L);
-    int64_t f = i / L;
-    const int b = (int)(f / nface);
-    f -= (int64_t)b * nface;
-    // decode boundary voxel index f
-    const int nx = (X > 1) ? 2 : 1, ny = (Y > 1) ? 2 : 1, nz = (Z > 1) ? 2 : 1;
-    const int Xi = X - nx, Yi = Y - ny;  // interior extents along x / y (voxels not on those faces)
-    int ux, uy, uz;
-    const int64_t n_xf = (int64_t)nx * Y * Z;
-    const int64_t n_yf = (int64_t)ny * Xi * Z;
-    if (f < n_xf) {
-        const int s = (int)(f / ((int64_t)Y * Z));
-        const int rem = (int)(f - (int64_t)s * Y * Z);
-        ux = s == 0 ? 0 : X - 1; uy = rem / Z; uz = rem % Z;
-    } else if (f < n_xf + n_yf) {
-        f -= n_xf;
-        const int s = (int)(f / ((int64_t)Xi * Z));
-        const int rem = (int)(f - (int64_t)s * Xi * Z);
-        uy = s == 0 ? 0 : Y - 1; ux = 1 + rem / Z; uz = rem % Z;
-    } else {
-        f -= n_xf + n_yf;
-        const int s = (int)(f / ((int64_t)Xi * Yi));
-        const int rem = (int)(f - (int64_t)s * Xi * Yi);
-        uz = s == 0 ? 0 : Z - 1; ux = 1 + rem / Yi; uy = 1 + rem % Yi;
-    }
-    int x0, x1, y0, y1, z0, z1;
-    fold_range(ux, X, x0, x1);
-    fold_range(uy, Y, y0, y1);
-    fold_range(uz, Z, z0, z1);
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    const int Xp = X + 2, Yp = Y + 2, Zp = Z + 2;
-    for (int px = x0; px <= x1; ++px)
-        for (int py = y0; py <= y1; ++py)
-            for (int pz = z0; pz <= z1; ++pz) {
-                if (px == ux + 1 && py == uy + 1 && pz == uz + 1) continue;  // interior term is already in dx
-                Vec8<T> t;
-                t.load(dpad + ((((int64_t)b * Xp + px) * Yp + py) * Zp + pz) * C + lc * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += t.v[j];
-            }
-    const int64_t vox = (((int64_t)b * X + ux) * Y + uy) * Z + uz;
-    const int c = lc * 8;
-    T* dst = (c < C1) ? dx1 + vox * C1 + c : dx2 + vox * C2 + (c - C1);
-    Vec8<T> o;
-    o.load(dst);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o.v[j] += acc[j];
-    o.store(dst);
-}
-
 // ------------------------------------------------------------------ direct weight grad ---
 // dwp[tap][ci][co] += sum over a chunk of voxels of x[clamp(v+tap), ci] * dy[v, co]
 #define D3W_VOX 8192
@@ -588,10 +524,15 @@ extern "C" int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void
 }
 
 extern "C" size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z, int Cin, int dtype, int impl) {
+    // the padded tensor of the vector-ALU path (shapes the MFMA kernels do not cover, TDX_CONV_DIRECT); which path a
+    // call takes also depends on Cout, so the size is the same for all; the MFMA paths do not touch it
     (void)impl;
     return (size_t)B * (X + 2) * (Y + 2) * (Z + 2) * Cin * (dtype == TDX_BF16 ? 2 : 4) + 256;
 }
 
+// dx = adjoint of the replicate-padded conv.  MFMA paths: main term = zero-padded correlation on the original grid
+// (the conv kernel, epilogue writes dx incl. the fused addend), then the halo-shell term added by
+// conv3_shell_launch.  Vector-ALU path: correlation on the padded grid into the workspace, then the fold.
 static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2, const void* add1,
                                const void* add2, int B, int X, int Y, int Z, int Cout, int dtype, int impl,
                                void* workspace, void* stream) {
@@ -599,50 +540,33 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
     TDX_CHECK_ARG(C2 == 0 || dx2);
     const int Cin = C1 + C2;
     if ((C1 % 8) || (C2 % 8) || (Cout % 8)) return TDX_ESHAPE;
-    // adjoint on the padded grid: dpad[p'] = sum_e wb[e] dy_zero[p' - 1 + e]
-    Conv3Geom g = {B, X, Y, Z, X + 2, Y + 2, Z + 2, -1};
+    hipStream_t st = as_stream(stream);
+    const Conv3Geom g0 = {B, X, Y, Z, X, Y, Z, 0};
     const bool use_mfma = dtype == TDX_BF16 && (impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, Cout, 0, Cin)));
     int rc;
     if (use_mfma) {
         if (!mfma_ok(dtype, Cout, 0, Cin)) return TDX_ESHAPE;
-        {
-            // interior of dx written by the conv epilogue, halo shell into the workspace, then faces
-            rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream), nullptr,
-                                   dx1, C1, dx2, add1, add2);
-            if (rc != TDX_OK) return rc;
-            const int nx = (X > 1) ? 2 : 1, ny = (Y > 1) ? 2 : 1, nz = (Z > 1) ? 2 : 1;
-            const int64_t nface = (int64_t)nx * Y * Z + (int64_t)ny * (X - nx) * Z + (int64_t)nz * (X - nx) * (Y - ny);
-            const int64_t total = (int64_t)B * nface * (Cin / 8);
-            if (total > 0)
-                hipLaunchKernelGGL((conv3_fold_faces_kernel<bf16>), dim3(ceil_div(total, 256)), dim3(256), 0,
-                                   as_stream(stream), (const bf16*)workspace, (bf16*)dx1, C1, (bf16*)dx2, C2, B, X, Y, Z,
-                                   nface, total);
-            return tdx_launch_status();
-        }
+        rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2);
+        if (rc != TDX_OK) return rc;
+        return conv3_shell_launch(dy, wb, dx1, C1, dx2, B, X, Y, Z, Cout, Cin, 0, st);
     } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT &&
                ((impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin)) || conv3_mfma_f32_supported(Cout, 0, Cin))) {
-        // as the bf16 path: dx from the conv epilogue, the halo shell into the workspace, then the faces
         const bool split = impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin);
-        rc = split ? conv3_mfma_split_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream), nullptr,
-                                             dx1, C1, dx2, add1, add2)
-                   : conv3_mfma_f32_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, true, as_stream(stream), nullptr,
-                                           dx1, C1, dx2, add1, add2);
+        rc = split ? conv3_mfma_split_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2,
+                                             add1, add2)
+                   : conv3_mfma_f32_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2,
+                                           add1, add2);
         if (rc != TDX_OK) return rc;
-        const int nx = (X > 1) ? 2 : 1, ny = (Y > 1) ? 2 : 1, nz = (Z > 1) ? 2 : 1;
-        const int64_t nface = (int64_t)nx * Y * Z + (int64_t)ny * (X - nx) * Z + (int64_t)nz * (X - nx) * (Y - ny);
-        const int64_t total = (int64_t)B * nface * (Cin / 8);
-        if (total > 0)
-            hipLaunchKernelGGL((conv3_fold_faces_kernel<float>), dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream),
-                               (const float*)workspace, (float*)dx1, C1, (float*)dx2, C2, B, X, Y, Z, nface, total);
-        return tdx_launch_status();
-    } else {
-        rc = conv3_direct_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, dtype, true, as_stream(stream));
+        return conv3_shell_launch(dy, wb, dx1, C1, dx2, B, X, Y, Z, Cout, Cin, split ? 2 : 1, st);
     }
+    // adjoint on the padded grid: dpad[p'] = sum_e wb[e] dy_zero[p' - 1 + e]
+    const Conv3Geom g = {B, X, Y, Z, X + 2, Y + 2, Z + 2, -1};
+    rc = conv3_direct_launch(dy, Cout, nullptr, 0, wb, nullptr, workspace, g, Cin, dtype, true, st);
     if (rc != TDX_OK) return rc;
     const int64_t total = (int64_t)B * X * Y * Z * (Cin / 8);
-    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv3_fold_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0,
-                                                  as_stream(stream), (const T*)workspace, (T*)dx1, C1, (T*)dx2, C2,
-                                                  (const T*)add1, (const T*)add2, B, X, Y, Z, total));
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv3_fold_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, st,
+                                                  (const T*)workspace, (T*)dx1, C1, (T*)dx2, C2, (const T*)add1, (const T*)add2,
+                                                  B, X, Y, Z, total));
     return tdx_launch_status();
 }
 

@@ -1,5 +1,5 @@
-// bf16 MFMA implicit-GEMM 3x3x3 convolution for gfx950 (forward and, with zero padding on
-// the padded grid, the data gradient).
+// bf16 MFMA implicit-GEMM 3x3x3 convolution for gfx950 (forward and, with zero padding, the main
+// term of the data gradient; its halo-shell term is tdx_conv3_shell.hip).
 //
 //   M = output voxels (a 256-voxel brick per workgroup), N = output channels (BN = 32/64 per
 //   workgroup), K = 27 taps x input channels, walked in 16-channel slices.
@@ -295,11 +295,11 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             uint4 val = *reinterpret_cast<const uint4*>(sO + out_addr<BN>(v, cidx));
             bool direct = false;
             if (ZERO_PAD && d1 != nullptr) {
-                // data gradient: padded position = original voxel + 1.  Interior positions go
+                // data gradient: output position c is voxel c + off of dx (off = 0: evaluated on the original
+                // grid, the halo-shell term comes from tdx_conv3_shell.hip).  Positions inside the grid go
                 // straight to dx (split over the two inputs of a concatenated conv, plus the optional
-                // fused addend = the gradient arriving over the block's residual path); only the
-                // halo shell is written to the padded workspace for the face fix-up.
-                const int u0 = c0 - 1, u1 = c1 - 1, u2 = c2 - 1;
+                // fused addend = the gradient arriving over the block's residual path).
+                const int u0 = c0 + g.off, u1 = c1 + g.off, u2 = c2 + g.off;
                 if (u0 >= 0 && u0 < g.Ei[0] && u1 >= 0 && u1 < g.Ei[1] && u2 >= 0 && u2 < g.Ei[2]) {
                     const int64_t u = (int64_t)b * g.in_batch + u0 * g.si[0] + u1 * g.si[1] + u2 * g.si[2];
                     const int n = n0 + cidx * 8;

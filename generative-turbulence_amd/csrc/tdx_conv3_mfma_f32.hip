@@ -285,15 +285,18 @@ int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const 
     } while (0)
     const bool perm = main.v[0].perm[0] != 0;
     if (NT == 2) {
-        if (zero_pad) F3_GO(2, true, BRICK_MAIN, false, main);
+        if (zero_pad && perm) F3_GO(2, true, BRICK_MAIN, true, main);
+        else if (zero_pad) F3_GO(2, true, BRICK_MAIN, false, main);
         else if (perm) F3_GO(2, false, BRICK_MAIN, true, main);
         else F3_GO(2, false, BRICK_MAIN, false, main);
     } else if (big) {
-        if (zero_pad) F3_GO(1, true, BRICK_BIG, false, main);
+        if (zero_pad && perm) F3_GO(1, true, BRICK_BIG, true, main);
+        else if (zero_pad) F3_GO(1, true, BRICK_BIG, false, main);
         else if (perm) F3_GO(1, false, BRICK_BIG, true, main);
         else F3_GO(1, false, BRICK_BIG, false, main);
     } else {
-        if (zero_pad) F3_GO(1, true, BRICK_MAIN, false, main);
+        if (zero_pad && perm) F3_GO(1, true, BRICK_MAIN, true, main);
+        else if (zero_pad) F3_GO(1, true, BRICK_MAIN, false, main);
         else if (perm) F3_GO(1, false, BRICK_MAIN, true, main);
         else F3_GO(1, false, BRICK_MAIN, false, main);
     }

@@ -338,15 +338,18 @@ int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, cons
     } while (0)
     const bool perm = main.v[0].perm[0] != 0;  // forward on ragged grids: the short brick edge on another axis
     if (NT == 2) {
-        if (zero_pad) SP_GO(2, true, BRICK_MAIN, false, main);
+        if (zero_pad && perm) SP_GO(2, true, BRICK_MAIN, true, main);
+        else if (zero_pad) SP_GO(2, true, BRICK_MAIN, false, main);
         else if (perm) SP_GO(2, false, BRICK_MAIN, true, main);
         else SP_GO(2, false, BRICK_MAIN, false, main);
     } else if (big) {
-        if (zero_pad) SP_GO(1, true, BRICK_BIG, false, main);
+        if (zero_pad && perm) SP_GO(1, true, BRICK_BIG, true, main);
+        else if (zero_pad) SP_GO(1, true, BRICK_BIG, false, main);
         else if (perm) SP_GO(1, false, BRICK_BIG, true, main);
         else SP_GO(1, false, BRICK_BIG, false, main);
     } else {
-        if (zero_pad) SP_GO(1, true, BRICK_MAIN, false, main);
+        if (zero_pad && perm) SP_GO(1, true, BRICK_MAIN, true, main);
+        else if (zero_pad) SP_GO(1, true, BRICK_MAIN, false, main);
         else if (perm) SP_GO(1, false, BRICK_MAIN, true, main);
         else SP_GO(1, false, BRICK_MAIN, false, main);
     }

@@ -305,6 +305,21 @@ class DenoisingModel(nn.Module):
         center = KwargsSequential(rb(mid, mid), Residual(PreNorm(norm_klass(mid), Attention(mid))), rb(mid, mid))
         self.u_net = UNet(down, up, center)
 
+    def grad_ready_order(self):
+        """Parameters in the order their gradients become ready in backward (the reverse of the forward's
+        execution order, which is NOT the registration order): decode, up path from the finest level down,
+        bottleneck, down path from the deepest level up, encoders, and last the conditioning MLP, whose
+        input gradient collects a term from every block.  ``parallel.BucketedDataParallel`` lays out its
+        all-reduce buckets in this order, so the first training step already overlaps."""
+        mods = [self.decode[1], self.decode[0]]
+        mods += list(reversed(self.u_net.upsampling_blocks))
+        mods += list(reversed(list(self.u_net.center_block)))
+        mods += list(reversed(self.u_net.downsampling_blocks))
+        mods += [getattr(self, n) for n in ("encode_c_local", "encode_x", "geometry_embedding", "encode_c_global", "process_c")
+                 if hasattr(self, n)]
+        for m in mods:
+            yield from reversed(list(m.parameters()))
+
     def set_compute_dtype(self, dtype: torch.dtype):
         """float32 (parity mode) or bfloat16 (activation storage + MFMA operands)."""
         assert dtype in (torch.float32, torch.bfloat16)
@@ -485,11 +500,13 @@ class GaussianDiffusion(nn.Module):
 
     # ---- helpers
     def domain_mask(self, cell_idx: torch.Tensor, V: int):
-        """(uint8 [V] mask, n_cells) for a flat in-domain cell index list; cached per tensor."""
-        key = (cell_idx.data_ptr(), cell_idx.numel(), V, cell_idx.device)
-        if self._mask_cache is None or self._mask_cache[0] != key:
-            self._mask_cache = (key, ops.cell_mask(cell_idx, V), int(cell_idx.numel()))
-        return self._mask_cache[1], self._mask_cache[2]
+        """(uint8 [V] mask, n_cells) for a flat in-domain cell index list.  Cached for the tensor OBJECT it was
+        built from (held alive by the cache, so its address cannot be handed to another geometry's index list)
+        at the version it had then (an in-place edit rebuilds the mask)."""
+        c = self._mask_cache
+        if c is None or c[0] is not cell_idx or c[1] != cell_idx._version or c[2] != V:
+            c = self._mask_cache = (cell_idx, cell_idx._version, V, ops.cell_mask(cell_idx, V), int(cell_idx.numel()))
+        return c[3], c[4]
 
     @property
     def loss_fn(self):

@@ -9,32 +9,62 @@ parameter mass sits in the middle of the network (center + down.3 + up.0 hold ~8
 gradients become ready when roughly half of backward -- all the high-resolution down path --
 is still to run, which is what hides the collective.
 
-Buckets follow the order in which gradients became ready during the first backward pass
-(decode -> up -> center -> down -> encoders), not the registration order.
+Buckets are PERSISTENT flat buffers, one set per (dtype, device), laid out in the order in which
+gradients become ready in backward (decode -> up -> center -> down -> encoders).  That order is
+taken from the module (``grad_ready_order()``, see ``models.ddpm.DenoisingModel``) when it offers
+one -- so the very first step already overlaps -- and otherwise observed during the first backward.
+A parameter's hook scales its fresh gradient by 1 / world straight into its slice of the bucket (one
+pass, no ``torch.cat``, no allocation) and re-points ``p.grad`` at that slice; the all-reduce runs in
+place, so after ``finish()`` the optimiser reads the averaged gradients through the same views.
+
+Contract: exactly ONE backward per ``finish()`` (no gradient accumulation across backwards), equal
+per-rank batch sizes (ranks are averaged with equal weight; ``data.ofles.OpenFOAMSampler`` pads
+the shards to equal length).
 """
 
 from __future__ import annotations
+
+import time
 
 import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None):
+def init_from_env(backend: str | None = None, force: bool = False):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun).
-    Returns (rank, world_size, local_rank).  No-op for single-process runs."""
+    Returns (rank, world_size, local_rank).  A single-process run creates no group unless
+    ``force`` (then a world-size-1 group: the communicator path runs without a second GPU)."""
     import os
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _static_ready_order(module: torch.nn.Module, params: list) -> list[int] | None:
+    """Indices into `params` in the order their gradients become ready, from the first submodule that
+    offers ``grad_ready_order()`` (an iterable of parameters); parameters it does not list go last."""
+    for m in module.modules():
+        fn = getattr(m, "grad_ready_order", None)
+        if callable(fn):
+            index = {id(p): i for i, p in enumerate(params)}
+            order, seen = [], set()
+            for p in fn():
+                i = index.get(id(p))
+                if i is not None and i not in seen:
+                    seen.add(i)
+                    order.append(i)
+            return order + [i for i in range(len(params)) if i not in seen]
+    return None
 
 
 class BucketedDataParallel:
@@ -44,51 +74,88 @@ class BucketedDataParallel:
         loss.backward()                            # hooks launch async all-reduces
         ddp.finish()                               # wait; p.grad <- mean over ranks
         optimizer.step()
+
+    compress="bf16": gradients travel as bfloat16 (half the bytes per xGMI link) and are widened
+    back into the fp32 buckets the optimiser reads; off by default (changes the arithmetic).
+    force=True keeps the hooks and collectives active at world size 1 (tests of the RCCL path).
     """
 
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, group=None, broadcast: bool = True):
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 48.0, group=None, broadcast: bool = True,
+                 compress: str | None = None, force: bool = False):
         self.module = module
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = (self.world > 1 or force) and dist.is_initialized()
+        self.enabled = True  # False: hooks do nothing (bench.py's no-communication reference leg)
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.bucket_bytes = int(bucket_mb * 2**20)
-        self._order: list[int] = []          # ready order observed in the first backward
+        assert compress in (None, "bf16")
+        self.compress = compress
+        self._order: list[int] = []          # ready order observed in a backward (when no static order exists)
         self._buckets: list[list[int]] | None = None
         self._bucket_of: dict[int, int] = {}
+        self._slot: dict[int, tuple[int, int]] = {}   # param index -> (bucket, offset)
         self._pending: list[int] = []
-        self._flat: dict[int, torch.Tensor] = {}
+        self._flat: list[torch.Tensor] = []           # persistent reduced-precision-free buckets (param dtype)
+        self._wire: list[torch.Tensor | None] = []    # bf16 wire buffers (compress) or None
         self._work: list = []
-        self._pads: dict = {}
         self._launched: set[int] = set()
-        if self.world > 1 and broadcast:
-            for p in self.params:
-                dist.broadcast(p.data, src=0, group=group)
-            for b in module.buffers():
-                dist.broadcast(b.data, src=0, group=group)
-        if self.world > 1:
+        self._seen: set[int] = set()
+        self.stats = {"wait_s": 0.0, "steps": 0}
+        if self.active and broadcast:
+            with torch.no_grad():
+                for p in self.params:
+                    dist.broadcast(p.detach(), src=0, group=group)
+                for b in module.buffers():
+                    dist.broadcast(b.detach(), src=0, group=group)
+            # the broadcast wrote through detached aliases: bump the version counters so that caches keyed
+            # on Tensor._version (ops._packed_conv3) repack on the non-zero ranks
+            torch.autograd.graph.increment_version(self.params)
+        if self.active:
+            order = _static_ready_order(module, self.params)
+            if order is not None:
+                self._build_buckets(order)
             for i, p in enumerate(self.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
     # -- bucket construction ------------------------------------------------------------
     def _build_buckets(self, order: list[int]):
-        seen = set(order)
-        order = order + [i for i in range(len(self.params)) if i not in seen]  # unused params last
-        buckets, cur, cur_bytes = [], [], 0
+        seen, dedup = set(), []
+        for i in order:  # de-duplicate (a parameter used twice fires once per backward, but be safe)
+            if i not in seen:
+                seen.add(i)
+                dedup.append(i)
+        order = dedup + [i for i in range(len(self.params)) if i not in seen]  # unused params last
+        buckets, cur, cur_bytes, cur_key = [], [], 0, None
         for i in order:
-            n = self.params[i].numel() * self.params[i].element_size()
-            if cur and cur_bytes + n > self.bucket_bytes:
+            p = self.params[i]
+            key = (p.dtype, p.device)
+            n = p.numel() * p.element_size()
+            if cur and (cur_bytes + n > self.bucket_bytes or key != cur_key):
                 buckets.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(i)
             cur_bytes += n
+            cur_key = key
         if cur:
             buckets.append(cur)
         self._buckets = buckets
         self._bucket_of = {i: b for b, idxs in enumerate(buckets) for i in idxs}
         self._pending = [len(b) for b in buckets]
+        self._flat, self._wire, self._slot = [], [], {}
+        for b, idxs in enumerate(buckets):
+            p0 = self.params[idxs[0]]
+            align = max(1, 16 // p0.element_size())  # every slice starts on a 16-byte boundary (fused optimiser)
+            off = 0
+            for i in idxs:
+                self._slot[i] = (b, off)
+                n = self.params[i].numel()
+                off += n + (-n) % align
+            self._flat.append(torch.zeros(off, dtype=p0.dtype, device=p0.device))
+            self._wire.append(torch.zeros(off, dtype=torch.bfloat16, device=p0.device) if self.compress == "bf16" else None)
 
     def bucket_layout(self):
-        """[(n_params, bytes)] per bucket, in launch order (None before the first backward)."""
+        """[(n_params, bytes)] per bucket, in launch order (None before the buckets exist)."""
         if self._buckets is None:
             return None
         return [(len(b), sum(self.params[i].numel() * self.params[i].element_size() for i in b)) for b in self._buckets]
@@ -96,9 +163,16 @@ class BucketedDataParallel:
     # -- hooks ----------------------------------------------------------------------------
     def _make_hook(self, i: int):
         def hook(param):
-            if self._buckets is None:
-                self._order.append(i)  # first pass: only record the order
+            if not self.enabled:
                 return
+            if i in self._seen:
+                raise RuntimeError("BucketedDataParallel: a parameter received a second gradient before finish() "
+                                   "(one backward per finish(); gradient accumulation is not supported)")
+            self._seen.add(i)
+            if self._buckets is None:
+                self._order.append(i)  # no static order: the first pass only records it
+                return
+            self._stage(i)
             b = self._bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0:
@@ -106,55 +180,73 @@ class BucketedDataParallel:
 
         return hook
 
-    def _pad(self, like: torch.Tensor, n: int) -> torch.Tensor:
-        key = (like.device, like.dtype, n)
-        z = self._pads.get(key)
-        if z is None:
-            z = self._pads[key] = torch.zeros(n, dtype=like.dtype, device=like.device)
-        return z
+    def _stage(self, i: int):
+        """g / world -> the parameter's slice of its bucket (one pass); p.grad becomes that slice."""
+        p = self.params[i]
+        b, off = self._slot[i]
+        view = self._flat[b][off : off + p.numel()].view_as(p)
+        g = p.grad
+        if g is None:
+            view.zero_()
+        elif g.data_ptr() != view.data_ptr():
+            torch.mul(g, 1.0 / self.world, out=view)
+        else:  # already the view (grad kept from the last step and accumulated in place): scale in place
+            view.mul_(1.0 / self.world)
+        p.grad = view
 
     def _launch(self, b: int):
-        idxs = self._buckets[b]
-        grads = [self.params[i].grad if self.params[i].grad is not None else torch.zeros_like(self.params[i]) for i in idxs]
-        # every slice starts on a 16-byte boundary (zero pads in between), so that the views handed back
-        # as .grad keep the alignment the fused optimiser's 16-B accesses want
-        parts = []
-        for g in grads:
-            parts.append(g.reshape(-1))
-            r = (-g.numel()) % 4
-            if r:
-                parts.append(self._pad(g, r))
-        flat = torch.cat(parts)
-        flat.div_(self.world)
-        self._flat[b] = flat
-        self._work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        assert b not in self._launched, "bucket launched twice in one step"
+        flat = self._flat[b]
+        if self.compress == "bf16":
+            wire = self._wire[b]
+            wire.copy_(flat)
+            self._work.append((dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True), b))
+        else:
+            self._work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), b))
         self._launched.add(b)
 
     # -- per-step API ----------------------------------------------------------------------
     def finish(self):
         """Complete the step's gradient exchange.  Must be called after backward()."""
-        if self.world == 1:
+        if not self.active or not self.enabled:
+            self._seen.clear()
             return
         if self._buckets is None:
-            # first step: gradients are all there; build buckets in the observed order and
+            # no static order and this was the first backward: build the buckets in the observed order and
             # reduce them now (no overlap on this step only)
             self._build_buckets(self._order)
-        for b in range(len(self._buckets)):
-            if b not in self._launched:
-                self._launch(b)  # parameters that received no gradient this step
-        for w in self._work:
-            w.wait()
+            for i in range(len(self.params)):
+                if i in self._seen:
+                    self._stage(i)
         for b, idxs in enumerate(self._buckets):
-            flat, off = self._flat[b], 0
-            for i in idxs:
-                p = self.params[i]
-                n = p.numel()
-                p.grad = flat[off : off + n].view_as(p)
-                off += n + (-n) % 4
+            if b not in self._launched:
+                for i in idxs:  # parameters that received no gradient this step contribute zeros
+                    if i not in self._seen:
+                        self._stage(i)
+                self._launch(b)
+        t0 = time.perf_counter()
+        for w, b in self._work:
+            w.wait()
+            if self.compress == "bf16":
+                self._flat[b].copy_(self._wire[b])
+        self.stats["wait_s"] += time.perf_counter() - t0
+        self.stats["steps"] += 1
         self._work.clear()
-        self._flat.clear()
         self._launched.clear()
+        self._seen.clear()
         self._pending = [len(b) for b in self._buckets]
+
+    def allreduce_only(self):
+        """Launch and wait for one all-reduce per bucket on whatever the buckets hold (bench.py's
+        communication-only leg: the time the collectives take when nothing overlaps them)."""
+        if not self.active or self._buckets is None:
+            return
+        for b in range(len(self._buckets)):
+            self._launch(b)
+        for w, b in self._work:
+            w.wait()
+        self._work.clear()
+        self._launched.clear()
 
 
 def shard_trajectories(n_total: int, rank: int, world: int) -> range:
