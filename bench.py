@@ -10,11 +10,16 @@ GaussianDiffusion.forward (t ~ randint, q_sample, U-Net forward, masked l2 loss)
 Inputs are resident in HBM before the timed region.  One JSON line is printed by rank 0:
   value        whole-job voxels/s = N * B * 192*64*48 * K / (max over ranks of the K-step time)
   roofline     the dominant kernel (MFMA implicit-GEMM 3x3x3 conv, forward launches): algorithmic
-               FLOPs of all its launches / their HIP-event time, against the 2.5 PFLOP/s dense
-               bf16 MFMA peak
-  cpu_baseline the CPU oracle (a PyTorch-CPU port of the reference math, fp32) timed on the
-               host cores on B = 1 of the same workload (N = 1, rank 0 only)
-  extra        fwd-only and sampling (DDPM samples/s, extrapolated from a few reverse steps) legs
+               FLOPs of all its launches / their HIP-event time, against the dense MFMA peak of the mode
+  cpu_baseline the CPU oracle (a PyTorch-CPU port of the reference math, fp32) timed on the host cores on
+               B = 1 of the same workload, at all cores and at 8 threads (N = 1, rank 0 only; runs FIRST,
+               so that the GPU legs are the last thing the driver's utilisation sampler sees)
+  extra        accuracy   rel-L2 of every mode's eps-hat against the CPU oracle at 192x64x48 (same weights, inputs)
+               parity_modes  the same step in the modes that meet north_star's 1e-4 gate (f32s: fp32 tensors +
+                             split-precision convs; f32: IEEE fp32 MFMA convs), each with its own roofline block
+               fwd-only and sampling legs (DDPM samples/s: >= 50 reverse steps timed; the full T = 1000 loop
+               when --steps >= 20); N > 1: overlap report of the gradient all-reduce and the sharded
+               sampling leg of BASELINE configs[3] (8 trajectories per GPU)
 """
 
 import argparse
@@ -33,8 +38,14 @@ for p in (ROOT, ROOT / "generative-turbulence_amd"):
 import torch  # noqa: E402
 
 GRID = (192, 64, 48)
+V = GRID[0] * GRID[1] * GRID[2]
 PEAK_BF16_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+# f32s issues three bf16 MFMAs per algorithmic product: its matrix-core ceiling is a third of the bf16 peak
+PEAK = {"bf16": PEAK_BF16_TFLOPS, "f32": PEAK_F32_TFLOPS, "f32s": PEAK_BF16_TFLOPS / 3}
+CONV_BYTES = {"bf16": 1417.6e6, "f32": 2835.2e6, "f32s": 2835.2e6}  # conv-only bytes per sample forward
+KERNEL = {"bf16": "conv3_mfma_kernel", "f32": "conv3_mfma_f32_kernel", "f32s": "conv3_mfma_split_kernel"}
+ACCURACY_T = 250  # diffusion time of the accuracy probe
 
 
 def synthetic_inputs(B, device, grid=GRID):
@@ -51,49 +62,69 @@ def synthetic_inputs(B, device, grid=GRID):
     return x.to(device), c.to(device), cell_idx.to(device)
 
 
-def build_model(device, dtype, timesteps=500):
-    from turbdiff_amd.models.ddpm import DenoisingModel, GaussianDiffusion
+def new_denoiser(timesteps=500):
+    from turbdiff_amd.models.ddpm import DenoisingModel
 
     torch.manual_seed(0)
-    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=timesteps,
-                         dim=32, u_net_levels=4, norm_type="group")
-    net.set_compute_dtype(dtype)
-    diff = GaussianDiffusion(net, timesteps=timesteps, beta_schedule="log-snr-linear", loss_type="l2", noise_bcs=True)
+    return DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=timesteps,
+                          dim=32, u_net_levels=4, norm_type="group")
+
+
+def build_model(device, timesteps=500):
+    from turbdiff_amd.models.ddpm import GaussianDiffusion
+
+    diff = GaussianDiffusion(new_denoiser(timesteps), timesteps=timesteps, beta_schedule="log-snr-linear", loss_type="l2",
+                             noise_bcs=True)
     return diff.to(device)
 
 
-def cpu_baseline(budget_s=25.0):
-    """fwd+bwd voxels/s of the CPU oracle on B=1 of the same workload."""
+def set_mode(diff, mode):
+    """bf16: bf16 storage + bf16 MFMA; f32: fp32 storage, IEEE fp32 MFMA convs; f32s: fp32 storage,
+    split-precision convs (bf16 hi + lo, three MFMAs per product)."""
+    diff.model.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
+    if mode == "f32s":
+        os.environ["TDX_CONV_IMPL"] = "split"
+    else:
+        os.environ.pop("TDX_CONV_IMPL", None)
+
+
+def cpu_baseline(budget_s=120.0):
+    """fwd+bwd voxels/s of the CPU oracle on B = 1 of the same workload, 1 warm-up + 3 timed iterations (fewer if
+    the budget runs out) at all host threads and at 8.  Also returns the oracle's eps-hat of the
+    accuracy probe (the forward of those iterations) for extra.accuracy."""
     from oracle import turbdiff_oracle as O
 
-    torch.manual_seed(0)
-    from turbdiff_amd.models.ddpm import DenoisingModel
-
-    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=500, dim=32,
-                         u_net_levels=4, norm_type="group")
+    net = new_denoiser()
     sd = {k: v.clone().requires_grad_() for k, v in net.state_dict().items()}
     del net
     x, c, cell_idx = synthetic_inputs(1, "cpu")
     buf = O.schedule_buffers("log-snr-linear", 500)
-    t = torch.tensor([250])
+    t = torch.tensor([ACCURACY_T])
     noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(1))
-    times = []
-    t_start = time.perf_counter()
-    it = 0
-    while True:
-        t0 = time.perf_counter()
-        loss, _ = O.p_losses(sd, buf, x, t, c, cell_idx, noise, timesteps=500, noise_bcs=True)
-        torch.autograd.grad(loss, list(sd.values()))
-        dt = time.perf_counter() - t0
-        if it > 0:  # first iteration is warm-up
-            times.append(dt)
-        it += 1
-        if len(times) >= 3 or (time.perf_counter() - t_start > budget_s and len(times) >= 1):
-            break
-    med = sorted(times)[len(times) // 2]
-    V = GRID[0] * GRID[1] * GRID[2]
-    return {"value": V / med, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"B=1 fwd+bwd of the same 192x64x48 step, fp32, median of {len(times)} after 1 warm-up ({med:.2f} s each)"}
+    all_threads = torch.get_num_threads()
+    legs, eps_ref = [], None
+    for nthreads in sorted({all_threads, min(8, all_threads)}, reverse=True):
+        torch.set_num_threads(nthreads)
+        times, t_start = [], time.perf_counter()
+        for it in range(4):
+            t0 = time.perf_counter()
+            loss, eps_hat = O.p_losses(sd, buf, x, t, c, cell_idx, noise, timesteps=500, noise_bcs=True)
+            torch.autograd.grad(loss, list(sd.values()))
+            dt = time.perf_counter() - t0
+            eps_ref = eps_hat.detach()
+            if it > 0:  # the first iteration is the warm-up
+                times.append(dt)
+            if time.perf_counter() - t_start > budget_s / 2 and times:
+                break
+        med = sorted(times)[len(times) // 2]
+        legs.append({"threads": nthreads, "voxels_per_s": V / med, "s_per_iteration": med, "timed_iterations": len(times)})
+    torch.set_num_threads(all_threads)
+    head = max(legs, key=lambda l: l["voxels_per_s"])  # the better of the two thread counts is the baseline
+    out = {"value": head["voxels_per_s"], "unit": "voxels/s", "cores": head["threads"], "kind": "port",
+           "sample": f"B=1 fwd+bwd of the same 192x64x48 step, fp32, median of {head['timed_iterations']} after 1 warm-up "
+                     f"({head['s_per_iteration']:.2f} s each)",
+           "legs": legs}
+    return out, {"x_t": O.q_sample(buf, x, t, noise), "t": t, "eps": eps_ref}
 
 
 def torch_rocm_baseline(B, dev, amp, steps=2):
@@ -102,11 +133,8 @@ def torch_rocm_baseline(B, dev, amp, steps=2):
     `cuda`, fp32 weights, optionally under bf16 autocast, same step (fwd + bwd + clip + RAdam).
     A reported baseline (--torch-baseline), never part of `value`."""
     from oracle import turbdiff_oracle as O
-    from turbdiff_amd.models.ddpm import DenoisingModel
 
-    torch.manual_seed(0)
-    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=500, dim=32,
-                         u_net_levels=4, norm_type="group")
+    net = new_denoiser()
     sd = {k: v.clone().to(dev).requires_grad_() for k, v in net.state_dict().items()}
     del net
     params = list(sd.values())
@@ -131,7 +159,6 @@ def torch_rocm_baseline(B, dev, amp, steps=2):
         step()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
-    V = GRID[0] * GRID[1] * GRID[2]
     res = {"ms_per_step": ms, "voxels_per_s": B * V / (ms * 1e-3), "batch": B, "precision": "bf16 autocast" if amp else "fp32",
            "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
     del sd, params, opt
@@ -161,6 +188,41 @@ def measured_traffic(mode="bf16"):
     return None, None
 
 
+CONV_CALLS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add", "tdx_conv3_bwd_weight"}
+
+
+def merged_kernel_times(timer):
+    kern = timer.summary()
+    # tdx_conv3_fwd_gn = the same conv kernel with the GroupNorm statistics in its epilogue
+    # (+ an 8 us finalize kernel inside the bracket): count it as a forward launch
+    for alias, name in (("tdx_conv3_fwd_gn", "tdx_conv3_fwd"), ("tdx_conv3_bwd_data_add", "tdx_conv3_bwd_data")):
+        if alias in kern:
+            f = kern.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+            g = kern.pop(alias)
+            for k in f:
+                f[k] += g[k]
+    return kern
+
+
+def roofline_block(kern, mode, B, K):
+    kf = kern.get("tdx_conv3_fwd")
+    if not kf or kf["ms"] <= 0:
+        return None
+    ach = kf["work"] / (kf["ms"] * 1e-3) / 1e12
+    traffic, tsrc = measured_traffic(mode)
+    return {"bound": "mfma", "achieved": ach, "peak": PEAK[mode], "unit": "TFLOP/s", "frac": ach / PEAK[mode],
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": tsrc, "algorithmic_bytes_per_launch": CONV_BYTES[mode] * B / 22,
+            "kernel": KERNEL[mode] + " (all tdx_conv3_fwd launches)", "launches": kf["launches"],
+            "avg_launch_ms": kf["ms"] / kf["launches"],
+            "conv_bandwidth_roofline_frac": (CONV_BYTES[mode] * B * K / (kf["ms"] * 1e-3)) / 8e12}
+
+
+def kernel_table(kern, K):
+    return {k: {"launches": v["launches"], "ms_per_step": v["ms"] / K, "tflops": v["work"] / max(v["ms"], 1e-9) / 1e9}
+            for k, v in kern.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,15 +230,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=6, help="per-GPU batch (reference: 6, config/model/diffusion.yaml:3)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32s"],
-                    help="bf16: bf16 storage + bf16 MFMA (BASELINE configs[1]); f32: fp32 storage, IEEE fp32 MFMA convs "
-                         "(the 1e-4 parity mode); f32s: fp32 storage, split-precision convs (bf16 hi + lo, 3 MFMAs per "
-                         "product: 1.2e-5 rel-L2 at full size, still inside the 1e-4 gate)")
-    ap.add_argument("--sample-steps", type=int, default=6, help="reverse steps timed for the sampling leg (0 = skip)")
+                    help="mode of the headline line.  bf16: bf16 storage + bf16 MFMA (BASELINE configs[1]); f32: fp32 storage, "
+                         "IEEE fp32 MFMA convs; f32s: fp32 storage, split-precision convs (bf16 hi + lo, 3 MFMAs per product). "
+                         "The other two modes are reported under extra.parity_modes / extra.accuracy in the same run")
+    ap.add_argument("--sample-steps", type=int, default=50, help="reverse steps timed for the sampling leg (0 = skip)")
     ap.add_argument("--sample-batch", type=int, default=8)
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="fused: ClipRAdam (clip + RAdam in 3 launches); torch: clip_grad_norm_ + torch.optim.RAdam")
+    ap.add_argument("--compress", default=None, choices=[None, "bf16"], help="N > 1: gradients travel as bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-parity-modes", action="store_true", help="skip the f32s / f32 legs of extra.parity_modes")
     ap.add_argument("--torch-baseline", action="store_true",
                     help="also time the same step through stock PyTorch-ROCm ops (MIOpen); adds extra.torch_rocm_reference")
     args = ap.parse_args()
@@ -192,36 +256,33 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    if args.dtype == "f32s":
-        os.environ["TDX_CONV_IMPL"] = "split"
     B, K, Wm = args.batch, args.steps, args.warmup
-    V = GRID[0] * GRID[1] * GRID[2]
 
-    diff = build_model(dev, dtype)
-    ddp = parallel.BucketedDataParallel(diff)
-    fused_opt = args.optimizer == "fused"
-    if fused_opt:  # clip 0.1 + RAdam in three launches (turbdiff_amd/optim.py)
-        from turbdiff_amd.optim import ClipRAdam
+    # ---- CPU leg first (rank 0, N = 1): baseline + the oracle's eps-hat for the accuracy probe
+    cpu, probe = None, None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, probe = cpu_baseline()
 
-        opt = ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1)
-    else:
-        opt = torch.optim.RAdam(diff.parameters(), lr=1e-4)
-    x, c_local, cell_idx = synthetic_inputs(B, dev)
     from turbdiff_amd.models.conditioning import Conditioning
+    from turbdiff_amd.optim import ClipRAdam
 
+    diff = build_model(dev)
+    x, c_local, cell_idx = synthetic_inputs(B, dev)
     C = {Conditioning.Type.CELL_TYPE: c_local}
     md = SimpleNamespace(cell_idx=cell_idx)
+    fused_opt = args.optimizer == "fused"
 
-    def train_step():
-        loss, _ = diff(x, C, md, None)
-        loss.backward()
-        ddp.finish()
-        if not fused_opt:
-            torch.nn.utils.clip_grad_norm_(diff.parameters(), 0.1)
-        opt.step()
-        opt.zero_grad(set_to_none=True)
-        return loss
+    # ---- accuracy probe: every mode's eps-hat on the oracle's x_t, BEFORE any optimiser step changes the weights
+    accuracy = None
+    if probe is not None:
+        accuracy = {"probe": f"eps-hat at t = {ACCURACY_T}, B = 1, 192x64x48, default init seed 0; rel-L2 vs the CPU oracle"}
+        xt, tt = probe["x_t"].to(dev), probe["t"].to(dev)
+        with torch.no_grad():
+            for m in ("bf16", "f32s", "f32"):
+                set_mode(diff, m)
+                e = diff.model(xt, tt, C).float().cpu()
+                accuracy[m] = ((e - probe["eps"]).norm() / probe["eps"].norm()).item()
+        del xt, tt
 
     def barrier():
         torch.cuda.synchronize()
@@ -229,33 +290,47 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(Wm):
-        train_step()
-    timer = _lib.KernelTimer({"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add",
-                               "tdx_conv3_bwd_weight"})
-    _lib.TIMER = timer
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        loss = train_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    _lib.TIMER = None
-    kern = timer.summary()
-    # tdx_conv3_fwd_gn = the same conv kernel with the GroupNorm statistics in its epilogue
-    # (+ a memset and an 8 us finalize kernel inside the bracket): count it as a forward launch
-    for alias, name in (("tdx_conv3_fwd_gn", "tdx_conv3_fwd"), ("tdx_conv3_bwd_data_add", "tdx_conv3_bwd_data")):
-        if alias in kern:
-            f = kern.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
-            g = kern.pop(alias)
-            for k in f:
-                f[k] += g[k]
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = tt.item()
-    value = world * B * V * K / elapsed
+    def max_over_ranks(v):
+        if world > 1:
+            tt = torch.tensor([v], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            return tt.item()
+        return v
 
+    ddp = parallel.BucketedDataParallel(diff, compress=args.compress)
+
+    def run_mode(mode, steps, warmup):
+        """`steps` timed training steps in `mode` -> (elapsed s (max over ranks), merged conv-kernel times, last loss)."""
+        set_mode(diff, mode)
+        opt = (ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1) if fused_opt
+               else torch.optim.RAdam(diff.parameters(), lr=1e-4))
+
+        def train_step():
+            loss, _ = diff(x, C, md, None)
+            loss.backward()
+            ddp.finish()
+            if not fused_opt:
+                torch.nn.utils.clip_grad_norm_(diff.parameters(), 0.1)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return loss.detach()
+
+        for _ in range(warmup):
+            train_step()
+        timer = _lib.KernelTimer(CONV_CALLS)
+        _lib.TIMER = timer
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = train_step()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        _lib.TIMER = None
+        kern = merged_kernel_times(timer)
+        return elapsed, kern, loss.item(), train_step
+
+    elapsed, kern, last_loss, train_step = run_mode(args.dtype, K, Wm)
+    value = world * B * V * K / elapsed
     out = {
         "metric": "U-Net fwd+bwd voxels/sec (DDPM training step, 192x64x48x4)",
         "value": value,
@@ -273,60 +348,103 @@ def main():
                                "DDPM train step (fwd+bwd+clip+RAdam)", "per_gpu_batch": B, "global_batch": B * world,
                    "grid": list(GRID), "timesteps": 500, "parallelism": f"dp{world}",
                    "optimizer": "ClipRAdam (fused clip 0.1 + RAdam)" if fused_opt else "clip_grad_norm_ + torch.optim.RAdam"},
-        "loss": float(loss),
+        "loss": last_loss,
     }
     if rank == 0:
-        # f32s issues three bf16 MFMAs per algorithmic product: its matrix-core ceiling is a third of the bf16 peak
-        peak = {"bf16": PEAK_BF16_TFLOPS, "f32": PEAK_F32_TFLOPS, "f32s": PEAK_BF16_TFLOPS / 3}[args.dtype]
-        kf = kern.get("tdx_conv3_fwd")
-        if kf and kf["ms"] > 0:
-            ach = kf["work"] / (kf["ms"] * 1e-3) / 1e12
-            traffic, tsrc = measured_traffic(args.dtype)
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                               "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-                               "traffic_source": tsrc,
-                               "algorithmic_bytes_per_launch": (1417.6e6 if dtype == torch.bfloat16 else 2835.2e6) * B / 22,
-                               "kernel": {"bf16": "conv3_mfma_kernel", "f32": "conv3_mfma_f32_kernel",
-                                          "f32s": "conv3_mfma_split_kernel"}[args.dtype] + " (all tdx_conv3_fwd launches)",
-                               "launches": kf["launches"], "avg_launch_ms": kf["ms"] / kf["launches"],
-                               "conv_bandwidth_roofline_frac": (1417.6e6 * B * K / (kf["ms"] * 1e-3)) / 8e12
-                               if dtype == torch.bfloat16 else (2835.2e6 * B * K / (kf["ms"] * 1e-3)) / 8e12}
-        out["kernels"] = {k: {"launches": v["launches"], "ms_per_step": v["ms"] / K,
-                              "tflops": v["work"] / max(v["ms"], 1e-9) / 1e9} for k, v in kern.items()}
+        rb = roofline_block(kern, args.dtype, B, K)
+        if rb:
+            out["roofline"] = rb
+        out["kernels"] = kernel_table(kern, K)
+    extra = {}
+    if accuracy is not None:
+        extra["accuracy"] = accuracy
+        out["rel_l2_vs_cpu_oracle"] = accuracy[args.dtype]
 
-    if not args.no_extra and world == 1:
-        extra = {}
-        # forward only (the north_star's "conv U-Net forward" figure)
-        with torch.no_grad():
-            tq = torch.full((B,), 250, device=dev)
-            for _ in range(2):
-                diff.model(x, tq, C)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                diff.model(x, tq, C)
-            torch.cuda.synchronize()
-            extra["fwd_ms_per_sample"] = 1e3 * (time.perf_counter() - t0) / 3 / B
+    # ---- N > 1: how much of the gradient all-reduce hides behind backward
+    if world > 1 and not args.no_extra:
+        ddp.enabled = False
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            train_step()
+        barrier()
+        t_nocomm = max_over_ranks(time.perf_counter() - t0) / K
+        ddp.enabled = True
+        train_step()  # buckets hold gradients again
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            ddp.allreduce_only()
+        barrier()
+        t_comm = max_over_ranks(time.perf_counter() - t0) / K
+        t_step = elapsed / K
+        exposed = max(t_step - t_nocomm, 0.0)
+        extra["overlap"] = {"ms_step": 1e3 * t_step, "ms_step_without_allreduce": 1e3 * t_nocomm,
+                            "ms_allreduce_alone": 1e3 * t_comm, "ms_exposed": 1e3 * exposed,
+                            "hidden_fraction": (1.0 - exposed / t_comm) if t_comm > 0 else None,
+                            "buckets": ddp.bucket_layout(), "compress": args.compress,
+                            "payload_MB": sum(b for _, b in (ddp.bucket_layout() or [])) / 1e6}
+
+    # ---- the modes that meet the 1e-4 parity gate, same run, same model (N = 1 only: they are not scaling legs)
+    if world == 1 and not args.no_extra and not args.no_parity_modes:
+        pm = {}
+        for m in ("f32s", "f32"):
+            if m == args.dtype:
+                continue
+            k2 = max(2, min(K, 3))
+            el, kn, _, _ = run_mode(m, k2, 1)
+            d = {"ms_per_step": 1e3 * el / k2, "voxels_per_s": B * V * k2 / el, "steps": k2,
+                 "roofline": roofline_block(kn, m, B, k2), "kernels": kernel_table(kn, k2)}
+            if accuracy is not None:
+                d["rel_l2_vs_cpu_oracle"] = accuracy[m]
+            pm[m] = d
+        extra["parity_modes"] = pm
+        set_mode(diff, args.dtype)
+
+    if not args.no_extra:
+        set_mode(diff, args.dtype)
+        if world == 1:
+            # forward only (the north_star's "conv U-Net forward" figure)
+            with torch.no_grad():
+                tq = torch.full((B,), 250, device=dev)
+                for _ in range(2):
+                    diff.model(x, tq, C)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    diff.model(x, tq, C)
+                torch.cuda.synchronize()
+                extra["fwd_ms_per_sample"] = 1e3 * (time.perf_counter() - t0) / 3 / B
         if args.sample_steps > 0:
+            # BASELINE configs[3]: T = 1000, trajectories sharded 8 per GPU, hipGraph-captured reverse step
             from turbdiff_amd.sampling import GraphSampler
 
+            T = 1000
+            sdiff = build_model(dev, timesteps=T)
+            set_mode(sdiff, args.dtype)
             Bs = args.sample_batch
+            ids = list(parallel.shard_trajectories(Bs * world, rank, world))
             xs, _, _ = synthetic_inputs(Bs, dev)
-            sampler = GraphSampler(diff, xs, C, cell_idx, seed=0)
+            sampler = GraphSampler(sdiff, xs, C, cell_idx, seed=0, trajectory_ids=ids)
             sampler.run_steps(2)  # warm-up (includes graph capture)
-            torch.cuda.synchronize()
+            full = K >= 20
+            n = (T - 2) if full else min(args.sample_steps, T - 2)
+            barrier()
             t0 = time.perf_counter()
-            sampler.run_steps(args.sample_steps)
-            torch.cuda.synchronize()
-            per_step = (time.perf_counter() - t0) / args.sample_steps
-            extra["sample_ms_per_step"] = 1e3 * per_step
-            extra["sample_batch"] = Bs
-            extra["ddpm_samples_per_s_T500_extrapolated"] = Bs / (per_step * 500)
-            extra["ddpm_samples_per_s_T1000_extrapolated"] = Bs / (per_step * 1000)
+            sampler.run_steps(n)
+            barrier()
+            per_step = max_over_ranks(time.perf_counter() - t0) / n
+            extra["sampling"] = {"ms_per_reverse_step": 1e3 * per_step, "reverse_steps_timed": n, "full_loop": full,
+                                 "trajectories_per_gpu": Bs, "trajectories": Bs * world, "T": T,
+                                 "ddpm_samples_per_s_T1000": Bs * world / (per_step * T),
+                                 "ddpm_samples_per_s_T500": Bs * world / (per_step * 500),
+                                 "note": "whole-job aggregate; per-step time x T" + ("" if full else " (extrapolated from the timed steps)")}
+            del sampler, sdiff
+    if extra:
         out["extra"] = extra
 
     if args.torch_baseline and world == 1:
-        del diff, ddp, opt
+        del diff
         torch.cuda.empty_cache()
         ref = {}
         for amp in (True, False):
@@ -337,8 +455,8 @@ def main():
                 ref["bf16_autocast" if amp else "fp32"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out.setdefault("extra", {})["torch_rocm_reference"] = ref
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -144,7 +144,8 @@ class ResnetBlock(nn.Module):
                 assert identity and x2 is None
                 return ops.resnet_block(x, None, scale, shift, (conv1[1], conv1[2]), (b1.norm.weight, b1.norm.bias),
                                         (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias), None,
-                                        _norm_groups(b1.norm), b1.norm.eps, conv1_input=conv1[0])
+                                        _norm_groups(b1.norm), b1.norm.eps, conv1_input=conv1[0],
+                                        conv1_real_channels=conv1[3] if len(conv1) > 3 else None)
             return ops.resnet_block(x, x2, scale, shift, (b1.conv.weight, b1.conv.bias), (b1.norm.weight, b1.norm.bias),
                                     (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias),
                                     None if identity else (self.conv.weight, self.conv.bias), _norm_groups(b1.norm),
@@ -369,7 +370,8 @@ class DenoisingModel(nn.Module):
     # (learned cell-type embedding): the data gradient w.r.t. the raw input then also runs on the MFMA path
 
     def compose_first_conv(self, x, c_local):
-        """(raw NDHWC input (B, X, Y, Z, 32), composed weight (Cout, 32, 3, 3, 3), composed bias) or None."""
+        """(raw NDHWC input (B, X, Y, Z, 2P), composed weight (Cout, 2P, 3, 3, 3), composed bias, number of raw
+        channels that carry data) or None."""
         first = self.u_net.downsampling_blocks[0]
         D = self.encode_x.out_channels
         if not (COMPOSE_FIRST_CONV and isinstance(first, ResnetBlock) and first.fused() and c_local is not None
@@ -400,7 +402,7 @@ class DenoisingModel(nn.Module):
         w8 = torch.einsum("octuv,ck->oktuv", W1, w_enc)
         w_eff = torch.cat((w8, eye[3]), dim=1).index_select(1, eye[4])
         b_eff = b1 + torch.einsum("octuv,c->o", W1, b_enc)
-        return raw, w_eff, b_eff
+        return raw, w_eff, b_eff, self.in_features + self.c_local_features
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
         B = x.shape[0]

@@ -640,7 +640,8 @@ class _ResnetBlock(torch.autograd.Function):
     cuts the number of autograd nodes per block from 6-7 to 1."""
 
     @staticmethod
-    def forward(ctx, x1, x2, scale, shift, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps, partial=None, xc=None):
+    def forward(ctx, x1, x2, scale, shift, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps, partial=None, xc=None,
+                xc_real=None):
         """xc: optional separate input of block1's conv (w1 then has xc's channel count); the residual
         path still uses x1.  Used for the U-Net's first block, whose conv is composed with the 1x1
         encoders and therefore runs on the raw input channels (models/ddpm.py, compose_first_conv)."""
@@ -664,11 +665,14 @@ class _ResnetBlock(torch.autograd.Function):
         scale, shift = f32c(scale.reshape(B, Cout)), f32c(shift.reshape(B, Cout))
         gws = _clean_ws(L.query("tdx_gn_workspace_bytes", B, Cout), dev)
 
-        def conv_gn(xa, Ca, xb, Cb, wf, bias):
+        def conv_gn(xa, Ca, xb, Cb, wf, bias, real=None):
+            # `real`: channels that carry data (the composed first conv runs on zero-padded raw channels; the
+            # timers' work figure counts the algorithmic channels only)
             y = torch.empty((B, X, Y, Z, Cout), dtype=dt, device=dev)
             stats = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
             L.call("tdx_conv3_fwd_gn", L.ptr(xa), Ca, L.ptr(xb), Cb, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats), groups,
-                   float(eps), L.ptr(gws), B, X, Y, Z, Cout, code, impl | WS_CLEAN, st, work=54.0 * (Ca + Cb) * Cout * B * V)
+                   float(eps), L.ptr(gws), B, X, Y, Z, Cout, code, impl | WS_CLEAN, st,
+                   work=54.0 * (real or (Ca + Cb)) * Cout * B * V)
             return y, stats
 
         if partial is not None:
@@ -682,7 +686,7 @@ class _ResnetBlock(torch.autograd.Function):
                    L.ptr(b1), L.ptr(init), 1, L.ptr(h1), L.ptr(st1), groups, float(eps), L.ptr(gws), B, X, Y, Z, Cout, code,
                    impl | WS_CLEAN, st, work=54.0 * n_lead * Cout * B * V)
         elif xc is not None:
-            h1, st1 = conv_gn(xc, Cc, None, 0, wf1, b1)
+            h1, st1 = conv_gn(xc, Cc, None, 0, wf1, b1, real=xc_real)
         else:
             h1, st1 = conv_gn(x1, C1, x2, C2, wf1, b1)
         a1 = torch.empty_like(h1)
@@ -704,6 +708,7 @@ class _ResnetBlock(torch.autograd.Function):
         ctx.save_for_backward(x1, x2, h1, st1, a1, h2, st2, scale, shift, g1, be1, g2, be2, wb1, wb2, wr2, xc)
         ctx.cfg = (groups, tuple(w1.shape), tuple(w2.shape), None if wr is None else tuple(wr.shape),
                    b1 is not None, b2 is not None, br is not None)
+        ctx.xc_real = xc_real
         return y
 
     @staticmethod
@@ -749,13 +754,13 @@ class _ResnetBlock(torch.autograd.Function):
             # feeds the identity skip, so its gradient is gy; the data gradient of the conv is needed only
             # if xc itself requires one (e.g. a learned cell-type embedding behind the raw conditioning)
             L.call("tdx_conv3_bwd_weight", L.ptr(xc), Cc, None, 0, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
-                   impl | WS_CLEAN, L.ptr(wws1), st, work=flops(Cc))
+                   impl | WS_CLEAN, L.ptr(wws1), st, work=flops(ctx.xc_real or Cc))
             dxc = None
             if ctx.needs_input_grad[17]:
                 dxc = torch.empty_like(xc)
                 L.call("tdx_conv3_bwd_data", L.ptr(dh1), L.ptr(wb1), L.ptr(dxc), Cc, None, 0, 0, B, X, Y, Z, Cout, code, impl,
-                       L.ptr(dws), st, work=flops(Cc))
-            return (gy, None, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, dxc)
+                       L.ptr(dws), st, work=flops(ctx.xc_real or Cc))
+            return (gy, None, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, dxc, None)
         L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
                impl | WS_CLEAN, L.ptr(wws1), st, work=flops(Cin))
         # ---- input gradient = conv1 data gradient + residual-path gradient
@@ -782,15 +787,18 @@ class _ResnetBlock(torch.autograd.Function):
                 L.call("tdx_conv1_bwd_weight", L.ptr(x2), C2, L.ptr(gy), Cout, dwt.data_ptr() + 4 * C1 * Cout, Cout, None,
                        B * V, code, st)
             dwr = dwt.t().reshape(wrs)
-        return (gx1, gx2, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None)
+        return (gx1, gx2, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None, None)
 
 
 def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, skip_wb, groups, eps=1e-5, partial=None,
-                 conv1_input=None):
+                 conv1_input=None, conv1_real_channels=None):
     """Fused ResnetBlock; *_wb are (weight, bias) pairs, skip_wb is None for an identity skip.
     Requires SiLU activations and bf16/f32 NDHWC inputs; scale/shift are (B, Cout).
     partial = (n_lead, init): no-grad only, see conv3_shared_tail.
-    conv1_input: separate input tensor of block1's conv (conv1_wb then matches ITS channel count)."""
+    conv1_input: separate input tensor of block1's conv (conv1_wb then matches ITS channel count);
+    conv1_real_channels: how many of its channels carry data (the rest is zero padding) -- bookkeeping for the
+    kernel timers only."""
     wr, br = skip_wb if skip_wb is not None else (None, None)
     return _ResnetBlock.apply(x1, x2, scale, shift, conv1_wb[0], conv1_wb[1], norm1_wb[0], norm1_wb[1], conv2_wb[0],
-                              conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps, partial, conv1_input)
+                              conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps, partial, conv1_input,
+                              conv1_real_channels)

@@ -22,7 +22,7 @@ def test_bench_two_ranks_one_gpu():
     env = dict(os.environ, TDX_BENCH_BACKEND="gloo", TDX_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
-           "--no-extra", "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--sample-steps", "3", "--sample-batch", "1"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
@@ -30,3 +30,10 @@ def test_bench_two_ranks_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 2
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["config"]["parallelism"] == "dp2"
     assert abs(d["value"] - 2 * 1 * 192 * 64 * 48 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6  # whole-job aggregate
+    # overlap report of the gradient all-reduce (step vs step without the collective vs the collective alone)
+    ov = d["extra"]["overlap"]
+    assert ov["ms_step"] > 0 and ov["ms_step_without_allreduce"] > 0 and ov["ms_allreduce_alone"] > 0
+    assert abs(ov["payload_MB"] - 55246788 * 4 / 1e6) < 1.0 and len(ov["buckets"]) >= 4
+    # BASELINE configs[3]: trajectories sharded over the ranks, aggregate samples/s
+    sm = d["extra"]["sampling"]
+    assert sm["trajectories"] == 2 and sm["trajectories_per_gpu"] == 1 and sm["ddpm_samples_per_s_T1000"] > 0

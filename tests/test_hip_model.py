@@ -173,6 +173,81 @@ def test_full_size_forward_matches_oracle_fp32(monkeypatch):
     assert rel_l2(yb.cpu(), ref) < 3e-2
 
 
+def _full_size_problem(seed=0):
+    from turbdiff_amd.models.ddpm import DenoisingModel
+
+    torch.manual_seed(seed)
+    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=500, dim=32,
+                         u_net_levels=4, norm_type="group")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    return net, sd
+
+
+@pytest.mark.timeout(900)
+def test_full_size_gradients_match_oracle(monkeypatch):
+    """BASELINE config 2 at full size (192x64x48, dim 32, 4 levels, B = 1): loss and parameter gradients of
+    p_losses against the CPU oracle's backward, in the fp32 mode and with split-precision convs.  This is where the
+    level-0 split-K weight gradient, the original-grid data gradient + halo-shell kernel and the brick tiling of the
+    finest level run at the sizes the benchmark uses.  Tolerance 1e-3 rel-L2 per tensor (north_star: fp32)."""
+    from turbdiff_amd.models.ddpm import GaussianDiffusion
+
+    net, sd = _full_size_problem()
+    X, Y, Z = 192, 64, 48
+    x = torch.randn(1, 4, X, Y, Z, generator=torch.Generator().manual_seed(1234))
+    c_local = torch.randn(4, X, Y, Z, generator=torch.Generator().manual_seed(1235))
+    noise = torch.randn(1, 4, X, Y, Z, generator=torch.Generator().manual_seed(1))
+    t = torch.tensor([250])
+    m = torch.zeros(X, Y, Z, dtype=torch.bool)
+    m[1:-1, 1:-1, 1:-1] = True
+    m[13:25, 24:40, 0:32] = False
+    cell_idx = m.flatten().nonzero().flatten()
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    buf = O.schedule_buffers("log-snr-linear", 500)
+    ref_loss, _ = O.p_losses(leaves, buf, x, t, c_local, cell_idx, noise, timesteps=500, noise_bcs=True)
+    ref_loss.backward()
+    diff = GaussianDiffusion(net, timesteps=500, beta_schedule="log-snr-linear", noise_bcs=True).to(dev())
+    md = SimpleNamespace(cell_idx=cell_idx.to(dev()))
+    # every level's convs, the bottleneck attention, both encoders (through the composed first conv), FiLM and norms
+    watched = ["u_net.downsampling_blocks.0.block1.conv.weight", "u_net.downsampling_blocks.0.block2.conv.weight",
+               "u_net.downsampling_blocks.1.block1.conv.weight", "u_net.downsampling_blocks.3.block2.conv.weight",
+               "u_net.center_block.0.block1.conv.weight", "u_net.center_block.1.fn.fn.to_qkv.weight",
+               "u_net.upsampling_blocks.0.block1.conv.weight", "u_net.upsampling_blocks.3.block1.conv.weight",
+               "u_net.upsampling_blocks.3.conv.weight", "decode.0.block2.conv.weight", "decode.1.weight", "encode_x.weight",
+               "encode_c_local.weight", "encode_x.bias", "u_net.downsampling_blocks.0.project_onto_scale_shift.weight",
+               "u_net.downsampling_blocks.0.block1.norm.weight", "u_net.upsampling_blocks.3.block2.norm.bias",
+               "process_c.0.weight"]
+    for mode in ("auto", "split"):
+        monkeypatch.setenv("TDX_CONV_IMPL", mode)
+        diff.zero_grad(set_to_none=True)
+        loss, _ = diff.p_losses(x.to(dev()), t.to(dev()), cond(c_local), md, None, noise=noise.to(dev()))
+        loss.backward()
+        assert abs(loss.item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item()), (mode, loss.item(), ref_loss.item())
+        params = dict(diff.model.named_parameters())
+        for name in watched:
+            assert_grad_close(f"{mode}:{name}", params[name].grad.cpu(), leaves[name].grad, 1e-3)
+    monkeypatch.delenv("TDX_CONV_IMPL")
+
+
+def test_reference_grid_194x50x50_four_levels_forward(monkeypatch):
+    """The reference's real grid (194 x 50 x 50: every axis leaves a remainder against the 4 x 8 x 8 brick, every
+    level down to 24 x 6 x 6 is ragged) through the full 4-level dim-32 net: forward vs the CPU oracle in the fp32
+    and split-precision modes (1e-4) and in bf16 (3e-2)."""
+    net, sd = _full_size_problem(seed=3)
+    x = torch.randn(1, 4, 194, 50, 50, generator=torch.Generator().manual_seed(5))
+    c_local = torch.randn(4, 194, 50, 50, generator=torch.Generator().manual_seed(6))
+    t = torch.tensor([77])
+    with torch.no_grad():
+        ref = O.denoiser(sd, x, t, c_local, timesteps=500)
+        net.to(dev())
+        y = net(x.to(dev()), t.to(dev()), cond(c_local))
+        monkeypatch.setenv("TDX_CONV_IMPL", "split")
+        ys = net(x.to(dev()), t.to(dev()), cond(c_local))
+        monkeypatch.delenv("TDX_CONV_IMPL")
+        net.set_compute_dtype(torch.bfloat16)
+        yb = net(x.to(dev()), t.to(dev()), cond(c_local))
+    assert rel_l2(y.cpu(), ref) < 1e-4 and rel_l2(ys.cpu(), ref) < 1e-4 and rel_l2(yb.cpu(), ref) < 3e-2
+
+
 def test_split_precision_training_step_vs_oracle(monkeypatch):
     """dim 32, 3 levels, 48x32x24, B = 2: loss and every parameter gradient of p_losses with
     TDX_CONV_IMPL=split (fp32 tensors, bf16 hi + lo MFMA convs) against the CPU oracle."""

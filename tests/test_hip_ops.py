@@ -497,6 +497,26 @@ def test_attention_full_config5_size(monkeypatch):
     assert rel_l2(dqp, dq) < 1.5e-2 and rel_l2(dkp, dk[:, perm]) < 1.5e-2 and rel_l2(dvp, dv[:, perm]) < 1.5e-2
 
 
+def test_attention_config5_rows_vs_oracle():
+    """BASELINE config 5 (N = 96*32*24 = 73 728 tokens, 4 heads x 32) against the oracle on a SUBSET of query rows:
+    softmax(q_i K^T / sqrt(d)) V for 256 random queries x all keys, evaluated by the CPU oracle's SDPA
+    restatement (reference attention.py:9-15) in fp32 on the same bf16-rounded inputs."""
+    from oracle import turbdiff_oracle as O
+    from turbdiff_amd import ops
+
+    B, H, D, N = 1, 4, 32, 96 * 32 * 24
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(11)
+    qkv = torch.randn(B, N, 3 * H * D, device=d, generator=g).bfloat16()
+    out = ops.attention(qkv, H).float().cpu()          # (B, N, H*D), head-major channels
+    rows = torch.randperm(N, generator=torch.Generator().manual_seed(12))[:256]
+    q, k, v = qkv.float().cpu().reshape(B, N, 3, H, D).permute(2, 0, 3, 1, 4)  # each (B, H, N, D)
+    ref = O.sdpa(q[:, :, rows], k, v)                  # (B, H, 256, D)
+    got = out.reshape(B, N, H, D)[:, rows].permute(0, 2, 1, 3)
+    assert rel_l2(got, ref) < 6e-3                     # bf16 P and V operands, fp32 accumulation
+    assert (got - ref).abs().max().item() < 2e-2
+
+
 @pytest.mark.parametrize("grid", [(18, 10, 10), (10, 18, 9), (9, 10, 18), (14, 18, 18), (6, 9, 10)])
 def test_conv3_thin_slab_bricks(grid, monkeypatch):
     """grids with a 1-2 voxel remainder per axis (the reference's real 194x50x50 family and every

@@ -23,7 +23,7 @@ def _make_model():
                                torch.nn.Linear(32, 3))
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, variant="dynamic"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import sys
     from pathlib import Path
@@ -37,7 +37,14 @@ def _worker(rank, world, port, outdir):
         with torch.no_grad():
             for p in model.parameters():
                 p.add_(1.0)
-    ddp = BucketedDataParallel(model, bucket_mb=0.003)  # ~3 KB buckets -> several buckets
+    if variant != "dynamic":
+        # a module that knows its backward order (as models.ddpm.DenoisingModel does): buckets exist -- and
+        # all-reduces overlap -- from the first step on
+        model.grad_ready_order = lambda: reversed(list(model.parameters()))
+    ddp = BucketedDataParallel(model, bucket_mb=0.003,  # ~3 KB buckets -> several buckets
+                               compress="bf16" if variant == "bf16" else None)
+    if variant != "dynamic":
+        assert ddp.bucket_layout() is not None, "static order must give buckets before the first backward"
     g = torch.Generator().manual_seed(100)
     data = torch.randn(3, 8, 6, generator=g)  # 3 steps, global batch 8
     out = []
@@ -47,16 +54,29 @@ def _worker(rank, world, port, outdir):
         model(x).pow(2).mean().backward()
         ddp.finish()
         out.append([p.grad.clone() for p in model.parameters()])
+        flats = {f.data_ptr(): f for f in ddp._flat}
+        assert all(any(f.data_ptr() <= p.grad.data_ptr() < f.data_ptr() + f.numel() * 4 for f in flats.values())
+                   for p in model.parameters()), "gradients must be views into the persistent buckets"
+    if variant == "static":  # a second backward before finish() is a contract violation, reported loudly
+        model.zero_grad(set_to_none=True)
+        model(data[0, :4]).pow(2).mean().backward()
+        try:
+            model(data[0, :4]).pow(2).mean().backward()
+            raise AssertionError("second backward before finish() must raise")
+        except RuntimeError as e:
+            assert "one backward per finish" in str(e)
+        ddp._seen.clear(); ddp._launched.clear(); ddp._work.clear(); ddp._pending = [len(b) for b in ddp._buckets]
     torch.save((out, ddp.bucket_layout(), [p.detach().clone() for p in model.parameters()]), f"{outdir}/rank{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(120)
-def test_bucketed_ddp_matches_single_process(tmp_path):
+@pytest.mark.parametrize("variant", ["dynamic", "static", "bf16"])
+def test_bucketed_ddp_matches_single_process(tmp_path, variant):
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, str(tmp_path), variant)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -76,7 +96,10 @@ def test_bucketed_ddp_matches_single_process(tmp_path):
         model(data[step]).pow(2).mean().backward()
         for rank in (0, 1):
             for gr, p in zip(results[rank][0][step], model.parameters()):
-                assert torch.allclose(gr, p.grad, rtol=1e-5, atol=1e-7)
+                if variant == "bf16":  # gradients travelled as bfloat16
+                    assert torch.allclose(gr, p.grad, rtol=2e-2, atol=1e-3)
+                else:
+                    assert torch.allclose(gr, p.grad, rtol=1e-5, atol=1e-7)
     layout = results[0][1]
     assert layout is not None and len(layout) >= 2, layout
     assert sum(n for n, _ in layout) == len(list(model.parameters()))

@@ -101,3 +101,52 @@ def test_two_ranks_one_gpu_gradient_average(tmp_path):
         assert abs(res[r][3] - ref_norm.item()) < 2e-3 * ref_norm.item()
         for name, p in diff.model.named_parameters():
             assert torch.allclose(res[r][2][name], p.detach().cpu(), rtol=1e-4, atol=2e-6), (name, r)
+
+
+def _rccl_worker(port, outdir):
+    """World size 1 over backend "nccl" (= RCCL): communicator creation, the hook-driven bucketed all-reduce of
+    device buffers on RCCL's stream, finish() -- everything the 2/4/8-GPU runs execute except a second peer."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    diff, x, C, md, t, noise = _build(dev)
+    from turbdiff_amd.parallel import BucketedDataParallel, init_from_env
+
+    rank, world, local = init_from_env("nccl", force=True)
+    assert (rank, world) == (0, 1) and torch.distributed.get_backend() == "nccl"
+    ddp = BucketedDataParallel(diff, bucket_mb=0.25, force=True)
+    assert ddp.active and ddp.bucket_layout() is not None  # static order from DenoisingModel.grad_ready_order()
+    res = {}
+    for tag, compress in (("f32", None), ("bf16", "bf16")):
+        ddp.compress = compress
+        if compress:
+            ddp._wire = [torch.zeros_like(f, dtype=torch.bfloat16) for f in ddp._flat]
+        diff.zero_grad(set_to_none=True)
+        loss, _ = diff.p_losses(x, t, C, md, None, noise=noise)
+        loss.backward()
+        ddp.finish()
+        res[tag] = {n: p.grad.detach().cpu().clone() for n, p in diff.model.named_parameters()}
+    ddp.allreduce_only()
+    torch.save((res, ddp.bucket_layout(), ddp.stats), f"{outdir}/rccl.pt")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_world_size_one_runs_the_communicator_path(tmp_path):
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), str(tmp_path)))
+    p.start()
+    p.join(timeout=280)
+    assert p.exitcode == 0
+    res, layout, stats = torch.load(tmp_path / "rccl.pt")
+    assert len(layout) >= 2 and stats["steps"] == 2
+    diff, x, C, md, t, noise = _build(torch.device("cuda:0"))
+    loss, _ = diff.p_losses(x, t, C, md, None, noise=noise)
+    loss.backward()
+    for name, p in diff.model.named_parameters():
+        ref = p.grad.cpu()
+        if ref.norm() < 1e-6:
+            continue
+        assert ((res["f32"][name] - ref).norm() / ref.norm()).item() < 2e-3, name     # atomics: not bit-identical
+        assert ((res["bf16"][name] - ref).norm() / ref.norm()).item() < 1e-2, name    # travelled as bfloat16
