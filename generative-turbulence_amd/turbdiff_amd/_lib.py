@@ -105,8 +105,21 @@ def dtype_code(dt: torch.dtype) -> int:
     raise TypeError(f"tdx kernels support float32 and bfloat16 activations, got {dt}")
 
 
+_CONV_IMPLS = {"auto": CONV_AUTO, "direct": CONV_DIRECT, "mfma": CONV_MFMA, "split": CONV_SPLIT}
+_conv_impl_override: str | None = None
+
+
+def set_conv_impl(name: str | None) -> None:
+    """Process-wide choice of the 3x3x3 conv implementation ("auto", "direct", "mfma", "split"; None: back to the
+    TDX_CONV_IMPL environment variable, default "auto").  "split" = split-precision MFMA convs on fp32 tensors."""
+    global _conv_impl_override
+    if name is not None and name not in _CONV_IMPLS:
+        raise ValueError(f"unknown conv implementation {name!r}")
+    _conv_impl_override = name
+
+
 def conv_impl() -> int:
-    return {"auto": CONV_AUTO, "direct": CONV_DIRECT, "mfma": CONV_MFMA, "split": CONV_SPLIT}[os.environ.get("TDX_CONV_IMPL", "auto")]
+    return _CONV_IMPLS[_conv_impl_override or os.environ.get("TDX_CONV_IMPL", "auto")]
 
 
 def pack_code(dt: torch.dtype) -> int:

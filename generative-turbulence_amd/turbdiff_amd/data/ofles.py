@@ -137,45 +137,48 @@ class OpenFOAMStats:
     stats: dict
     _normalizers: dict = field(default_factory=dict)
 
+    # normalisation rule of a mode: which statistics record it reads ("norm(<v>)" = statistics of the vector norm, or
+    # the per-component record "<v>"), which entry becomes the shift (None: 0) and which the scale
+    _RULES = {
+        "norm": ("norm({})", None, lambda st: st["mean"]),
+        "norm-std": ("norm({})", "mean", lambda st: st["std"]),
+        "norm-max": ("norm({})", None, lambda st: st["max"]),
+        "abs-max": ("{}", None, lambda st: torch.maximum(st["min"].abs(), st["max"].abs())),
+        "mean-std": ("{}", "mean", lambda st: st["std"]),
+        "std": ("{}", None, lambda st: st["std"]),
+    }
+
+    @staticmethod
+    def _modes_by_variable(variables, mode: str) -> dict:
+        """"u:norm-max;p:abs-max" -> one mode per variable; a plain mode name applies to every variable."""
+        if ":" not in mode:
+            return {v: mode for v in variables}
+        given = dict(item.split(":") for item in mode.split(";"))
+        by_var = {Variable.from_str(name): m for name, m in given.items()}
+        return {v: by_var[v] for v in variables}  # KeyError: a variable without a mode, as in the reference
+
     def normalizers(self, variables, mode: str):
+        """(shift, scale), each (sum of dims,): x_normalised = (x - shift) / scale  (reference ofles.py:248-293)."""
         key = (tuple(variables), mode)
-        if key in self._normalizers:  # the reference caches with cachedmethod
-            return self._normalizers[key]
-        if ":" in mode:
-            mode_of = {Variable.from_str((pair := cfg.split(":"))[0]).name: pair[1] for cfg in mode.split(";")}
-        else:
-            orig = mode
-            mode_of = defaultdict(lambda: orig)
-        any_tensor = self.stats[variables[0].name.lower()]["mean"]
-        dims = [v.dims for v in variables]
-        mean, std = any_tensor.new_zeros(sum(dims)), any_tensor.new_ones(sum(dims))
-        for v, mean_v, std_v in zip(variables, torch.split(mean, dims), torch.split(std, dims)):
-            v_mode = mode_of[v.name]
-            if "norm" in v_mode:
-                st = self.stats[f"norm({v.name.lower()})"]
-                if v_mode == "norm":
-                    std_v[:] = st["mean"]
-                elif v_mode == "norm-std":
-                    mean_v[:] = st["mean"]
-                    std_v[:] = st["std"]
-                elif v_mode == "norm-max":
-                    std_v[:] = st["max"]
-                else:
-                    raise RuntimeError(f"Unknown normalization mode {v_mode}")
-            else:
-                st = self.stats[v.name.lower()]
-                if v_mode == "abs-max":
-                    std_v[:] = torch.maximum(st["min"].abs(), st["max"].abs())
-                elif v_mode == "mean-std":
-                    mean_v[:] = st["mean"]
-                    std_v[:] = st["std"]
-                elif v_mode == "std":
-                    std_v[:] = st["std"]
-                else:
-                    raise RuntimeError(f"Unknown normalization mode {v_mode}")
-        std = torch.where(std >= 1e-8, std, 1.0)  # avoid division by 0 (ofles.py:291)
-        self._normalizers[key] = (mean, std)
-        return mean, std
+        hit = self._normalizers.get(key)  # the reference memoises with cachedmethod
+        if hit is not None:
+            return hit
+        shifts, scales = [], []
+        for v, v_mode in self._modes_by_variable(variables, mode).items():
+            rule = self._RULES.get(v_mode)
+            if rule is None:
+                raise RuntimeError(f"Unknown normalization mode {v_mode}")
+            record, shift_key, scale_of = rule
+            st = self.stats[record.format(v.name.lower())]
+            scale = scale_of(st)
+            shift = st[shift_key] if shift_key is not None else torch.zeros_like(scale)
+            # scalar statistics (those of a vector norm) apply to every component of the variable
+            shifts.append(shift.reshape(-1).expand(v.dims) if shift.numel() == 1 else shift.reshape(v.dims))
+            scales.append(scale.reshape(-1).expand(v.dims) if scale.numel() == 1 else scale.reshape(v.dims))
+        shift, scale = torch.cat(shifts), torch.cat(scales)
+        scale = torch.where(scale >= 1e-8, scale, torch.ones_like(scale))  # no division by ~0 (ofles.py:291)
+        self._normalizers[key] = (shift, scale)
+        return shift, scale
 
     @staticmethod
     def from_file(file: Path):
@@ -238,29 +241,37 @@ class OpenFOAMDataset(torch.utils.data.Dataset):
     def reset_caches(self):
         self.repo.reset_caches()
         self.valid_steps = [np.nonzero(np.asarray(t) > self.discard_first_seconds)[0] for t in self.repo.times]
+        # case c owns the flat sample indices [first[c], first[c + 1])
+        self._first = np.concatenate(([0], np.cumsum([len(v) for v in self.valid_steps]))).astype(np.int64)
+        self._step_of_time = {}
 
     def sample_idxs_by_file(self):
-        out, i = [], 0
-        for steps in self.valid_steps:
-            out.append(list(range(i, i + len(steps))))
-            i += len(steps)
-        return out
+        return [list(range(int(a), int(b))) for a, b in zip(self._first[:-1], self._first[1:])]
 
     def __len__(self):
-        return sum(len(v) for v in self.valid_steps)
+        return int(self._first[-1])
 
     def __getitem__(self, index):
-        index = np.array([index] if isinstance(index, int) else index)
-        file_idx = 0
-        while index.min() >= len(self.valid_steps[file_idx]):
-            index = index - len(self.valid_steps[file_idx])
-            file_idx += 1
-        assert index.max() < len(self.valid_steps[file_idx]), "All samples have to be from the same geometry"
-        return OpenFOAMBatch(self.repo.read(file_idx, [self.valid_steps[file_idx][i] for i in index]), self.stats)
+        """A batch = flat indices that all fall into ONE case (same geometry), reference ofles.py:441-468."""
+        flat = np.atleast_1d(np.asarray(index, dtype=np.int64))
+        case = int(np.searchsorted(self._first, flat.min(), side="right")) - 1
+        assert flat.max() < self._first[case + 1], "All samples have to be from the same geometry"
+        steps = self.valid_steps[case][flat - self._first[case]]
+        return OpenFOAMBatch(self.repo.read(case, list(steps)), self.stats)
 
     def get_times(self, file_idx: int, times):
-        t = np.round(np.asarray(self.repo.times[file_idx]) * 10_000).astype(int).tolist()  # tenths of milliseconds
-        return OpenFOAMBatch(self.repo.read(file_idx, [t.index(round(x * 10_000)) for x in times]), self.stats)
+        """The samples of a case at the given physical times, matched at 0.1 ms resolution (ofles.py:470-479)."""
+        lookup = self._step_of_time.get(file_idx)
+        if lookup is None:
+            lookup = {}
+            for step, t in enumerate(np.asarray(self.repo.times[file_idx])):
+                lookup.setdefault(int(round(float(t) * 10_000)), step)  # first occurrence wins, like list.index
+            self._step_of_time[file_idx] = lookup
+        try:
+            steps = [lookup[int(round(float(t) * 10_000))] for t in times]
+        except KeyError as e:
+            raise ValueError(f"no sample at time key {e.args[0]} in case {file_idx}") from None
+        return OpenFOAMBatch(self.repo.read(file_idx, steps), self.stats)
 
 
 class OpenFOAMSampler(torch.utils.data.Sampler):

@@ -66,26 +66,77 @@ def _metric_placeholders():
     return coll
 
 
+# torch.set_float32_matmul_precision(config.matmul_precision) of the reference's entry points (train.py,
+# scripts/eval_ckpt.py:57) -> compute mode here: "highest" keeps IEEE fp32 products (fp32 MFMA convs); "high" and
+# "medium" allow reduced-precision products on fp32 tensors (TF32 / bf16 in stock PyTorch) -> split-precision convs
+# (bf16 hi + lo: 16 significand bits, more than TF32's 10).  bf16 STORAGE is never implied by a reference config;
+# ask for it explicitly (compute_mode="bf16").
+MATMUL_PRECISION_TO_MODE = {"highest": "f32", "high": "f32s", "medium": "f32s"}
+COMPUTE_MODES = ("f32", "f32s", "bf16")
+
+
+def apply_compute_mode(net: DenoisingModel, mode: str) -> None:
+    """f32: fp32 tensors, IEEE fp32 MFMA convs; f32s: fp32 tensors, split-precision convs; bf16: bf16 tensors."""
+    from . import _lib
+
+    if mode not in COMPUTE_MODES:
+        raise ValueError(f"compute mode {mode!r} not in {COMPUTE_MODES}")
+    net.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
+    _lib.set_conv_impl("split" if mode == "f32s" else None)
+
+
+def _get(cfg, key, default=None):
+    """cfg[key] for dict-like (dict, OmegaConf DictConfig) and attribute-style (SimpleNamespace) configs."""
+    if cfg is None:
+        return default
+    if hasattr(cfg, "get") and callable(cfg.get):
+        v = cfg.get(key, default)
+        return default if v is None and default is not None else v
+    return getattr(cfg, key, default)
+
+
 class DiffusionTrainer(nn.Module):
-    def __init__(self, dim: int = 32, cell_type_embedding_dim: int = 4, n_features: int = 4,
+    """Constructor surface = the reference task's (``DiffusionTraining.__init__``, diffusion.py:42-70: the 27
+    keywords ``config.py:74-101`` forwards), plus ``gradient_clip_val`` (the trainer's, train.yaml:30-31),
+    ``u_net_levels`` (hard-coded 4 in the reference, diffusion.py:120) and ``compute_mode``."""
+
+    def __init__(self, data_dir=None, samples_root=None, dim: int = 32, cell_type_embedding_type: str = "learned",
+                 cell_type_embedding_dim: int = 4, normalization_mode: str = "mean-std", variables=("u", "p"),
                  beta_schedule: str = "log-snr-linear", timesteps: int = 500, learning_rate: float = 1e-4,
                  min_learning_rate: float = 1e-6, lr_decay: str | None = "exp", max_train_steps: int = 1000,
-                 loss: str = "l2", clip_denoised: bool = False, noise_bcs: bool = True, learned_variances: bool = False,
-                 elbo_weight: float | None = None, detach_elbo_mean: bool = True, actfn: str = "silu",
-                 optimizer: str = "radam", norm_type: str = "group", with_geometry_embedding: bool = False,
-                 gradient_clip_val: float = 0.1, u_net_levels: int = 4, compute_dtype: torch.dtype = torch.float32,
-                 variables=("u", "p"), normalization_mode: str = "mean-std"):
+                 loss: str = "l2", cell_type_features: bool = True, cell_pos_features: bool = False,
+                 clip_denoised: bool = False, noise_bcs: bool = True, learned_variances: bool = False,
+                 elbo_weight: float | None = None, detach_elbo_mean: bool = True, time_embedding: str = "nyquist",
+                 actfn: str = "silu", optimizer: str = "radam", norm_type: str = "group",
+                 with_geometry_embedding: bool = False, *, gradient_clip_val: float = 0.1, u_net_levels: int = 4,
+                 compute_dtype: torch.dtype | None = None, compute_mode: str | None = None, n_features: int | None = None):
         super().__init__()
+        self.data_dir, self.samples_root = data_dir, samples_root
         self.variables = tuple(v if isinstance(v, Variable) else Variable.from_str(v) for v in variables)
+        vars_dim = sum(v.dims for v in self.variables)
+        assert n_features is None or n_features == vars_dim, "n_features follows from the variables"
+        self.normalization_mode = normalization_mode
         self.normalization = Normalization(self.variables, normalization_mode)
-        self.cell_type_embedding = CellTypeEmbedding.create("learned", cell_type_embedding_dim)
+        self.dim, self.timesteps, self.beta_schedule, self.loss = dim, timesteps, beta_schedule, loss
+        self.cell_type_embedding_type, self.cell_type_embedding_dim = cell_type_embedding_type, cell_type_embedding_dim
+        self.cell_type_features, self.cell_pos_features = cell_type_features, cell_pos_features
+        self.time_embedding = time_embedding  # accepted and unused, as in the reference (diffusion.py:64, never read)
+        self.cell_type_embedding = (CellTypeEmbedding.create(cell_type_embedding_type, cell_type_embedding_dim)
+                                    if cell_type_features else None)
         # holds the embedding a second time, as in the reference (diffusion.py:89-93) -> two state_dict aliases
-        self.conditioning = Conditioning(self.variables, self.cell_type_embedding, False)
-        net = DenoisingModel(in_features=n_features, out_features=n_features * (2 if learned_variances else 1),
-                             c_local_features=cell_type_embedding_dim, c_global_features=0, timesteps=timesteps, dim=dim,
+        self.conditioning = Conditioning(self.variables, self.cell_type_embedding, cell_pos_features)
+        net = DenoisingModel(in_features=vars_dim, out_features=vars_dim * (2 if learned_variances else 1),
+                             c_local_features=self.conditioning.local_conditioning_dim,
+                             c_global_features=self.conditioning.global_conditioning_dim, timesteps=timesteps, dim=dim,
                              u_net_levels=u_net_levels, actfn=ACTFNS[actfn], norm_type=norm_type,
                              with_geometry_embedding=with_geometry_embedding)
-        net.set_compute_dtype(compute_dtype)
+        if compute_mode is None:
+            compute_mode = "bf16" if compute_dtype == torch.bfloat16 else None
+        self.compute_mode = compute_mode
+        if compute_mode is not None:
+            apply_compute_mode(net, compute_mode)
+        elif compute_dtype is not None:
+            net.set_compute_dtype(compute_dtype)
         self.model = GaussianDiffusion(net, timesteps=timesteps, beta_schedule=beta_schedule, loss_type=loss,
                                        clip_denoised=clip_denoised, noise_bcs=noise_bcs,
                                        learned_variances=learned_variances, elbo_weight=elbo_weight,
@@ -94,10 +145,64 @@ class DiffusionTrainer(nn.Module):
         self.test_sample_metrics = _metric_placeholders()
         self.learning_rate, self.min_learning_rate = learning_rate, min_learning_rate
         self.lr_decay, self.max_train_steps, self.optimizer = lr_decay, max_train_steps, optimizer
+        self.clip_denoised, self.noise_bcs, self.learned_variances = clip_denoised, noise_bcs, learned_variances
+        self.elbo_weight, self.detach_elbo_mean, self.actfn = elbo_weight, detach_elbo_mean, actfn
         self.gradient_clip_val = gradient_clip_val
         self.fused_optimizer = True  # ClipRAdam on GPU; False -> clip_grad_norm_ + torch.optim.RAdam
         self._opt = self._sched = None
         self.ddp = None  # set to a parallel.BucketedDataParallel(self) for multi-GPU training
+        self.stats = None
+
+    # the keys config.py:74-101 reads off ``config.model`` and forwards under the same name
+    CONFIG_KEYS = ("dim", "cell_type_embedding_type", "cell_type_embedding_dim", "normalization_mode", "beta_schedule",
+                   "timesteps", "learning_rate", "min_learning_rate", "lr_decay", "loss", "cell_type_features",
+                   "clip_denoised", "noise_bcs", "learned_variances", "elbo_weight", "detach_elbo_mean", "time_embedding",
+                   "actfn", "optimizer", "norm_type", "with_geometry_embedding")
+
+    @classmethod
+    def from_config(cls, config, *, max_train_steps: int | None = None, steps_per_epoch: int | None = None,
+                    compute_mode: str | None = None, **overrides):
+        """Build the task from a run configuration, as ``instantiate_data_and_task`` does (config.py:64-101).
+
+        ``config`` is either the whole run config (``config.model``, ``config.data.root``, ``config.samples_root``,
+        ``config.trainer.gradient_clip_val``, ``config.matmul_precision`` -- what a checkpoint's ``ckpt["config"]``
+        holds) or just its ``model`` group (the keys of ``config/model/diffusion.yaml``); dicts, OmegaConf nodes and
+        namespaces all work.  ``max_train_steps`` = ``model.max_epochs * len(train_dataloader)`` in the reference:
+        pass it, or ``steps_per_epoch``.  ``compute_mode`` overrides the mapping of ``matmul_precision``."""
+        model = _get(config, "model")
+        root = config if model is not None else None
+        model = model if model is not None else config
+        name = _get(model, "name", "diffusion")
+        if not str(name).startswith("diffusion"):
+            raise ValueError(f"model.name = {name!r}: only the diffusion task is built here")
+        kw = {k: _get(model, k) for k in cls.CONFIG_KEYS if _get(model, k) is not None}
+        var = _get(model, "variables")
+        kw["variables"] = tuple(Variable) if var is None else tuple(
+            Variable.from_str(v) for v in (var.split(",") if isinstance(var, str) else var))
+        kw["cell_pos_features"] = bool(_get(model, "cell_pos_features", False))
+        if max_train_steps is None and steps_per_epoch is not None:
+            max_train_steps = int(_get(model, "max_epochs", 1)) * int(steps_per_epoch)
+        if max_train_steps is not None:
+            kw["max_train_steps"] = int(max_train_steps)
+        if root is not None:
+            data_root = _get(_get(root, "data"), "root")
+            if data_root is not None:
+                from pathlib import Path
+
+                kw["data_dir"] = Path(data_root) / "data"
+            if _get(root, "samples_root") is not None:
+                kw["samples_root"] = _get(root, "samples_root")
+            clip = _get(_get(root, "trainer"), "gradient_clip_val")
+            if clip is not None:
+                kw["gradient_clip_val"] = float(clip)
+            if compute_mode is None and _get(root, "matmul_precision") is not None:
+                compute_mode = MATMUL_PRECISION_TO_MODE[str(_get(root, "matmul_precision"))]
+        kw["compute_mode"] = compute_mode or "f32"
+        for k in ("learning_rate", "min_learning_rate", "elbo_weight"):  # YAML 1.1 reads "1e-4" as a string
+            if isinstance(kw.get(k), str):
+                kw[k] = float(kw[k])
+        kw.update(overrides)
+        return cls(**kw)
 
     # ---- the glue around the hot path ------------------------------------------------------
     @staticmethod
@@ -149,6 +254,14 @@ class DiffusionTrainer(nn.Module):
     def _sample_normalized(self, batch, start_from, noise_fn):
         x, C = self._model_input(batch)
         return self.model.p_sample_loop(x, C, self._cell_idx(batch), pbar=False, start_from=start_from, noise_fn=noise_fn)
+
+    @torch.no_grad()
+    def validation_step(self, batch, store):
+        """diffusion.py:167-175: remember the statistics, sample, hand the samples to the store."""
+        if self.stats is None:
+            self.stats = batch.stats
+        store.add_cells(self.sample_cells(batch), batch.data.metadata)
+        return {}
 
     def configure_optimizers(self):
         klass = {"adam": torch.optim.Adam, "adamw": torch.optim.AdamW, "radam": torch.optim.RAdam}.get(self.optimizer)

@@ -80,6 +80,9 @@ CONV_CASES = [
     (1, 128, 0, 32, 4, 8, 8),
     (1, 16, 0, 96, 3, 3, 3),
     (1, 64, 0, 64, 12, 4, 3),
+    # the deep U-Net levels at their real channel counts
+    (2, 256, 0, 256, 12, 4, 3),
+    (1, 256, 256, 128, 24, 8, 6),
 ]
 
 
