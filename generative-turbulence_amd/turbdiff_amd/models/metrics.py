@@ -1,5 +1,6 @@
 """Sample metrics on the device (interface of turbdiff/models/metrics.py:220-380):
-``interp3``, ``TurbulentKineticEnergySpectrum``, ``LogTKESpectrumL2Distance``.
+``interp3``, ``TurbulentKineticEnergySpectrum``, ``LogTKESpectrumL2Distance``, and ``SampleStore``
+(metrics.py:36-124) kept in memory instead of an HDF5 file (h5py is not part of this package's requirements).
 
 The spectrum's FFT is rocFFT (``torch.fft.fftn``); everything around it is two HIP kernels
 (``tdx_tke_energy``, ``tdx_tke_sphere``: csrc/tdx_metrics.hip).  The Lebedev rule comes from
@@ -101,3 +102,68 @@ class LogTKESpectrumL2Distance(nn.Module):
         log_tke_b = self.tke_spectrum(u_b - u_mean, k).log()
         D = slope * torch.einsum("ijk, k -> ij", (log_tke_a[:, None] - log_tke_b[None]) ** 2, self.legendre_weights)
         return torch.sqrt(D), log_tke_a, log_tke_b, k
+
+
+class SampleStore:
+    """Generated samples per case, as the reference's ``SampleStore`` keeps them (metrics.py:36-124): for every
+    variable the in-domain values, channels-last, ``(n_samples, n_cells, dims)`` -- in host memory instead of an
+    HDF5 file.  ``samples_file`` is optional: ``save()`` writes one ``.npz`` with the arrays
+    ``<case>/<variable>`` (the reference's ``<case>/data/<variable>`` datasets).
+
+    Like the reference's, a store belongs to one process: under data-parallel evaluation every rank keeps the
+    cases it sampled (``data.ofles.OpenFOAMEvaluationSampler`` shards whole batches) and rank 0 merges."""
+
+    def __init__(self, samples_file=None, variables=()):
+        self.samples_file = samples_file
+        self.variables = tuple(variables)
+        self._cases: dict = {}   # case name -> {variable: [tensor (b, n_cells, dims), ...]}
+
+    # -- adding
+    def add_cells(self, cells: dict, metadata):
+        """``cells``: {variable: (B, n_cells, dims)} as ``Normalization.denormalized_cells`` / ``tdx_grid_select``
+        produce them on the device (the gather + channels-last split of metrics.py:52-58 already done)."""
+        case = self._cases.setdefault(metadata.case_name, {v: [] for v in self.variables})
+        for v in self.variables:
+            case[v].append(cells[v].detach().to("cpu", copy=True))
+
+    def add_samples(self, x: torch.Tensor, metadata):
+        """``x``: dense denormalised samples (B, F, X, Y, Z), as ``task.sample`` returns them (metrics.py:50-88)."""
+        from ..data.ofles import split_channels
+        from .utils import select_cells
+
+        cells = select_cells(x, metadata.cell_idx.to(x.device)).transpose(-1, -2)  # (B, n_cells, F)
+        self.add_cells(split_channels(cells, self.variables, dim=-1), metadata)
+
+    # -- reading
+    @property
+    def case_names(self):
+        return list(self._cases)
+
+    def n_samples(self, case_name: str) -> int:
+        return sum(t.shape[0] for t in self._cases[case_name][self.variables[0]])
+
+    def load_samples(self, metadata, *, range=None):
+        """All samples of the case described by ``metadata`` as an ``OpenFOAMData`` (metrics.py:95-112)."""
+        from ..data.ofles import OpenFOAMData
+
+        out = {}
+        for v, parts in self._cases[metadata.case_name].items():
+            t = torch.cat(parts) if parts else torch.empty(0)
+            if range is not None:
+                t = t[range]
+                if t.ndim == 2:  # a single sample keeps its batch axis
+                    t = t[None]
+            out[v] = t
+        return OpenFOAMData(metadata, torch.tensor([]), out)
+
+    def reset(self):
+        self._cases.clear()
+
+    def save(self, path=None):
+        import numpy as np
+
+        path = path or self.samples_file
+        arrays = {f"{case}/{v.name.lower()}": torch.cat(parts).numpy()
+                  for case, per_var in self._cases.items() for v, parts in per_var.items() if parts}
+        np.savez(path, **arrays)
+        return path

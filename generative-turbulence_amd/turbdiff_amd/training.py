@@ -95,6 +95,14 @@ def _get(cfg, key, default=None):
     return getattr(cfg, key, default)
 
 
+def _has(cfg, key) -> bool:
+    return key in cfg if hasattr(cfg, "__contains__") else hasattr(cfg, key)
+
+
+def _raw(cfg, key):
+    return cfg[key] if hasattr(cfg, "__getitem__") else getattr(cfg, key)
+
+
 class DiffusionTrainer(nn.Module):
     """Constructor surface = the reference task's (``DiffusionTraining.__init__``, diffusion.py:42-70: the 27
     keywords ``config.py:74-101`` forwards), plus ``gradient_clip_val`` (the trainer's, train.yaml:30-31),
@@ -175,7 +183,8 @@ class DiffusionTrainer(nn.Module):
         name = _get(model, "name", "diffusion")
         if not str(name).startswith("diffusion"):
             raise ValueError(f"model.name = {name!r}: only the diffusion task is built here")
-        kw = {k: _get(model, k) for k in cls.CONFIG_KEYS if _get(model, k) is not None}
+        # a key that is present is forwarded as is -- None included (lr_decay: ~, elbo_weight: ~), as config.py does
+        kw = {k: _raw(model, k) for k in cls.CONFIG_KEYS if _has(model, k)}
         var = _get(model, "variables")
         kw["variables"] = tuple(Variable) if var is None else tuple(
             Variable.from_str(v) for v in (var.split(",") if isinstance(var, str) else var))

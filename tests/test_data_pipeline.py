@@ -3,12 +3,16 @@ golden vectors from the reference's own classes (tests/golden/make_golden_sample
 and the staged batches on the GPU."""
 
 import random
+import sys
+from pathlib import Path
 
 import numpy as np
 import pytest
 import torch
 
 from conftest import GOLDEN
+
+ROOT = Path(__file__).resolve().parent.parent
 from turbdiff_amd.data.ofles import (InMemoryRepository, OpenFOAMBatch, OpenFOAMDataset, OpenFOAMEvaluationSampler,
                                      OpenFOAMMetadata, OpenFOAMSampler, OpenFOAMStats, Variable)
 
@@ -169,3 +173,53 @@ def test_trainer_runs_from_dataset_sampler_and_stager():
     losses = [tr.fit_step(b).item() for b in DeviceStager((ds[i] for i in sampler), "cuda:0")]
     assert len(losses) == len(sampler) == 2 and all(np.isfinite(losses))
     assert tr.cell_type_embedding.embedding.weight.grad is None or torch.isfinite(tr.cell_type_embedding.embedding.weight).all()
+
+
+@pytest.mark.gpu
+def test_eval_ckpt_flow_on_in_memory_cases(tmp_path):
+    """The flow of the reference's scripts/eval_ckpt.py:43-76 (tools/eval_ckpt.py): run configuration from the
+    checkpoint -> overrides -> task from the configuration -> strict load -> sample every validation batch ->
+    SampleStore -> metrics; on synthetic cases held by InMemoryRepository, with a small model and a short reverse
+    process.  Checks the plumbing: every case sampled, store layout as SampleStore.add_samples keeps it, the stored
+    values equal a direct sample_cells() replay, reruns reproduce, and the CLI prints the metric."""
+    import importlib.util
+    import json
+    import subprocess
+
+    from turbdiff_amd.data.ofles import Variable
+    from turbdiff_amd.training import DiffusionTrainer
+
+    spec = importlib.util.spec_from_file_location("eval_ckpt", ROOT / "tools" / "eval_ckpt.py")
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    run = json.loads((ROOT / "tests" / "golden" / "task_configs.json").read_text())["shipped"]["run_config"]
+    run["model"].update(dim=8, timesteps=10, eval_batch_size=2)
+    run["matmul_precision"] = "highest"
+    torch.manual_seed(3)
+    src = DiffusionTrainer.from_config(run, max_train_steps=1)
+    ckpt = {"config": run, "state_dict": {k: v.clone() for k, v in src.state_dict().items()}}
+    cases, stats = ev.synthetic_cases(2, grid=(24, 16, 16), n_times=6)
+    dev = torch.device("cuda:0")
+    store, metrics, task = ev.evaluate(ckpt, cases, stats, dev, overrides=["model.noise_bcs=false"], val_samples=3, start_from=4,
+                                       samples_path=tmp_path / "samples.npz")
+    assert task.noise_bcs is False and task.compute_mode == "f32"
+    for k, v in task.state_dict().items():
+        assert torch.equal(v.cpu(), ckpt["state_dict"][k]), k
+    assert store.case_names == [c[0].case_name for c in cases]
+    for meta, _, _ in cases:
+        data = store.load_samples(meta)
+        assert data.samples[Variable.U].shape == (3, meta.n_cells, 3) and data.samples[Variable.P].shape == (3, meta.n_cells, 1)
+        assert torch.isfinite(data.samples[Variable.U]).all()
+    z = np.load(tmp_path / "samples.npz")
+    assert sorted(z.files) == sorted(f"{c[0].case_name}/{v}" for c in cases for v in ("u", "p"))
+    assert np.isfinite(list(metrics.values())).all() and "val/log_tke_l2" in metrics
+    # same seed, same checkpoint -> the same samples
+    store2, metrics2, _ = ev.evaluate(ckpt, cases, stats, dev, overrides=["model.noise_bcs=false"], val_samples=3, start_from=4)
+    for meta, _, _ in cases:
+        assert torch.equal(store2.load_samples(meta).samples[Variable.U], store.load_samples(meta).samples[Variable.U])
+    assert metrics2 == metrics
+    # the command line
+    torch.save(ckpt, tmp_path / "model.ckpt")
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "eval_ckpt.py"), str(tmp_path / "model.ckpt"), str(tmp_path / "cli.npz"),
+                          "--synthetic", "1", "--start-from", "2", "model.eval_batch_size=2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "val/log_tke_l2:" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
