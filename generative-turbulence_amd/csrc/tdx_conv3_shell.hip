@@ -204,6 +204,7 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
 
+    struct Frags { uint4 x[PARTS][2], w[PARTS][NT]; };
     const int nchunks = K / (KC * S);
     load_slice(0);
     for (int c = 0; c < nchunks; ++c) {
@@ -211,41 +212,59 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
         store_slice();
         __syncthreads();
         if (c + 1 < nchunks) load_slice(c + 1);
-#pragma unroll
-        for (int ts = 0; ts < 9 * S; ++ts) {
+        // Fragment ring, prefetch distance RING - 1: the LDS reads of tap-step ts + 2 are issued before the MFMAs of step ts
+        // (2-12 MFMAs per step do not cover an LDS round trip; with one or two waves per SIMD nothing else does).
+        constexpr int NS = 9 * S;
+        constexpr int NREAD = PARTS * (2 + NT);  // ds_read_b128 per step
+        constexpr int NMFMA = 2 * NT * (MODE == SH_F32 ? 4 : (MODE == SH_SPLIT ? 3 : 1));
+        constexpr int RING = (MODE == SH_SPLIT && NT == 2) ? 2 : 3;  // (the widest split tile has no registers for 3)
+        Frags ring[RING];
+        auto read_step = [&](int ts, Frags& f) {
             const int t9 = ts % 9, sl = ts / 9;
             const int toff = ((t9 / 3 - 1) * SH_SZ + (t9 % 3 - 1)) * 16;
-            uint4 xf[PARTS][2], wf[PARTS][NT];
 #pragma unroll
             for (int pt = 0; pt < PARTS; ++pt) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    xf[pt][mt] = *reinterpret_cast<const uint4*>(sA + (pt * Q + 2 * sl) * APLANE + a_h[mt] + toff);
+                    f.x[pt][mt] = *reinterpret_cast<const uint4*>(sA + (pt * Q + 2 * sl) * APLANE + a_h[mt] + toff);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    wf[pt][nt] = *reinterpret_cast<const uint4*>(sB + (pt * Q + 2 * sl) * B_PLANE + b_off + (t9 * BN + nt * 32) * 16);
+                    f.w[pt][nt] = *reinterpret_cast<const uint4*>(sB + (pt * Q + 2 * sl) * B_PLANE + b_off + (t9 * BN + nt * 32) * 16);
             }
+        };
+        auto mfma_step = [&](const Frags& f) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     if (MODE == SH_F32) {
-                        const uint4 w = wf[0][nt], x = xf[0][mt];
+                        const uint4 w = f.w[0][nt], x = f.x[0][mt];
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(x.x), acc[nt][mt], 0, 0, 0);
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(x.y), acc[nt][mt], 0, 0, 0);
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(x.z), acc[nt][mt], 0, 0, 0);
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc[nt][mt], 0, 0, 0);
                     } else {
-                        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&wf[0][nt]), xh = *reinterpret_cast<const bf16x8*>(&xf[0][mt]);
+                        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&f.w[0][nt]), xh = *reinterpret_cast<const bf16x8*>(&f.x[0][mt]);
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[nt][mt], 0, 0, 0);
                         if (MODE == SH_SPLIT) {
-                            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&wf[PARTS - 1][nt]);
-                            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(&xf[PARTS - 1][mt]);
+                            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&f.w[PARTS - 1][nt]);
+                            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(&f.x[PARTS - 1][mt]);
                             acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[nt][mt], 0, 0, 0);
                             acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[nt][mt], 0, 0, 0);
                         }
                     }
                 }
+        };
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i) read_step(i, ring[i]);
+        __builtin_amdgcn_sched_group_barrier(0x100, (RING - 1) * NREAD, 0);
+#pragma unroll
+        for (int ts = 0; ts < NS; ++ts) {
+            constexpr int D = RING - 1;
+            if (ts + D < NS) read_step(ts + D, ring[(ts + D) % RING]);
+            mfma_step(ring[ts % RING]);
+            if (ts + D < NS) __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);  // DS reads of step ts + D first,
+            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);                    // then the MFMAs of step ts
         }
     }
 

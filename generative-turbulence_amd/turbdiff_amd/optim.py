@@ -8,7 +8,8 @@ The reference trains with ``torch.optim.RAdam(lr)`` (models/diffusion.py:210-218
 fp32 state) through ``tdx_grad_norm`` / ``tdx_radam_step`` (csrc/tdx_optim.hip).
 
 It is a ``torch.optim.Optimizer``: ``param_groups[i]["lr"]`` is honoured every step (LR schedulers
-work), and the per-parameter state uses torch's RAdam keys (``step``, ``exp_avg``, ``exp_avg_sq``), so
+work), and the per-parameter state uses torch's RAdam keys (``step``, ``exp_avg``, ``exp_avg_sq``) with
+per-parameter step counts (parameters at different counts are updated in one launch per count), so
 optimizer state_dicts move between the two implementations.
 """
 
@@ -69,6 +70,16 @@ class ClipRAdam(torch.optim.Optimizer):
         self._plans[gi] = plan
         return plan
 
+    @staticmethod
+    def _chunks_of(plan, members):
+        """Chunk tables restricted to the parameters `members` (cached per member set)."""
+        cache = plan.setdefault("subsets", {})
+        hit = cache.get(members)
+        if hit is None:
+            keep = torch.isin(plan["chunk_tensor"], torch.tensor(members, dtype=torch.int32, device=plan["dev"]))
+            hit = cache[members] = (plan["chunk_tensor"][keep].contiguous(), plan["chunk_off"][keep].contiguous(), int(keep.sum()))
+        return hit
+
     @torch.no_grad()
     def step(self, closure=None):
         """clip (if ``max_norm``) + RAdam.  Returns the loss of ``closure`` if given; the total gradient
@@ -102,11 +113,9 @@ class ClipRAdam(torch.optim.Optimizer):
             plan["table"].copy_(plan["hosts"][k], non_blocking=True)
             plan["events"][k] = torch.cuda.Event()
             plan["events"][k].record()
-            steps = {float(self.state[p]["step"]) for p in plan["params"] if p.grad is not None}
-            if not steps:
+            live = [i for i, p in enumerate(plan["params"]) if p.grad is not None]
+            if not live:
                 continue
-            if len(steps) != 1:
-                raise RuntimeError("parameters of one group are at different step counts")
             stream = L.stream()
             clip = None
             if self.max_norm:
@@ -115,9 +124,19 @@ class ClipRAdam(torch.optim.Optimizer):
                 clip = plan["norm"]
                 self.last_grad_norm = plan["norm"][0]
             b1, b2 = group["betas"]
-            L.call("tdx_radam_step", L.ptr(plan["table"]), L.ptr(plan["chunk_tensor"]), L.ptr(plan["chunk_off"]),
-                   plan["nchunks"], L.ptr(clip), int(steps.pop()), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                   int(self.write_clipped_grads), stream)
+            # RAdam's bias corrections depend on the step count, which torch keeps per parameter: parameters that
+            # received gradients on different numbers of steps (conditional branches, a state_dict loaded from
+            # torch.optim.RAdam) are updated in one launch per distinct count, over that count's chunks only
+            by_step = {}
+            for i in live:
+                by_step.setdefault(int(self.state[plan["params"][i]]["step"]), []).append(i)
+            for step_count, members in by_step.items():
+                if len(by_step) == 1:
+                    ct, co, n = plan["chunk_tensor"], plan["chunk_off"], plan["nchunks"]
+                else:
+                    ct, co, n = self._chunks_of(plan, tuple(members))
+                L.call("tdx_radam_step", L.ptr(plan["table"]), L.ptr(ct), L.ptr(co), n, L.ptr(clip), step_count,
+                       float(group["lr"]), float(b1), float(b2), float(group["eps"]), int(self.write_clipped_grads), stream)
             # the kernels wrote through raw pointers: tell autograd (and the packed-weight caches keyed
             # on Tensor._version, ops._packed_conv3) that the parameters changed
             torch.autograd.graph.increment_version([p for p in plan["params"] if p.grad is not None])

@@ -86,11 +86,20 @@ class GraphSampler:
         with torch.cuda.graph(self.graph):
             self._step()
         self.x_t.copy_(state[0]); self.t.copy_(state[1]); self.offset.copy_(state[2])
+        # The graph has the addresses of the packed weight operands (ops._pack_cache) baked in.  Keep those
+        # buffers alive for as long as the graph lives, and remember the parameter versions they were packed
+        # from: a weight update (optimiser step, load_state_dict) makes replay() re-capture instead of running on
+        # stale operands.
+        self._held = list(ops._pack_cache.values())
+        self._versions = [(p, p._version) for p in self.d.parameters()]
+
+    def _stale(self) -> bool:
+        return any(p._version != v for p, v in self._versions)
 
     @torch.no_grad()
     def run_steps(self, n: int):
         n = min(n, self.steps_left)
-        if self.use_graph and self.graph is None:
+        if self.use_graph and (self.graph is None or self._stale()):
             self._capture()
         for _ in range(n):
             if self.use_graph:

@@ -324,6 +324,28 @@ def test_graph_sampler_equals_eager_loop(golden, nb):
     assert rel_l2(solo[0], out_graph[1]) < 1e-5
 
 
+def test_graph_sampler_recaptures_after_a_weight_update(golden):
+    """The captured graph has the packed weight operands' addresses baked in.  After the weights change (optimiser
+    step, load_state_dict, here an in-place update) the sampler must not replay stale operands: it re-captures, and
+    the result equals the eager loop on the NEW weights."""
+    from turbdiff_amd.sampling import GraphSampler
+
+    g = golden("sample_cfg1")
+    diff = build_cfg1(golden, noise_bcs=True)
+    x_bcs, C, cidx = g["x_bcs"].to(dev()), cond(g["c_local"]), g["cell_idx"].to(dev())
+    gs = GraphSampler(diff, x_bcs, C, cidx, seed=7)
+    before = gs.sample()
+    first_graph = gs.graph
+    with torch.no_grad():
+        for p in diff.model.parameters():
+            p.mul_(1.05)  # bumps Tensor._version, as an optimiser step does
+    after = gs.sample()
+    assert gs.graph is not first_graph, "the sampler kept replaying the graph captured on the old weights"
+    stream = gs.noise_stream()
+    eager = diff.p_sample_loop(x_bcs, C, cidx, noise_fn=lambda like: next(stream))
+    assert rel_l2(after, eager) < 1e-5 and rel_l2(after, before) > 1e-3
+
+
 def test_unfused_block_composition_matches_golden(golden, monkeypatch):
     """TDX_FUSE_BLOCKS=0 path (one autograd node per operator) -- same kernels, cross-check of the
     hand-written ResnetBlock backward used by default."""

@@ -635,6 +635,29 @@ def test_clip_radam_matches_torch(max_norm):
         assert torch.allclose(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-4, atol=1e-12)
 
 
+def test_clip_radam_parameters_at_different_step_counts():
+    """A parameter that receives a gradient only on some steps (a conditional branch of the model) has its own
+    step count in torch.optim.RAdam; the fused optimiser follows (one launch per distinct count)."""
+    from turbdiff_amd.optim import ClipRAdam
+
+    torch.manual_seed(2)
+    d = torch.device("cuda:0")
+    shapes = [(9,), (33, 5), (20000,), (7, 3)]
+    pa = [torch.randn(s, device=d).requires_grad_() for s in shapes]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    oa, ob = torch.optim.RAdam(pa, lr=1e-2), ClipRAdam(pb, lr=1e-2, max_norm=None)
+    for step in range(9):
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            skip = (k == 1 and step % 2 == 1) or (k == 3 and step < 4)  # parameter 1: every other step; 3: late joiner
+            g = torch.randn(a.shape, device=d)
+            a.grad, b.grad = (None, None) if skip else (g.clone(), g.clone())
+        oa.step()
+        ob.step()
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (step, k)
+    assert [int(oa.state[p]["step"]) for p in pa] == [int(ob.state[p]["step"]) for p in pb] == [9, 5, 9, 5]
+
+
 def test_clip_radam_with_bucket_view_gradients():
     """Gradients that are views into a flat all-reduce bucket (parallel.BucketedDataParallel.finish) are
     only 4-byte aligned: the fused optimiser must not assume 16-byte alignment."""
