@@ -68,6 +68,9 @@ SIGNATURES = {
     "tdx_tke_sphere": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_randn": (_i, [_vp, _i64, _u64, _u64, _vp, _vp]),
     "tdx_randn_batched": (_i, [_vp, _i, _i64, _u64, _vp, _vp, _vp]),
+    "tdx_convg_apply": (_i, [_vp, _vp, _vp, _vp] + [_i] * 16 + [_vp]),
+    "tdx_convg_fold_clamp": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tdx_convg_bwd_weight": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
     "tdx_opt_chunk_elems": (_i64, []),
     "tdx_grad_norm": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "tdx_radam_step": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _f, _f, _f, _f, _i, _vp]),

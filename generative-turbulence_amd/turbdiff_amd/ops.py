@@ -802,3 +802,120 @@ def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, s
     return _ResnetBlock.apply(x1, x2, scale, shift, conv1_wb[0], conv1_wb[1], norm1_wb[0], norm1_wb[1], conv2_wb[0],
                               conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps, partial, conv1_input,
                               conv1_real_channels)
+
+
+# --------------------------------------------------------------------------- baseline conv variants
+
+
+def _taps_first(w5: torch.Tensor, in_axis: int, out_axis: int) -> torch.Tensor:
+    """(.., k, k, k) weight with its in / out channel axes named -> [k^3][in][out] f32 (tdx_convg_* operand)."""
+    k = w5.shape[-1]
+    return w5.detach().float().permute(2, 3, 4, in_axis, out_axis).reshape(k**3, w5.shape[in_axis], w5.shape[out_axis]).contiguous()
+
+
+def _convg_apply(x, w_t, bias, out_grid, Cout, k, stride, dilation, pad, replicate, transposed):
+    B, Xi, Yi, Zi, Cin = _grid(x)
+    y = torch.empty((B, *out_grid, Cout), dtype=x.dtype, device=x.device)
+    L.call("tdx_convg_apply", L.ptr(x), L.ptr(w_t), L.ptr(bias), L.ptr(y), B, Xi, Yi, Zi, Cin, *out_grid, Cout, k, stride,
+           dilation, pad, int(replicate), int(transposed), L.dtype_code(x.dtype), L.stream())
+    return y
+
+
+class _ConvG(torch.autograd.Function):
+    """nn.Conv3d(k, stride, dilation, padding, padding_mode in {"zeros", "replicate"}) on NDHWC tensors: the dilated
+    convs of DilatedCNNBlock (dilresnet.py:28-35) and the strided convs of tfnet's conv() (tfnet.py:187-193)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, dilation, padding, replicate):
+        B, Xi, Yi, Zi, Cin = _grid(x)
+        Cout, k = weight.shape[0], weight.shape[-1]
+        assert weight.shape[1] == Cin and not (replicate and stride != 1), "replicate padding: stride 1 only"
+        x = x.contiguous()
+        out = tuple((e + 2 * padding - dilation * (k - 1) - 1) // stride + 1 for e in (Xi, Yi, Zi))
+        y = _convg_apply(x, _taps_first(weight, 1, 0), None if bias is None else bias.detach().float().contiguous(), out, Cout, k,
+                         stride, dilation, padding, replicate, False)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, dilation, padding, replicate, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, dilation, pad, replicate, has_bias = ctx.cfg
+        B, Xi, Yi, Zi, Cin = _grid(x)
+        Cout, k = weight.shape[0], weight.shape[-1]
+        gy = gy.contiguous()
+        Xo, Yo, Zo = gy.shape[1:4]
+        code, st = L.dtype_code(x.dtype), L.stream()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            w_b = _taps_first(weight, 0, 1)  # [k^3][Cout][Cin]
+            if replicate:  # adjoint on the padded grid, then every padded position onto the voxel it clamps to
+                dpad = _convg_apply(gy, w_b, None, (Xi + 2 * pad, Yi + 2 * pad, Zi + 2 * pad), Cin, k, stride, dilation, 0, False, True)
+                gx = torch.empty_like(x)
+                L.call("tdx_convg_fold_clamp", L.ptr(dpad), L.ptr(gx), B, Xi, Yi, Zi, pad, Cin, code, st)
+            else:
+                gx = _convg_apply(gy, w_b, None, (Xi, Yi, Zi), Cin, k, stride, dilation, pad, False, True)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((k**3, Cin, Cout), dtype=torch.float32, device=x.device)
+            gb = torch.zeros(Cout, dtype=torch.float32, device=x.device) if has_bias else None
+            L.call("tdx_convg_bwd_weight", L.ptr(x), L.ptr(gy), L.ptr(dw), L.ptr(gb), B, Xi, Yi, Zi, Cin, Xo, Yo, Zo, Cout, k,
+                   stride, dilation, pad, int(replicate), code, st)
+            gw = dw.reshape(k, k, k, Cin, Cout).permute(4, 3, 0, 1, 2).contiguous()
+        return gx, gw, gb, None, None, None, None
+
+
+def conv3d(x, weight, bias=None, stride=1, dilation=1, padding=0, padding_mode="zeros"):
+    """General NDHWC 3-D convolution (weight in nn.Conv3d's layout (Cout, Cin, k, k, k)); padding_mode "zeros" or
+    "replicate".  Channel counts must be multiples of 8.  Vector-ALU kernels: baseline models only -- the U-Net's
+    3x3x3 convs go through conv3 / resnet_block."""
+    if padding_mode not in ("zeros", "replicate"):
+        raise ValueError(f"padding_mode {padding_mode!r}")
+    return _ConvG.apply(x, weight, bias, int(stride), int(dilation), int(padding), padding_mode == "replicate")
+
+
+class _ConvTransposeG(torch.autograd.Function):
+    """nn.ConvTranspose3d(k, stride, padding) (tfnet.py:203-205: k = 4, stride 2, padding 1) on NDHWC tensors;
+    weight in its layout (Cin, Cout, k, k, k)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding):
+        B, Xi, Yi, Zi, Cin = _grid(x)
+        Cout, k = weight.shape[1], weight.shape[-1]
+        assert weight.shape[0] == Cin
+        x = x.contiguous()
+        out = tuple((e - 1) * stride - 2 * padding + k for e in (Xi, Yi, Zi))
+        y = _convg_apply(x, _taps_first(weight, 0, 1), None if bias is None else bias.detach().float().contiguous(), out, Cout, k,
+                         stride, 1, padding, False, True)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, padding, bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        stride, pad, has_bias = ctx.cfg
+        B, Xi, Yi, Zi, Cin = _grid(x)
+        Cout, k = weight.shape[1], weight.shape[-1]
+        gy = gy.contiguous()
+        Xo, Yo, Zo = gy.shape[1:4]
+        code, st = L.dtype_code(x.dtype), L.stream()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:  # a strided conv of dy
+            gx = _convg_apply(gy, _taps_first(weight, 1, 0), None, (Xi, Yi, Zi), Cin, k, stride, 1, pad, False, False)
+        if ctx.needs_input_grad[1]:
+            # dW[ci][co][t] = sum_i x[i][ci] dy[i*s - p + t][co]: the weight gradient of that strided conv, roles swapped
+            dw = torch.zeros((k**3, Cout, Cin), dtype=torch.float32, device=x.device)
+            L.call("tdx_convg_bwd_weight", L.ptr(gy), L.ptr(x), L.ptr(dw), None, B, Xo, Yo, Zo, Cout, Xi, Yi, Zi, Cin, k, stride,
+                   1, pad, 0, code, st)
+            gw = dw.reshape(k, k, k, Cout, Cin).permute(4, 3, 0, 1, 2).contiguous()
+            if has_bias:
+                gb = gy.float().sum(dim=(0, 1, 2, 3))
+        return gx, gw, gb, None, None
+
+
+def conv_transpose3d(x, weight, bias=None, stride=2, padding=1):
+    """NDHWC transposed 3-D convolution (weight (Cin, Cout, k, k, k) as in nn.ConvTranspose3d)."""
+    return _ConvTransposeG.apply(x, weight, bias, int(stride), int(padding))

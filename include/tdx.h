@@ -318,6 +318,32 @@ int tdx_radam_step(const TdxOptTensor* table, const int* chunk_tensor, const int
                    const float* clip, int64_t step, float lr, float beta1, float beta2, float eps, int write_grad,
                    void* stream);
 
+/* ------------------------------------------------------------------ baseline conv variants
+ * The conv layers of the reference's regression baselines, NDHWC, off the benchmark path:
+ *   nn.Conv3d(dim, dim, 3, dilation=d, padding=d, padding_mode="replicate")        dilresnet.py:28-35
+ *   nn.Conv3d(cin, cout, k, stride=2, padding=(k-1)//2)                            tfnet.py:187-193
+ *   nn.ConvTranspose3d(cin, cout, kernel_size=4, stride=2, padding=1)              tfnet.py:203-205
+ * Weights are passed as w[tap][Cin][Cout] f32, tap = (t0*k + t1)*k + t2, Cin = channels of `in`, Cout = channels of
+ * `out` (for a transposed layer and for data gradients the caller passes the appropriately transposed matrix).
+ *
+ * tdx_convg_apply, transposed == 0 (conv forward; data gradient of a transposed conv):
+ *     out[b, o, :] = bias + sum_t in[b, src(o, t), :] @ w[t],   src = o*stride - pad + t*dilation, taken with
+ *     replicate != 0 by clamping to the grid, else skipped when outside.
+ * transposed != 0 (transposed-conv forward; data gradient of a zero-padded conv):
+ *     out[b, i, :] = bias + sum_t in[b, (i + pad - t*dilation)/stride, :] @ w[t]   where divisible and in range.
+ * The data gradient of a REPLICATE-padded conv (stride 1) is the transposed form evaluated on the padded grid
+ * (out grid = E + 2 pad, pad argument 0 ... see turbdiff_amd/ops.py) followed by tdx_convg_fold_clamp, which adds every
+ * padded position onto the voxel it clamps to.  Cin % 8 == Cout % 8 == 0. */
+int tdx_convg_apply(const void* in, const float* w, const float* bias, void* out, int B, int Xi, int Yi, int Zi, int Cin,
+                    int Xo, int Yo, int Zo, int Cout, int k, int stride, int dilation, int pad, int replicate,
+                    int transposed, int dtype, void* stream);
+int tdx_convg_fold_clamp(const void* dpad, void* dx, int B, int X, int Y, int Z, int pad, int C, int dtype, void* stream);
+/* dw[tap][Cin][Cout] (+ dbias[Cout], may be NULL) of out = apply(in, w) in the non-transposed form; accumulates with
+ * f32 atomics: dw / dbias must be zero on entry.  Cout <= 512. */
+int tdx_convg_bwd_weight(const void* in, const void* dy, float* dw, float* dbias, int B, int Xi, int Yi, int Zi, int Cin,
+                         int Xo, int Yo, int Zo, int Cout, int k, int stride, int dilation, int pad, int replicate,
+                         int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -190,3 +190,31 @@ def test_oracle_norm_type_variants(golden, tag, norm):
     with torch.no_grad():
         eps = O.denoiser(sd, g["x"], g["t"], g["c_local"], timesteps=10, norm_type=norm)
     assert rel_l2(eps, g[f"{tag}/eps_hat"]) < 1e-5
+
+
+# --------------------------------------------------------------------------- baseline conv layers
+
+
+@pytest.mark.parametrize("tag", ["dil", "dil8", "conv_s2", "conv_k5", "deconv"])
+def test_baseline_conv_oracle(golden, tag):
+    """oracle/baselines_oracle.py against the reference's DilatedCNNBlock / tfnet.conv / tfnet.deconv
+    (tests/golden/make_golden_baselines.py): forward, input gradient and every parameter gradient."""
+    from oracle import baselines_oracle as BO
+
+    g = golden("baselines")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "num_batches" not in k)
+          for k, v in g.sub(f"{tag}/sd/").items()}
+    x = g[f"{tag}/x"].clone().requires_grad_()
+    if tag.startswith("dil"):
+        y = BO.dilated_block(sd, x, [int(d) for d in g[f"{tag}/dilations"]])
+    elif tag == "conv_s2":
+        y = BO.tfnet_conv(sd, x, 3, 2, training=True)
+    elif tag == "conv_k5":
+        y = BO.tfnet_conv(sd, x, 5, 2, training=False)
+    else:
+        y = BO.tfnet_deconv(sd, x)
+    y.backward(g[f"{tag}/gy"])
+    assert rel_l2(y, g[f"{tag}/y"]) < 1e-6 and rel_l2(x.grad, g[f"{tag}/gx"]) < 1e-5
+    for k in g.keys(f"{tag}/grad/"):
+        name = k[len(f"{tag}/grad/"):]
+        assert rel_l2(sd[name].grad, g[k]) < 1e-5, name
