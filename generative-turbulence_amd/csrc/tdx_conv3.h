@@ -47,13 +47,6 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
                       void* d1 = nullptr, int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr,
                       const void* a2 = nullptr, const Conv3Ext* ext = nullptr);
 
-// wide-tile bf16 kernel (tdx_conv3_mfma_v2.hip): 4 x 8 x 16 bricks, 128 x 64 register tile per wave; perm_out = the brick
-// orientation (local axis k = global axis perm_out[k])
-bool conv3_mfma_v2_applies(const Conv3Geom& g, int C1, int C2, int Cout, int perm_out[3]);
-int conv3_mfma_v2_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
-                         const Conv3Geom& g, int Cout, bool zero_pad, const int perm[3], hipStream_t st, double* gn_acc,
-                         void* d1, int D1, void* d2, const void* a1, const void* a2);
-
 bool conv3_wgrad_mfma_supported(int C1, int C2, int Cout);
 bool conv3_wgrad_mfma_split_supported(int C1, int C2, int Cout);
 int conv3_wgrad_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,

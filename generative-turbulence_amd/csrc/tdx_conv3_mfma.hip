@@ -392,11 +392,6 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
                       void* d2, const void* a1, const void* a2, const Conv3Ext* ext) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const void* init = ext ? ext->init : nullptr;
-    {   // big, well-tiled launches with 64-wide output tiles: the wide-tile kernel
-        int perm[3];
-        if (ext == nullptr && conv3_mfma_v2_applies(g, C1, C2, Cout, perm))
-            return conv3_mfma_v2_launch(x1, C1, x2, C2, wp, bias, y, g, Cout, zero_pad, perm, st, gn_acc, d1, D1, d2, a1, a2);
-    }
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
     static const bool no_thin = getenv("TDX_CONV3_THIN") && atoi(getenv("TDX_CONV3_THIN")) == 0;  // A/B switch
 
