@@ -431,6 +431,20 @@ conv3_wgrad_direct_kernel(const T* __restrict__ x1, int C1, const T* __restrict_
     if (do_bias && tid < D3_BN && co0 + tid < Cout) atomicAdd(&dbias[co0 + tid], bsum);
 }
 
+// ------------------------------------------------------------------ scratch arena --------
+// caller-provided transient workspace of kernels whose entry points have no argument for one (the K-split slabs of
+// the small-grid conv, tdx_conv3_small.hip).  The first 64 bytes must be zero and stay zero.
+static void* g_scratch = nullptr;
+static size_t g_scratch_bytes = 0;
+void* tdx_scratch_ptr() { return g_scratch; }
+size_t tdx_scratch_bytes() { return g_scratch_bytes; }
+extern "C" int tdx_set_scratch(void* ptr, size_t bytes) {
+    if (ptr != nullptr && bytes < ((size_t)1 << 20)) return TDX_EINVAL;
+    g_scratch = ptr;
+    g_scratch_bytes = ptr ? bytes : 0;
+    return TDX_OK;
+}
+
 // ------------------------------------------------------------------ entry points ---------
 static bool mfma_ok(int dtype, int Cin1, int Cin2, int Cout) {
     return dtype == TDX_BF16 && conv3_mfma_supported(Cin1, Cin2, Cout);
@@ -451,6 +465,10 @@ extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, con
     const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout));
     if (use_mfma) {
         if (!mfma_ok(dtype, C1, C2, Cout)) return TDX_ESHAPE;
+        // deep U-Net levels: the small-grid kernel (packed M tiles, split K); TDX_ESHAPE = not such a case
+        int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false,
+                                    as_stream(stream));
+        if (rs != TDX_ESHAPE) return rs;
         return conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));
     }
     return conv3_direct_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, dtype, false, as_stream(stream));
@@ -488,6 +506,11 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     }
     if (!mfma_ok(dtype, C1, C2, Cout)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
     hipStream_t st = as_stream(stream);
+    {   // deep U-Net levels: small-grid conv, then the statistics pass over its (tiny) result
+        int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false, st);
+        if (rs == TDX_OK) return tdx_gn_stats(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, stream);
+        if (rs != TDX_ESHAPE) return rs;
+    }
     double* acc = (double*)gn_workspace;
     if (!clean) {
         hipError_t e = hipMemsetAsync(acc, 0, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
@@ -546,6 +569,9 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
     int rc;
     if (use_mfma) {
         if (!mfma_ok(dtype, Cout, 0, Cin)) return TDX_ESHAPE;
+        // deep U-Net levels: adjoint on the padded grid by the small-grid kernel, halo fold in its reduce pass
+        rc = conv3_small_launch(dy, Cout, nullptr, 0, wb, nullptr, dx1, C1, dx2, add1, add2, B, X, Y, Z, Cin, true, st);
+        if (rc != TDX_ESHAPE) return rc;
         rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2);
         if (rc != TDX_OK) return rc;
         return conv3_shell_launch(dy, wb, dx1, C1, dx2, B, X, Y, Z, Cout, Cin, 0, st);

@@ -1,0 +1,386 @@
+// bf16 MFMA 3x3x3 convolution for SMALL grids (the deep U-Net levels: 24 x 8 x 6 and 12 x 4 x 3 voxels, 256-1024
+// channels), forward and data gradient.  gfx950.
+//
+// The brick kernel (tdx_conv3_mfma.hip) gives such a launch 96-288 workgroups, each filling 28-75 % of a 4 x 8 x 8
+// brick and walking K = 27 x 512 alone on its CU, one 73-KB stage per 2.8 us: 130-600 TFLOP/s, and another 55-80 us
+// per layer for the halo-shell kernel of the data gradient.  Here the GEMM is cut the other way:
+//
+//   M rows     = voxels of a "virtual grid", packed densely into 32-row M tiles regardless of brick shapes.  Forward:
+//                the real grid, sources clamped (replicate padding).  Data gradient: the PADDED grid (X+2)(Y+2)(Z+2)
+//                with zero sources outside the real grid -- the adjoint on the padded grid, whose rows the reduce pass
+//                folds onto the voxels they clamp to; no separate shell launch.
+//   workgroup  = (row group, 32 output channels, K split).  A row group is a few whole samples or an x slab of one,
+//                at most 28 M tiles = 7 per wave; its sources live in LDS as a zero- / clamp-filled image with a
+//                one-voxel rim, so a tap is a uniform offset and any row can sit in any lane.
+//   K split    = contiguous ranges of 16-channel slices; every workgroup stores its fp32 partial tile to
+//                slab[split][virtual voxel][channel], and conv3_small_reduce_kernel sums the splits (and, for the data
+//                gradient, the up to 8 padded positions that clamp onto a voxel), adds bias / the residual addend,
+//                converts and stores.  The split is what fills the chip: 12 x 4 x 3 x 6 samples is 27 M tiles in all.
+//   staging    = LDS-DMA (global_load_lds_dwordx4), double-buffered: slice c + 1 lands while slice c's 27 taps run;
+//                zero fill = DMA from a zeroed 16-B block.  No staging registers: 7 accumulator tiles + fragments fit.
+//
+// Slab traffic is the price (S x rows x N x 4 B written and read once); at these sizes it is 5-40 MB per layer.
+#include "tdx_common.h"
+#include "tdx_conv3.h"
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define SM_KC 16
+#define SM_BN 32
+#define SM_MAX_TILES 28
+
+struct SmallGeom {
+    int B;
+    int Ev[3];     // virtual grid (rows)
+    int Es[3];     // source grid
+    int off;       // source coordinate = virtual coordinate - off
+    int clamp;     // 1: clamp sources into the grid (forward), 0: zero outside (data gradient)
+    int nbg;       // samples per row group (1 when a sample is cut into x slabs)
+    int xs;        // virtual x planes per row group
+    int gx;        // x slabs per sample
+    int Ix, Iy, Iz;  // LDS image per sample of a group: (xs + 2) x (Ev[1] + 2) x (Ev[2] + 2) entries
+    int K, N;      // channels of the source tensor(s) / of the result
+    int per_split; // K slices per split
+    int nsplit;
+};
+
+template <int MTW>
+__global__ void __launch_bounds__(256, 1)
+conv3_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2, const bf16* __restrict__ wp,
+                   float* __restrict__ slab, const bf16* __restrict__ zero16, SmallGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+
+    // ---- this workgroup: row group (samples b0 .. b0 + nb, virtual planes x0 .. x0 + xs), channel tile, K split
+    const int group = blockIdx.x, n0 = blockIdx.y * SM_BN, split = blockIdx.z;
+    const int b0 = (group / g.gx) * g.nbg, x0 = (group % g.gx) * g.xs;
+    const int nb = min(g.nbg, g.B - b0), xs = min(g.xs, g.Ev[0] - x0);
+    const int per_sample = xs * g.Ev[1] * g.Ev[2];
+    const int nrows = nb * per_sample;
+    const int img = g.Ix * g.Iy * g.Iz;           // entries per sample image
+    const int entries = nb * img;
+    const int IMG_HALF = ((g.nbg * img + 63) & ~63) * 16;  // bytes of one half-plane: a full group, in whole 1-KiB DMA pieces
+    constexpr int W_HALF = 27 * SM_BN * 16;       // 13824 B
+    unsigned char* sImg = smem;                   // [2 buffers][2 halves][IMG_HALF]
+    unsigned char* sW = smem + 4 * IMG_HALF;      // [2 buffers][2 halves][W_HALF]
+
+    // ---- DMA plan of the image: pieces of 64 consecutive entries of one half; lane l of piece p fills entry 64 p + l.
+    // The source voxel of an entry does not depend on the slice: computed once (-1: zero fill, or beyond the image).
+    // A wave owns pieces wave, wave + 4, ...: at most MAXP per wave.
+    constexpr int MAXP = 8;                       // 4 waves x 8 pieces x 64 = 2048 entries
+    int src_vox[MAXP];
+#pragma unroll
+    for (int j = 0; j < MAXP; ++j) {
+        const int e = (wave + 4 * j) * 64 + lane;
+        int v = -1;
+        if (e < entries) {
+            const int bl = e / img, rem = e - bl * img;
+            const int ix = rem / (g.Iy * g.Iz), rem2 = rem - ix * (g.Iy * g.Iz);
+            const int iy = rem2 / g.Iz, iz = rem2 - iy * g.Iz;
+            int s0 = x0 + ix - 1 - g.off, s1 = iy - 1 - g.off, s2 = iz - 1 - g.off;
+            bool ok = true;
+            if (g.clamp) {
+                s0 = min(max(s0, 0), g.Es[0] - 1); s1 = min(max(s1, 0), g.Es[1] - 1); s2 = min(max(s2, 0), g.Es[2] - 1);
+            } else {
+                ok = s0 >= 0 && s0 < g.Es[0] && s1 >= 0 && s1 < g.Es[1] && s2 >= 0 && s2 < g.Es[2];
+            }
+            if (ok) v = (((b0 + bl) * g.Es[0] + s0) * g.Es[1] + s1) * g.Es[2] + s2;
+        }
+        src_vox[j] = v;
+    }
+    const int npieces = (entries + 63) >> 6;
+    auto dma_slice = [&](int c, int buf) {
+        const int k0 = c * SM_KC;
+        const bf16* xs_;
+        int Cs, kk;
+        if (k0 < C1) { xs_ = x1; Cs = C1; kk = k0; } else { xs_ = x2; Cs = C2; kk = k0 - C1; }
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j) {
+                const int p = wave + 4 * j;
+                if (p < npieces) {
+                    const bf16* src = src_vox[j] >= 0 ? xs_ + (int64_t)src_vox[j] * Cs + kk + half * 8 : zero16;
+                    unsigned char* dst = sImg + (buf * 2 + half) * IMG_HALF + p * 1024;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                }
+            }
+        // weights of the slice: LDS image [half][row = tap * 32 + n] of 16-B entries, 864 rows per half = 13.5 DMA pieces
+        // of 64 rows -> 14 pieces per half (the last one half full: its upper lanes re-read the last row into slack)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int q = wave + 4 * j;           // 0..27: piece index over both halves (14 each)
+            if (q < 28) {
+                const int half = q / 14, row = (q % 14) * 64 + lane;  // row = tap * 32 + n
+                const int rr = min(row, 27 * SM_BN - 1);               // the last piece is half full: harmless re-read
+                const int tap = rr >> 5, n = rr & 31;
+                const bf16* src = wp + ((int64_t)(c * 27 + tap) * g.N + n0 + n) * SM_KC + half * 8;
+                unsigned char* dst = sW + (buf * 2 + half) * (W_HALF + 512) + (q % 14) * 1024;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- rows of this lane: M tile m = wave + 4 i, row = 32 m + r -> image entry of its centre
+    int a_ent[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int row = (wave + 4 * i) * 32 + r;
+        int ent = 0;
+        if (row < nrows) {
+            const int bl = row / per_sample, rem = row - bl * per_sample;
+            const int lx = rem / (g.Ev[1] * g.Ev[2]), rem2 = rem - lx * (g.Ev[1] * g.Ev[2]);
+            const int ly = rem2 / g.Ev[2], lz = rem2 - ly * g.Ev[2];
+            ent = ((bl * g.Ix + lx + 1) * g.Iy + ly + 1) * g.Iz + lz + 1;
+        } else {
+            ent = g.Iy * g.Iz + g.Iz + 1;  // any entry with a full neighbourhood inside the image
+        }
+        a_ent[i] = ent * 16 + hh * IMG_HALF;
+    }
+    const int w_off = hh * (W_HALF + 512) + r * 16;
+
+    f32x16 acc[MTW];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    const int c_first = split * g.per_split, c_end = min(g.K / SM_KC, c_first + g.per_split);
+    auto drain_and_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    if (c_first < c_end) dma_slice(c_first, 0);
+    drain_and_sync();
+    for (int c = c_first; c < c_end; ++c) {
+        const int buf = (c - c_first) & 1;
+        if (c + 1 < c_end) dma_slice(c + 1, buf ^ 1);  // lands while this slice's taps run (buffer last read one slice ago)
+        const unsigned char* A = sImg + buf * 2 * IMG_HALF;
+        const unsigned char* W = sW + buf * 2 * (W_HALF + 512) + w_off;
+        // fragments of tap t + 1 are read while the MTW MFMAs of tap t issue (two register sets, pinned with
+        // sched_group_barrier): one wave per SIMD has nothing else to hide an LDS round trip behind
+        struct Frags { bf16x8 w, x[MTW]; };
+        auto read_tap = [&](int tap, Frags& f) {
+            const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
+            const int toff = ((ex * g.Iy + ey) * g.Iz + ez) * 16;
+            f.w = *reinterpret_cast<const bf16x8*>(W + tap * (SM_BN * 16));
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) f.x[i] = *reinterpret_cast<const bf16x8*>(A + a_ent[i] + toff);
+        };
+        auto mfma_tap = [&](const Frags& f) {
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w, f.x[i], acc[i], 0, 0, 0);
+        };
+        Frags f0, f1;
+        read_tap(0, f0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MTW + 1, 0);
+#pragma unroll
+        for (int tap = 0; tap < 27; tap += 2) {
+            if (tap + 1 < 27) read_tap(tap + 1, f1);
+            mfma_tap(f0);
+            if (tap + 1 < 27) {
+#pragma unroll
+                for (int k = 0; k < MTW; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (k == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                if (tap + 2 < 27) read_tap(tap + 2, f0);
+                mfma_tap(f1);
+                if (tap + 2 < 27) {
+#pragma unroll
+                    for (int k = 0; k < MTW; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (k == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);
+            }
+        }
+        drain_and_sync();
+    }
+
+    // ---- partial tile -> slab[split][b][virtual voxel][N] (fp32).  Lane (r, hh) holds, for tile i, row 32 m + r and
+    // channels 8 j + 4 hh + (0..3) in accumulator registers 4 j .. 4 j + 3.
+    const int64_t Vv = (int64_t)g.Ev[0] * g.Ev[1] * g.Ev[2];
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+        const int row = (wave + 4 * i) * 32 + r;
+        if (row >= nrows) continue;
+        const int bl = row / per_sample, rem = row - bl * per_sample;
+        const int64_t vox = (int64_t)x0 * g.Ev[1] * g.Ev[2] + rem;  // x slabs are contiguous runs of virtual voxels
+        float* dst = slab + (((int64_t)split * g.B + b0 + bl) * Vv + vox) * g.N + n0 + 4 * hh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(dst + 8 * j) = make_float4(acc[i][4 * j], acc[i][4 * j + 1], acc[i][4 * j + 2], acc[i][4 * j + 3]);
+    }
+}
+
+// out[b, u, :] = sum over splits and over the virtual voxels v that map onto real voxel u of slab[split][b][v][:]
+//                (+ bias) (+ addend), as bf16.  fold == 0: v = u (forward).  fold == 1: the virtual grid is the padded
+//                grid and v ranges over the positions that clamp onto u (data gradient).  The result has N channels,
+//                split over out1 (channels [0, D1)) and out2.
+__global__ void __launch_bounds__(256)
+conv3_small_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias, bf16* __restrict__ out1, int D1,
+                          bf16* __restrict__ out2, const bf16* __restrict__ add1, const bf16* __restrict__ add2, int B, int X,
+                          int Y, int Z, int N, int nsplit, int fold) {
+    const int groups = N >> 3;
+    const int64_t total = (int64_t)B * X * Y * Z * groups;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int cg = (int)(idx % groups);
+    int64_t u = idx / groups;
+    const int uz = (int)(u % Z); int64_t t = u / Z;
+    const int uy = (int)(t % Y); t /= Y;
+    const int ux = (int)(t % X);
+    const int b = (int)(t / X);
+    const int E[3] = {X + 2 * fold, Y + 2 * fold, Z + 2 * fold}, c[3] = {ux, uy, uz}, R[3] = {X, Y, Z};
+    int lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = fold ? (c[a] == 0 ? 0 : c[a] + 1) : c[a];
+        hi[a] = fold ? (c[a] == R[a] - 1 ? R[a] + 1 : c[a] + 1) : c[a];
+    }
+    const int64_t Vv = (int64_t)E[0] * E[1] * E[2];
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[cg * 8 + j] : 0.f;
+    for (int s = 0; s < nsplit; ++s)
+        for (int v0 = lo[0]; v0 <= hi[0]; ++v0)
+            for (int v1 = lo[1]; v1 <= hi[1]; ++v1)
+                for (int v2 = lo[2]; v2 <= hi[2]; ++v2) {
+                    const float* p = slab + (((int64_t)s * B + b) * Vv + ((int64_t)v0 * E[1] + v1) * E[2] + v2) * N + cg * 8;
+                    const float4 a = *reinterpret_cast<const float4*>(p), bq = *reinterpret_cast<const float4*>(p + 4);
+                    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+                    acc[4] += bq.x; acc[5] += bq.y; acc[6] += bq.z; acc[7] += bq.w;
+                }
+    const int n = cg * 8;
+    const int64_t vox = idx / groups;
+    const bool first = n < D1;
+    bf16* dst = first ? out1 + vox * D1 + n : out2 + vox * (N - D1) + (n - D1);
+    const bf16* asrc = first ? (add1 ? add1 + vox * D1 + n : nullptr) : (add2 ? add2 + vox * (N - D1) + (n - D1) : nullptr);
+    Vec8<bf16> o;
+    if (asrc) {
+        o.load(asrc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] += acc[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+    }
+    o.store(dst);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static const bf16* small_zero_block(char* arena) { return reinterpret_cast<const bf16*>(arena); }  // first 64 B: zeros
+
+// Plan a launch; false if the small-grid kernel does not apply (grid too large, shapes, no arena, arena too small).
+static bool small_plan(SmallGeom& g, int B, int X, int Y, int Z, int K, int N, bool data_gradient, size_t arena_bytes,
+                       size_t& lds_bytes) {
+    static const int mode = getenv("TDX_CONV3_SMALL") ? atoi(getenv("TDX_CONV3_SMALL")) : 1;
+    if (mode == 0) return false;
+    if ((K % SM_KC) || (N % SM_BN) || K < 128) return false;
+    const int pad = data_gradient ? 1 : 0;
+    g.B = B;
+    g.Ev[0] = X + 2 * pad; g.Ev[1] = Y + 2 * pad; g.Ev[2] = Z + 2 * pad;
+    g.Es[0] = X; g.Es[1] = Y; g.Es[2] = Z;
+    g.off = pad; g.clamp = data_gradient ? 0 : 1;
+    g.K = K; g.N = N;
+    const int64_t rows_total = (int64_t)B * g.Ev[0] * g.Ev[1] * g.Ev[2];
+    // Where it pays (tools/conv_bench.py, B = 6, us per launch, against brick kernel [+ halo-shell kernel]):
+    //   12 x 4 x 3, 512 -> 512:    forward 33 vs 91;   data gradient 73 vs 141 + 55
+    //   24 x 8 x 6, 512 -> 512:    forward 154 vs 162; 1024 -> 256: 149 vs 181; 256 -> 512: 90 vs 85
+    //   24 x 8 x 6 data gradients: 183-353 vs 166-297 (the padded grid has 1.8x the rows there) -> brick kernels
+    // TDX_CONV3_SMALL_ROWS moves the row gate (tests, A/B runs; read per call).
+    const char* env_rows = getenv("TDX_CONV3_SMALL_ROWS");
+    const int max_total = env_rows ? atoi(env_rows) : 6000;
+    const bool deep_forward = !data_gradient && K >= 512 && rows_total <= 24000;
+    if (rows_total > max_total && !(deep_forward && !env_rows)) return false;
+    const int plane = g.Ev[1] * g.Ev[2], sample = g.Ev[0] * plane;
+    const int max_rows = SM_MAX_TILES * 32;
+    if (plane > max_rows) return false;
+    if (sample <= max_rows) {  // whole samples per group; prefer >= 2 groups so that two row groups share the weights' L2 lines
+        g.nbg = max(1, min(B, max_rows / sample));
+        if (g.nbg == B && B > 1) g.nbg = (B + 1) / 2;
+        g.xs = g.Ev[0]; g.gx = 1;
+    } else {
+        g.nbg = 1;
+        const int slabs = ceil_div(sample, max_rows);
+        g.xs = ceil_div(g.Ev[0], slabs);
+        g.gx = ceil_div(g.Ev[0], g.xs);
+    }
+    g.Ix = g.xs + 2; g.Iy = g.Ev[1] + 2; g.Iz = g.Ev[2] + 2;
+    const int img = g.Ix * g.Iy * g.Iz;
+    auto lds_for = [&](int nbg) { return (size_t)4 * (((size_t)nbg * img + 63) & ~(size_t)63) * 16 + (size_t)4 * (27 * SM_BN * 16 + 512); };
+    while (g.nbg > 1 && ((int64_t)g.nbg * img > 2048 || lds_for(g.nbg) > 160 * 1024)) --g.nbg;  // DMA plan: 4 x 8 x 64 entries
+    if ((int64_t)g.nbg * img > 2048) return false;
+    lds_bytes = lds_for(g.nbg);
+    if (lds_bytes > 160 * 1024) return false;
+    // K splits: aim at >= 256 workgroups, at least 2 slices per split, slabs inside the arena
+    const int ngroups = ceil_div(B, g.nbg) * g.gx, nslices = K / SM_KC;
+    const int64_t base = (int64_t)ngroups * (N / SM_BN);
+    int splits = (int)std::max<int64_t>(1, 256 / base);  // one workgroup per CU (LDS) and no second round of them
+    splits = std::min(splits, std::max(1, nslices / 2));
+    splits = std::min(splits, 16);
+    while (splits > 1 && (size_t)splits * rows_total * N * 4 + 64 > arena_bytes) --splits;
+    if ((size_t)splits * rows_total * N * 4 + 64 > arena_bytes) return false;
+    g.per_split = ceil_div(nslices, splits);
+    g.nsplit = ceil_div(nslices, g.per_split);
+    return true;
+}
+
+template <int MTW>
+static int small_go(const void* x1, int C1, const void* x2, int C2, const void* wp, float* slab, const bf16* zero16,
+                    const SmallGeom& g, size_t lds, hipStream_t st) {
+    auto kern = conv3_small_kernel<MTW>;
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr = lds;
+    }
+    const int ngroups = ceil_div(g.B, g.nbg) * g.gx;
+    hipLaunchKernelGGL(kern, dim3(ngroups, g.N / SM_BN, g.nsplit), dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2,
+                       (const bf16*)wp, slab, zero16, g);
+    return tdx_launch_status();
+}
+
+// Forward (data_gradient == false: y = conv3([x1 | x2]) + bias, N = Cout) or data gradient (x1 = dy with K = C1
+// channels, x2 unused; result N channels split over out1 [0, D1) / out2, plus addends).  Returns TDX_ESHAPE when the
+// launch is not a small-grid case (the caller then takes the brick kernels).
+int conv3_small_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* out1, int D1,
+                       void* out2, const void* add1, const void* add2, int B, int X, int Y, int Z, int N, bool data_gradient,
+                       hipStream_t st) {
+    char* arena = (char*)tdx_scratch_ptr();
+    if (arena == nullptr) return TDX_ESHAPE;
+    if ((C1 % SM_KC) || (C2 % SM_KC)) return TDX_ESHAPE;
+    SmallGeom g;
+    size_t lds = 0;
+    if (!small_plan(g, B, X, Y, Z, C1 + C2, N, data_gradient, tdx_scratch_bytes(), lds)) return TDX_ESHAPE;
+    float* slab = reinterpret_cast<float*>(arena + 64);
+    const int rows = g.nbg * g.xs * g.Ev[1] * g.Ev[2];
+    const int mtw = ceil_div(ceil_div(rows, 32), 4);
+    int rc;
+    const bf16* z16 = small_zero_block(arena);
+    switch (mtw) {
+        case 1: case 2: case 3: rc = small_go<3>(x1, C1, x2, C2, wp, slab, z16, g, lds, st); break;
+        case 4: rc = small_go<4>(x1, C1, x2, C2, wp, slab, z16, g, lds, st); break;
+        case 5: rc = small_go<5>(x1, C1, x2, C2, wp, slab, z16, g, lds, st); break;
+        case 6: rc = small_go<6>(x1, C1, x2, C2, wp, slab, z16, g, lds, st); break;
+        default: rc = small_go<7>(x1, C1, x2, C2, wp, slab, z16, g, lds, st); break;
+    }
+    if (rc != TDX_OK) return rc;
+    const int64_t total = (int64_t)B * X * Y * Z * (N / 8);
+    hipLaunchKernelGGL(conv3_small_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, slab, bias, (bf16*)out1, D1,
+                       (bf16*)out2, (const bf16*)add1, (const bf16*)add2, B, X, Y, Z, N, g.nsplit, data_gradient ? 1 : 0);
+    return tdx_launch_status();
+}

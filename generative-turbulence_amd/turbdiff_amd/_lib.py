@@ -27,6 +27,7 @@ _vp, _i, _i64, _u64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_f
 SIGNATURES = {
     "tdx_version": (_i, []),
     "tdx_arch": (C.c_char_p, []),
+    "tdx_set_scratch": (_i, [_vp, _sz]),
     "tdx_ncv_to_nvc": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _vp]),
     "tdx_nvc_to_ncv": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _vp]),
     "tdx_cast": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
@@ -100,6 +101,31 @@ def load() -> C.CDLL:
     return _lib
 
 
+_SCRATCH = {}  # device index -> arena tensor (kept alive for the life of the process); "active" -> registered index
+SCRATCH_BYTES = int(os.environ.get("TDX_SCRATCH_MB", "96")) << 20
+
+
+def ensure_scratch(device) -> None:
+    """Hand the library its scratch arena on `device` (tdx_set_scratch: K-split slabs of the small-grid conv kernel
+    on the deep U-Net levels).  One process drives one GPU; a process that touches several registers the arena of the
+    device it is launching on.  TDX_SCRATCH_MB=0: no arena (those layers then run on the brick kernels)."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if _SCRATCH.get("active") == idx:
+        return
+    if SCRATCH_BYTES <= 0:
+        load().tdx_set_scratch(None, 0)
+        _SCRATCH["active"] = idx
+        return
+    buf = _SCRATCH.get(idx)
+    if buf is None:
+        buf = _SCRATCH[idx] = torch.zeros(SCRATCH_BYTES, dtype=torch.uint8, device=torch.device("cuda", idx))
+    rc = load().tdx_set_scratch(buf.data_ptr(), buf.numel())
+    if rc != 0:
+        raise RuntimeError(f"tdx_set_scratch failed: {rc}")
+    _SCRATCH["active"] = idx
+
+
 def dtype_code(dt: torch.dtype) -> int:
     if dt == torch.float32:
         return F32
@@ -140,6 +166,8 @@ def ptr(t: torch.Tensor | None):
         raise RuntimeError("tdx kernels need device tensors (no CPU path exists in the product)")
     if not t.is_contiguous():
         raise RuntimeError("tdx kernels need contiguous tensors")
+    if _SCRATCH.get("active") != t.device.index:
+        ensure_scratch(t.device)
     return t.data_ptr()
 
 

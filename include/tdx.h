@@ -57,6 +57,13 @@ extern "C" {
 #define TDX_WS_CLEAN 0x100
 
 int tdx_version(void);
+/* Scratch arena for kernels that need transient device workspace their entry point has no argument for: the K-split
+ * slabs of the small-grid 3x3x3 conv (ddpm.py:164 on the 24x8x6 and 12x4x3 levels: several workgroups share an output
+ * tile's K range, fp32 partial tiles go through the arena, a reduce kernel finishes them).  The library never
+ * allocates: the caller hands over `bytes` (>= 1 MiB; 96 MiB covers the shipped model at B <= 8) of device memory
+ * whose first 64 bytes are zero, keeps it alive and otherwise untouched, and orders all tdx_conv3_* launches on one
+ * stream (or re-registers per stream).  Without an arena (ptr = NULL) those layers run on the brick kernels. */
+int tdx_set_scratch(void* ptr, size_t bytes);
 /* name of the gfx target the library was built for ("gfx950") */
 const char* tdx_arch(void);
 
