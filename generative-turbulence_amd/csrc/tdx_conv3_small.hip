@@ -55,7 +55,9 @@ conv3_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__
     const int r = lane & 31, hh = lane >> 5;
 
     // ---- this workgroup: row group (samples b0 .. b0 + nb, virtual planes x0 .. x0 + xs), channel tile, K split
-    const int group = blockIdx.x, n0 = blockIdx.y * SM_BN, split = blockIdx.z;
+    // blockIdx.x = channel tile (fastest), so that the workgroups an XCD receives (linear id mod 8) share 1/8 of the
+    // weights instead of every XCD's L2 streaming all of them; y = row group, z = K split
+    const int group = blockIdx.y, n0 = blockIdx.x * SM_BN, split = blockIdx.z;
     const int b0 = (group / g.gx) * g.nbg, x0 = (group % g.gx) * g.xs;
     const int nb = min(g.nbg, g.B - b0), xs = min(g.xs, g.Ev[0] - x0);
     const int per_sample = xs * g.Ev[1] * g.Ev[2];
@@ -349,7 +351,7 @@ static int small_go(const void* x1, int C1, const void* x2, int C2, const void* 
         attr = lds;
     }
     const int ngroups = ceil_div(g.B, g.nbg) * g.gx;
-    hipLaunchKernelGGL(kern, dim3(ngroups, g.N / SM_BN, g.nsplit), dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2,
+    hipLaunchKernelGGL(kern, dim3(g.N / SM_BN, ngroups, g.nsplit), dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2,
                        (const bf16*)wp, slab, zero16, g);
     return tdx_launch_status();
 }
