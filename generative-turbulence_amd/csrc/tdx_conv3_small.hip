@@ -55,8 +55,9 @@ conv3_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__
     const int r = lane & 31, hh = lane >> 5;
 
     // ---- this workgroup: row group (samples b0 .. b0 + nb, virtual planes x0 .. x0 + xs), channel tile, K split
-    // blockIdx.x = channel tile (fastest), so that the workgroups an XCD receives (linear id mod 8) share 1/8 of the
-    // weights instead of every XCD's L2 streaming all of them; y = row group, z = K split
+    // blockIdx.x = channel tile, y = row group, z = K split.  (An XCD-aware layout -- the low 3 bits of the block id
+    // enumerating (K split, channel-tile class), so that one XCD's L2 sees 3.5 instead of 21 MB at 24 x 8 x 6 -- was
+    // measured: no difference; the kernel is bound by its LDS fragment reads, 1.2 per MFMA at 32-wide channel tiles.)
     const int group = blockIdx.y, n0 = blockIdx.x * SM_BN, split = blockIdx.z;
     const int b0 = (group / g.gx) * g.nbg, x0 = (group % g.gx) * g.xs;
     const int nb = min(g.nbg, g.B - b0), xs = min(g.xs, g.Ev[0] - x0);
@@ -327,13 +328,20 @@ static bool small_plan(SmallGeom& g, int B, int X, int Y, int Z, int K, int N, b
     if ((int64_t)g.nbg * img > 2048) return false;
     lds_bytes = lds_for(g.nbg);
     if (lds_bytes > 160 * 1024) return false;
-    // K splits: aim at >= 256 workgroups, at least 2 slices per split, slabs inside the arena
+    // K splits.  One workgroup per CU (LDS), so a launch runs in rounds of 256 workgroups; a split count is judged by
+    // rounds x slices per workgroup (at ~3.5 us per slice) plus the slab round trip it causes (written and read once
+    // at ~5 TB/s), the smallest estimate wins: 12 x 4 x 3 forward 8 splits (1 round x 4 slices), 24 x 8 x 6 with 192
+    // tile-groups 4 splits (3 full rounds x 8 slices instead of 2 rounds, the second half empty, x 16)
     const int ngroups = ceil_div(B, g.nbg) * g.gx, nslices = K / SM_KC;
     const int64_t base = (int64_t)ngroups * (N / SM_BN);
-    int splits = (int)std::max<int64_t>(1, 256 / base);  // one workgroup per CU (LDS) and no second round of them
-    splits = std::min(splits, std::max(1, nslices / 2));
-    splits = std::min(splits, 16);
-    while (splits > 1 && (size_t)splits * rows_total * N * 4 + 64 > arena_bytes) --splits;
+    int splits = 1;
+    double best = 1e30;
+    for (int sp = 1; sp <= 16 && sp * 2 <= std::max(nslices, 2); ++sp) {
+        if ((size_t)sp * rows_total * N * 4 + 64 > arena_bytes) break;
+        const double rounds = (double)ceil_div(base * sp, 256), per = (double)ceil_div(nslices, sp);
+        const double est = rounds * per * 3.5e-6 + (sp > 1 ? 2.0 * sp * rows_total * N * 4 / 5e12 : rows_total * N * 8.0 / 5e12);
+        if (est < best * 0.97) { best = est; splits = sp; }
+    }
     if ((size_t)splits * rows_total * N * 4 + 64 > arena_bytes) return false;
     g.per_split = ceil_div(nslices, splits);
     g.nsplit = ceil_div(nslices, g.per_split);
