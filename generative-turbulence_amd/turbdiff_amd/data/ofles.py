@@ -55,6 +55,20 @@ class BoundaryCondition:
     type: "BoundaryCondition.Type"
     value: torch.Tensor | None = None
 
+    _H5_TYPES = {"fixed-value": "FIXED_VALUE", "zero-gradient": "ZERO_GRADIENT", "inlet-outlet": "INLET_OUTLET"}
+
+    @staticmethod
+    def from_h5(group) -> "BoundaryCondition":
+        """A ``boundary-conditions/<variable>/<boundary>`` group of a case file (ofles.py:68-84): attribute ``type``,
+        and a ``value`` dataset for fixed values (a scalar for scalar fields)."""
+        kind = group.attrs["type"]
+        kind = kind.decode() if isinstance(kind, bytes) else kind
+        name = BoundaryCondition._H5_TYPES.get(kind)
+        if name is None:
+            raise RuntimeError(f"Unknown boundary condition {group}")
+        t = BoundaryCondition.Type[name]
+        return BoundaryCondition(t, torch.tensor(np.array(group["value"])) if t is BoundaryCondition.Type.FIXED_VALUE else None)
+
 
 def split_channels(x: torch.Tensor, variables, *, dim=-4):
     """ofles.py:87-97."""
@@ -198,16 +212,157 @@ class OpenFOAMBatch:
 
 
 # ---------------------------------------------------------------------------------------------------------
-# Dataset and samplers (ofles.py:424-540).  The repository is any object with `times` (one array of sample
-# times per case file), `n_cases` and `read(file_idx, steps) -> OpenFOAMData`; the reference's HDF5-backed
-# OpenFOAMDataRepository (ofles.py:312-421) satisfies it, and so does InMemoryRepository below.  h5py is not
-# part of this package's requirements, so no file reader is provided.
+# Repository, dataset, samplers and data module (ofles.py:312-643).  A repository is any object with `times` (one array
+# of sample times per case file), `n_cases` and `read(file_idx, steps) -> OpenFOAMData`: OpenFOAMDataRepository reads the
+# data.h5 case files through h5py's File interface (h5py itself is imported on first use: the build image has none, the
+# tests drive the reader through an in-memory stand-in and pin it against the reference's reader run on the same
+# stand-in), InMemoryRepository holds cases in memory.
 import math
 import random
 
 
 def _chunked(seq, n):
     return [seq[i:i + n] for i in range(0, len(seq), n)]
+
+
+@dataclass
+class ChannelHole:
+    """ofles.py:100-103."""
+
+    pos: np.ndarray
+    size: np.ndarray
+
+
+def _open_h5(path, mode="r"):
+    try:
+        import h5py
+    except ImportError as e:  # the build image has no h5py; the reader itself only needs its File / Group interface
+        raise ImportError("reading data.h5 case files needs h5py (pip install h5py), or pass opener= to "
+                          "OpenFOAMDataRepository") from e
+    return h5py.File(path, mode)
+
+
+class OpenFOAMDataRepository:
+    """The case files' reader (reference ofles.py:320-421): ``times`` per file, ``read(file_idx, samples)`` ->
+    ``OpenFOAMData``.  File layout (scripts/foam2h5.py:165-191, scripts/grid-embedding.py:74-90):
+    ``data/{times, u, p, k, nut}`` with fields (T, n_cells[, 3]) fp32, ``grid/{cell_counts, cell_idx, boundaries/<name>}``
+    (+ attribute ``type``), ``geometry/{bounding_box, cell_counts, holes/{positions, sizes}}``, ``physical`` (attribute
+    ``nu``), ``boundary-conditions/<variable>/<boundary>``.  ``opener(path, mode)`` returns a context manager yielding
+    an object with h5py's File interface (default: ``h5py.File``)."""
+
+    def __init__(self, files, variables, opener=None):
+        self.files, self.variables = list(files), tuple(variables)
+        self._open = opener or _open_h5
+        self.reset_caches()
+
+    def reset_caches(self):
+        self._metadata, self._times = {}, None
+
+    @property
+    def n_cases(self):
+        return len(self.files)
+
+    @property
+    def times(self):
+        if self._times is None:
+            self._times = []
+            for path in self.files:
+                with self._open(path, "r") as f:
+                    self._times.append(np.array(f["data/times"]).copy())
+        return self._times
+
+    def read_metadata(self, file_idx: int) -> OpenFOAMMetadata:
+        meta = self._metadata.get(file_idx)  # geometry is read once per file (the reference memoises the method)
+        if meta is not None:
+            return meta
+        with self._open(self.files[file_idx], "r") as f:
+            geo, grid = f["geometry"], f["grid"]
+            h = torch.tensor(np.array(geo["bounding_box"])) / torch.tensor(np.array(geo["cell_counts"]))
+            positions, sizes = np.array(geo["holes/positions"]).copy(), np.array(geo["holes/sizes"]).copy()
+            boundaries = {}
+            for name in grid["boundaries"].keys():
+                ds = grid["boundaries"][name]
+                boundaries[name] = {"type": ds.attrs["type"], "idx": torch.tensor(np.array(ds))}
+            conditions = {Variable.from_str(var): {b: BoundaryCondition.from_h5(g) for b, g in per_boundary.items()}
+                          for var, per_boundary in f["boundary-conditions"].items()}
+            meta = OpenFOAMMetadata(cell_counts=np.array(grid["cell_counts"]).copy(), cell_idx=torch.tensor(np.array(grid["cell_idx"])),
+                                    boundaries=boundaries, boundary_conditions=conditions, file=self.files[file_idx],
+                                    nu=f["physical"].attrs["nu"], h=h,
+                                    holes=[ChannelHole(p, s) for p, s in zip(positions, sizes)])
+        self._metadata[file_idx] = meta
+        return meta
+
+    def read_data(self, file_idx: int, sample_idxs) -> dict:
+        """{variable: (len(sample_idxs), n_cells, dims)}: HDF5 wants increasing unique row indices, so the rows are
+        read once in sorted order and spread back to the request's order (duplicates included)."""
+        want = np.asarray(sample_idxs)
+        rows, back = np.unique(want, return_inverse=True)
+        out = {}
+        with self._open(self.files[file_idx], "r") as f:
+            fields = f["data"]
+            for v in self.variables:
+                block = torch.tensor(np.array(fields[v.name.lower()][rows]))
+                if block.ndim == 2:  # scalar field: (T, n_cells) -> (T, n_cells, 1)
+                    block = block.unsqueeze(-1)
+                out[v] = block[back]
+        return out
+
+    def read(self, file_idx: int, samples) -> OpenFOAMData:
+        return OpenFOAMData(self.read_metadata(file_idx), torch.tensor(self.times[file_idx][samples]), self.read_data(file_idx, samples))
+
+
+def find_data_files(cases_root: Path, exists=None):
+    """``<cases_root>/<case>/data.h5`` of every case directory, without walking the case directories (ofles.py:548-551)."""
+    exists = exists or (lambda p: p.is_file())
+    return [p for d in sorted(Path(cases_root).iterdir()) if exists(p := d / "data.h5")]
+
+
+def reset_dataset_caches(worker_id):
+    info = torch.utils.data.get_worker_info()
+    if info is not None:
+        info.dataset.reset_caches()
+
+
+class OpenFOAMDataModule:
+    """ofles.py:564-643 without Lightning: ``setup(stage)`` loads ``<root>/stats.pickle`` and builds the datasets of
+    ``<root>/{train,val,test}``; the three loaders are ``DataLoader(dataset, sampler=..., batch_size=None)`` with the
+    reference's samplers.  ``rank`` / ``world_size`` / ``seed`` shard the training batches for data-parallel runs (every
+    rank the same number of whole single-geometry batches)."""
+
+    def __init__(self, root: Path, discard_first_seconds: float, num_workers: int = 2, batch_size: int = 1,
+                 eval_batch_size: int = 8, val_samples: int = 8, test_samples: int = 32, pin_memory: bool = True,
+                 variables=tuple(Variable), *, rank: int = 0, world_size: int = 1, seed=None, opener=None, list_cases=None):
+        self.root, self.discard_first_seconds, self.num_workers = Path(root), discard_first_seconds, num_workers
+        self.batch_size, self.eval_batch_size = batch_size, eval_batch_size
+        self.val_samples, self.test_samples, self.pin_memory, self.variables = val_samples, test_samples, pin_memory, tuple(variables)
+        self.rank, self.world_size, self.seed = rank, world_size, seed
+        self._opener, self._list_cases = opener, list_cases or find_data_files
+        self.train_dataset = self.val_dataset = self.test_dataset = None
+        self.stats = None
+
+    def setup(self, stage: str, stats=None):
+        self.stats = stats if stats is not None else OpenFOAMStats.from_file(self.root / "stats.pickle")
+        wanted = {"fit": ("train", "val"), "validate": ("val",), "test": ("test",)}.get(stage, ())
+        for phase in wanted:
+            if getattr(self, f"{phase}_dataset") is None:
+                repo = OpenFOAMDataRepository(self._list_cases(self.root / phase), self.variables, opener=self._opener)
+                setattr(self, f"{phase}_dataset", OpenFOAMDataset(repo, self.stats, self.discard_first_seconds))
+
+    def _loader(self, dataset, sampler):
+        return torch.utils.data.DataLoader(dataset, sampler=sampler, worker_init_fn=reset_dataset_caches, batch_size=None,
+                                           num_workers=self.num_workers, pin_memory=self.pin_memory)
+
+    def train_dataloader(self):
+        return self._loader(self.train_dataset, OpenFOAMSampler(self.train_dataset, batch_size=self.batch_size, shuffle=True,
+                                                                rank=self.rank, world_size=self.world_size, seed=self.seed))
+
+    def val_dataloader(self):
+        return self._loader(self.val_dataset, OpenFOAMEvaluationSampler(self.val_dataset, batch_size=self.eval_batch_size,
+                                                                        samples_per_file=self.val_samples))
+
+    def test_dataloader(self):
+        return self._loader(self.test_dataset, OpenFOAMEvaluationSampler(self.test_dataset, batch_size=self.eval_batch_size,
+                                                                         samples_per_file=self.test_samples))
 
 
 class InMemoryRepository:

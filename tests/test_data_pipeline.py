@@ -223,3 +223,76 @@ def test_eval_ckpt_flow_on_in_memory_cases(tmp_path):
     out = subprocess.run([sys.executable, str(ROOT / "tools" / "eval_ckpt.py"), str(tmp_path / "model.ckpt"), str(tmp_path / "cli.npz"),
                           "--synthetic", "1", "--start-from", "2", "model.eval_batch_size=2"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "val/log_tke_l2:" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+# --------------------------------------------------------------------------- the case-file reader (§8 f2)
+
+
+def test_repository_reads_case_files_like_the_reference():
+    """OpenFOAMDataRepository through h5py's File interface (tests/h5fake.py stands in for h5py, which the image
+    lacks) against the reference's own reader run on the same trees (tests/golden/make_golden_repository.py): times,
+    every metadata field, and reads of unsorted index lists with duplicates."""
+    import h5fake
+    from turbdiff_amd.data.ofles import OpenFOAMDataRepository
+
+    z = np.load(GOLDEN / "repository.npz")
+    files = h5fake.install_cases()
+    requests = [[5, 2, 2, 7], [0], [10, 9, 8, 0, 10], [3, 4, 5]]
+    for phase, paths in files.items():
+        repo = OpenFOAMDataRepository(paths, (Variable.U, Variable.P, Variable.NUT), opener=h5fake.File)
+        assert repo.n_cases == len(paths)
+        for i in range(repo.n_cases):
+            k = f"{phase}/{i}"
+            assert np.array_equal(repo.times[i], z[f"{k}/times"])
+            m = repo.read_metadata(i)
+            assert repo.read_metadata(i) is m, "geometry must be read once per file"
+            assert np.array_equal(m.cell_counts, z[f"{k}/cell_counts"]) and np.array_equal(m.cell_idx.numpy(), z[f"{k}/cell_idx"])
+            assert np.array_equal(m.h.numpy(), z[f"{k}/h"]) and m.nu == float(z[f"{k}/nu"]) and m.case_name == str(z[f"{k}/case_name"])
+            assert np.array_equal(np.stack([np.concatenate((h.pos, h.size)) for h in m.holes]), z[f"{k}/holes"])
+            assert sorted(m.boundaries) == sorted(n.split("/")[3] for n in z.files if n.startswith(f"{k}/boundary/") and n.endswith("/idx"))
+            for name, desc in m.boundaries.items():
+                assert np.array_equal(desc["idx"].numpy(), z[f"{k}/boundary/{name}/idx"]) and desc["type"] == str(z[f"{k}/boundary/{name}/type"])
+            for var, per in m.boundary_conditions.items():
+                for bname, bc in per.items():
+                    assert bc.type.name == str(z[f"{k}/bc/{var.name}/{bname}/type"])
+                    if bc.value is not None:
+                        assert np.array_equal(bc.value.numpy(), z[f"{k}/bc/{var.name}/{bname}/value"])
+            for r, req in enumerate(requests):
+                data = repo.read(i, req)
+                assert np.array_equal(data.t.numpy(), z[f"{k}/read/{r}/t"])
+                assert [v.name for v in data.samples] == ["U", "P", "NUT"]
+                for v, x in data.samples.items():
+                    assert x.dtype == torch.float32 and np.array_equal(x.numpy(), z[f"{k}/read/{r}/{v.name}"])
+
+
+def test_data_module_builds_datasets_and_loaders():
+    """OpenFOAMDataModule (ofles.py:564-643 without Lightning) on the stand-in case files: datasets per phase, the
+    reference's samplers behind batch_size=None loaders, batches of one geometry each, sharded training batches."""
+    import h5fake
+    from turbdiff_amd.data.ofles import OpenFOAMDataModule
+
+    files = h5fake.install_cases(root_dir="/fake2", phases=("train", "val", "test"), per_phase=2)
+    stats = OpenFOAMStats({"u": {"mean": torch.zeros(3), "std": torch.ones(3)}, "p": {"mean": torch.tensor(0.0), "std": torch.tensor(1.0)}})
+    listing = lambda d: files[Path(d).name]
+    dm = OpenFOAMDataModule("/fake2", discard_first_seconds=0.1, num_workers=0, batch_size=3, eval_batch_size=2, val_samples=4,
+                            test_samples=3, pin_memory=False, variables=(Variable.U, Variable.P), opener=h5fake.File, list_cases=listing)
+    dm.setup("fit", stats=stats)
+    assert dm.train_dataset is not None and dm.val_dataset is not None and dm.test_dataset is None
+    random.seed(0)
+    batches = list(dm.train_dataloader())
+    assert len(batches) == len(dm.train_dataloader().sampler) and all(isinstance(b, OpenFOAMBatch) for b in batches)
+    for b in batches:
+        assert b.data.samples[Variable.U].shape[1:] == (b.data.metadata.n_cells, 3) and b.data.n_samples <= 3
+        assert float(b.data.t.min()) > 0.1  # discard_first_seconds
+    val = list(dm.val_dataloader())
+    assert sum(b.data.n_samples for b in val) == 2 * 4 and all(b.data.n_samples <= 2 for b in val)
+    dm.setup("test", stats=stats)
+    assert sum(b.data.n_samples for b in dm.test_dataloader()) == 2 * 3
+    # two ranks draw disjoint halves of one seeded shuffle, in lock step
+    shards = []
+    for r in range(2):
+        d2 = OpenFOAMDataModule("/fake2", 0.1, num_workers=0, batch_size=3, pin_memory=False, variables=(Variable.U, Variable.P),
+                                opener=h5fake.File, list_cases=listing, rank=r, world_size=2, seed=7)
+        d2.setup("fit", stats=stats)
+        shards.append([tuple(np.round(b.data.t.numpy(), 4)) + (b.data.metadata.case_name,) for b in d2.train_dataloader()])
+    assert len(shards[0]) == len(shards[1]) and not set(shards[0]) & set(shards[1])
