@@ -47,11 +47,12 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
                       void* d1 = nullptr, int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr,
                       const void* a2 = nullptr, const Conv3Ext* ext = nullptr);
 
-// small-grid bf16 conv (tdx_conv3_small.hip): forward or data gradient (then x1 = dy, result split over out1 / out2 with
-// addends, halo fold included); TDX_ESHAPE = not a small-grid case, take the brick kernels.  Needs the scratch arena.
+// small-grid conv (tdx_conv3_small.hip; bf16 tensors, or fp32 tensors with split-precision products when split): forward
+// or data gradient (then x1 = dy, result split over out1 / out2 with addends, halo fold included); TDX_ESHAPE = not a
+// small-grid case, take the brick kernels.  Needs the scratch arena.
 int conv3_small_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* out1, int D1,
                        void* out2, const void* add1, const void* add2, int B, int X, int Y, int Z, int N, bool data_gradient,
-                       hipStream_t st);
+                       bool split, hipStream_t st);
 // the caller-provided scratch arena (tdx_set_scratch, include/tdx.h); nullptr if none
 void* tdx_scratch_ptr();
 size_t tdx_scratch_bytes();

@@ -458,6 +458,9 @@ extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, con
     if (dtype == TDX_F32 && impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(C1 + C2, 0, Cout)) {
         // the operand was packed as split images (layout is a function of (K, N)); both inputs must be sliceable
         if (!conv3_mfma_split_supported(C1, C2, Cout)) return TDX_ESHAPE;
+        int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false, true,
+                                    as_stream(stream));
+        if (rs != TDX_ESHAPE) return rs;
         return conv3_mfma_split_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));
     }
     if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT && conv3_mfma_f32_supported(C1, C2, Cout))
@@ -467,7 +470,7 @@ extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, con
         if (!mfma_ok(dtype, C1, C2, Cout)) return TDX_ESHAPE;
         // deep U-Net levels: the small-grid kernel (packed M tiles, split K); TDX_ESHAPE = not such a case
         int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false,
-                                    as_stream(stream));
+                                    false, as_stream(stream));
         if (rs != TDX_ESHAPE) return rs;
         return conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));
     }
@@ -488,6 +491,11 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     if (f32_split || f32_mfma) {  // fp32 tensors: the MFMA kernels accumulate the moments in their store loop too
         if (f32_split && !conv3_mfma_split_supported(C1, C2, Cout)) return TDX_ESHAPE;
         hipStream_t st = as_stream(stream);
+        if (f32_split) {  // deep U-Net levels: small-grid conv, then the statistics pass over its (tiny) result
+            int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false, true, st);
+            if (rs == TDX_OK) return tdx_gn_stats(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, stream);
+            if (rs != TDX_ESHAPE) return rs;
+        }
         double* acc = (double*)gn_workspace;
         if (!clean) {
             hipError_t e = hipMemsetAsync(acc, 0, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
@@ -507,7 +515,7 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     if (!mfma_ok(dtype, C1, C2, Cout)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
     hipStream_t st = as_stream(stream);
     {   // deep U-Net levels: small-grid conv, then the statistics pass over its (tiny) result
-        int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false, st);
+        int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false, false, st);
         if (rs == TDX_OK) return tdx_gn_stats(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, stream);
         if (rs != TDX_ESHAPE) return rs;
     }
@@ -570,7 +578,7 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
     if (use_mfma) {
         if (!mfma_ok(dtype, Cout, 0, Cin)) return TDX_ESHAPE;
         // deep U-Net levels: adjoint on the padded grid by the small-grid kernel, halo fold in its reduce pass
-        rc = conv3_small_launch(dy, Cout, nullptr, 0, wb, nullptr, dx1, C1, dx2, add1, add2, B, X, Y, Z, Cin, true, st);
+        rc = conv3_small_launch(dy, Cout, nullptr, 0, wb, nullptr, dx1, C1, dx2, add1, add2, B, X, Y, Z, Cin, true, false, st);
         if (rc != TDX_ESHAPE) return rc;
         rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2);
         if (rc != TDX_OK) return rc;
@@ -578,6 +586,10 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
     } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT &&
                ((impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin)) || conv3_mfma_f32_supported(Cout, 0, Cin))) {
         const bool split = impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin);
+        if (split) {
+            rc = conv3_small_launch(dy, Cout, nullptr, 0, wb, nullptr, dx1, C1, dx2, add1, add2, B, X, Y, Z, Cin, true, true, st);
+            if (rc != TDX_ESHAPE) return rc;
+        }
         rc = split ? conv3_mfma_split_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2,
                                              add1, add2)
                    : conv3_mfma_f32_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2,

@@ -46,13 +46,21 @@ struct SmallGeom {
     int nsplit;
 };
 
-template <int MTW>
+// SPLIT = false: bf16 tensors.  SPLIT = true: fp32 tensors with split-precision products (every operand as bf16 hi + lo,
+// x w ~ xh wh + xl wh + xh wl, as tdx_conv3_mfma_split.hip): the image is staged as raw fp32 (four 16-B quarter planes of
+// 4 channels) and split into hi / lo when a fragment is read; the weights arrive pre-split ([2 parts][K/16][27][N][16]
+// bf16, lo_offset elements apart).  fp32 images and two weight parts do not fit twice: that mode is single-buffered.
+template <int MTW, bool SPLIT>
 __global__ void __launch_bounds__(256, 1)
-conv3_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2, const bf16* __restrict__ wp,
-                   float* __restrict__ slab, const bf16* __restrict__ zero16, SmallGeom g) {
+conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict__ x2_, int C2, const bf16* __restrict__ wp,
+                   float* __restrict__ slab, const void* __restrict__ zero16, SmallGeom g, int64_t lo_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
+    constexpr int NPL = SPLIT ? 4 : 2;            // 16-B planes per image entry (8 bf16 / 4 fp32 channels each)
+    constexpr int NBUF = SPLIT ? 1 : 2;           // LDS buffers of image and weights
+    constexpr int WPARTS = SPLIT ? 2 : 1;         // weight images: hi, lo
+    constexpr int ESZ = SPLIT ? 4 : 2;            // bytes per source element
 
     // ---- this workgroup: row group (samples b0 .. b0 + nb, virtual planes x0 .. x0 + xs), channel tile, K split
     // blockIdx.x = channel tile, y = row group, z = K split.  (An XCD-aware layout -- the low 3 bits of the block id
@@ -65,10 +73,12 @@ conv3_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__
     const int nrows = nb * per_sample;
     const int img = g.Ix * g.Iy * g.Iz;           // entries per sample image
     const int entries = nb * img;
-    const int IMG_HALF = ((g.nbg * img + 63) & ~63) * 16;  // bytes of one half-plane: a full group, in whole 1-KiB DMA pieces
+    const int IMG_HALF = ((g.nbg * img + 63) & ~63) * 16;  // bytes of one plane: a full group, in whole 1-KiB DMA pieces
     constexpr int W_HALF = 27 * SM_BN * 16;       // 13824 B
-    unsigned char* sImg = smem;                   // [2 buffers][2 halves][IMG_HALF]
-    unsigned char* sW = smem + 4 * IMG_HALF;      // [2 buffers][2 halves][W_HALF]
+    unsigned char* sImg = smem;                   // [NBUF][NPL planes][IMG_HALF]
+    unsigned char* sW = smem + NBUF * NPL * IMG_HALF;  // [NBUF][WPARTS][2 halves][W_HALF + 512]
+    const unsigned char* x1 = reinterpret_cast<const unsigned char*>(x1_);
+    const unsigned char* x2 = reinterpret_cast<const unsigned char*>(x2_);
 
     // ---- DMA plan of the image: pieces of 64 consecutive entries of one half; lane l of piece p fills entry 64 p + l.
     // The source voxel of an entry does not depend on the slice: computed once (-1: zero fill, or beyond the image).
@@ -97,32 +107,32 @@ conv3_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__
     const int npieces = (entries + 63) >> 6;
     auto dma_slice = [&](int c, int buf) {
         const int k0 = c * SM_KC;
-        const bf16* xs_;
+        const unsigned char* xs_;
         int Cs, kk;
         if (k0 < C1) { xs_ = x1; Cs = C1; kk = k0; } else { xs_ = x2; Cs = C2; kk = k0 - C1; }
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
             for (int j = 0; j < MAXP; ++j) {
                 const int p = wave + 4 * j;
                 if (p < npieces) {
-                    const bf16* src = src_vox[j] >= 0 ? xs_ + (int64_t)src_vox[j] * Cs + kk + half * 8 : zero16;
-                    unsigned char* dst = sImg + (buf * 2 + half) * IMG_HALF + p * 1024;
+                    const void* src = src_vox[j] >= 0 ? (const void*)(xs_ + ((int64_t)src_vox[j] * Cs + kk) * ESZ + pl * 16) : zero16;
+                    unsigned char* dst = sImg + (buf * NPL + pl) * IMG_HALF + p * 1024;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
                 }
             }
-        // weights of the slice: LDS image [half][row = tap * 32 + n] of 16-B entries, 864 rows per half = 13.5 DMA pieces
-        // of 64 rows -> 14 pieces per half (the last one half full: its upper lanes re-read the last row into slack)
+        // weights of the slice: LDS image [part][half][row = tap * 32 + n] of 16-B entries, 864 rows per half = 13.5 DMA
+        // pieces of 64 rows -> 14 pieces per half (the last one half full: its upper lanes re-read the last row into slack)
 #pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            const int q = wave + 4 * j;           // 0..27: piece index over both halves (14 each)
-            if (q < 28) {
-                const int half = q / 14, row = (q % 14) * 64 + lane;  // row = tap * 32 + n
-                const int rr = min(row, 27 * SM_BN - 1);               // the last piece is half full: harmless re-read
+        for (int j = 0; j < 7 * WPARTS; ++j) {
+            const int q = wave + 4 * j;           // piece index over parts x halves (14 each)
+            if (q < 28 * WPARTS) {
+                const int part = q / 28, half = (q % 28) / 14, row = (q % 14) * 64 + lane;  // row = tap * 32 + n
+                const int rr = min(row, 27 * SM_BN - 1);
                 const int tap = rr >> 5, n = rr & 31;
-                const bf16* src = wp + ((int64_t)(c * 27 + tap) * g.N + n0 + n) * SM_KC + half * 8;
-                unsigned char* dst = sW + (buf * 2 + half) * (W_HALF + 512) + (q % 14) * 1024;
+                const bf16* src = wp + part * lo_offset + ((int64_t)(c * 27 + tap) * g.N + n0 + n) * SM_KC + half * 8;
+                unsigned char* dst = sW + ((buf * WPARTS + part) * 2 + half) * (W_HALF + 512) + (q % 14) * 1024;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             }
@@ -143,7 +153,7 @@ conv3_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__
         } else {
             ent = g.Iy * g.Iz + g.Iz + 1;  // any entry with a full neighbourhood inside the image
         }
-        a_ent[i] = ent * 16 + hh * IMG_HALF;
+        a_ent[i] = ent * 16 + hh * (SPLIT ? 2 : 1) * IMG_HALF;  // split: this lane's 8 channels = planes 2 hh and 2 hh + 1
     }
     const int w_off = hh * (W_HALF + 512) + r * 16;
 
@@ -158,56 +168,87 @@ conv3_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
+    // 8 fp32 -> 8 bf16 hi and 8 bf16 lo
+    auto split8 = [](const float4& a, const float4& b, bf16x8& hi, bf16x8& lo) {
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+            l[i] = pack_bf16x2(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+        }
+        const uint4 uh = make_uint4(h[0], h[1], h[2], h[3]), ul = make_uint4(l[0], l[1], l[2], l[3]);
+        hi = *reinterpret_cast<const bf16x8*>(&uh);
+        lo = *reinterpret_cast<const bf16x8*>(&ul);
+    };
     if (c_first < c_end) dma_slice(c_first, 0);
     drain_and_sync();
     for (int c = c_first; c < c_end; ++c) {
-        const int buf = (c - c_first) & 1;
-        if (c + 1 < c_end) dma_slice(c + 1, buf ^ 1);  // lands while this slice's taps run (buffer last read one slice ago)
-        const unsigned char* A = sImg + buf * 2 * IMG_HALF;
-        const unsigned char* W = sW + buf * 2 * (W_HALF + 512) + w_off;
-        // fragments of tap t + 1 are read while the MTW MFMAs of tap t issue (two register sets, pinned with
+        const int buf = SPLIT ? 0 : ((c - c_first) & 1);
+        if (!SPLIT && c + 1 < c_end) dma_slice(c + 1, buf ^ 1);  // lands while this slice's taps run (buffer last read one slice ago)
+        const unsigned char* A = sImg + buf * NPL * IMG_HALF;
+        const unsigned char* W = sW + buf * WPARTS * 2 * (W_HALF + 512) + w_off;
+        // fragments of tap t + 1 are read while the MFMAs of tap t issue (two register sets, pinned with
         // sched_group_barrier): one wave per SIMD has nothing else to hide an LDS round trip behind
-        struct Frags { bf16x8 w, x[MTW]; };
+        struct Frags { bf16x8 w, wl, x[MTW]; float4 xa[SPLIT ? MTW : 1], xb[SPLIT ? MTW : 1]; };
         auto read_tap = [&](int tap, Frags& f) {
             const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
             const int toff = ((ex * g.Iy + ey) * g.Iz + ez) * 16;
             f.w = *reinterpret_cast<const bf16x8*>(W + tap * (SM_BN * 16));
+            if (SPLIT) f.wl = *reinterpret_cast<const bf16x8*>(W + 2 * (W_HALF + 512) + tap * (SM_BN * 16));
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) f.x[i] = *reinterpret_cast<const bf16x8*>(A + a_ent[i] + toff);
+            for (int i = 0; i < MTW; ++i) {
+                if (SPLIT) {
+                    f.xa[SPLIT ? i : 0] = *reinterpret_cast<const float4*>(A + a_ent[i] + toff);
+                    f.xb[SPLIT ? i : 0] = *reinterpret_cast<const float4*>(A + a_ent[i] + toff + IMG_HALF);
+                } else {
+                    f.x[i] = *reinterpret_cast<const bf16x8*>(A + a_ent[i] + toff);
+                }
+            }
         };
         auto mfma_tap = [&](const Frags& f) {
 #pragma unroll
-            for (int i = 0; i < MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w, f.x[i], acc[i], 0, 0, 0);
+            for (int i = 0; i < MTW; ++i) {
+                if (SPLIT) {
+                    bf16x8 xh, xl;
+                    split8(f.xa[SPLIT ? i : 0], f.xb[SPLIT ? i : 0], xh, xl);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w, xh, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w, xl, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wl, xh, acc[i], 0, 0, 0);
+                } else {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w, f.x[i], acc[i], 0, 0, 0);
+                }
+            }
         };
+        constexpr int NRD = SPLIT ? 2 * MTW + 2 : MTW + 1;  // ds_read_b128 per tap
+        constexpr int NMF = SPLIT ? 3 * MTW : MTW;          // MFMAs per tap
         Frags f0, f1;
         read_tap(0, f0);
-        __builtin_amdgcn_sched_group_barrier(0x100, MTW + 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
 #pragma unroll
         for (int tap = 0; tap < 27; tap += 2) {
             if (tap + 1 < 27) read_tap(tap + 1, f1);
             mfma_tap(f0);
             if (tap + 1 < 27) {
-#pragma unroll
-                for (int k = 0; k < MTW; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (k == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
                 if (tap + 2 < 27) read_tap(tap + 2, f0);
                 mfma_tap(f1);
                 if (tap + 2 < 27) {
-#pragma unroll
-                    for (int k = 0; k < MTW; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (k == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
                 } else {
-                    __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
                 }
             } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, MTW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
             }
+        }
+        if (SPLIT) {  // single-buffered: the next slice is copied only after every wave is done with this one
+            __syncthreads();
+            if (c + 1 < c_end) dma_slice(c + 1, 0);
         }
         drain_and_sync();
     }
@@ -229,12 +270,13 @@ conv3_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__
 }
 
 // out[b, u, :] = sum over splits and over the virtual voxels v that map onto real voxel u of slab[split][b][v][:]
-//                (+ bias) (+ addend), as bf16.  fold == 0: v = u (forward).  fold == 1: the virtual grid is the padded
+//                (+ bias) (+ addend), as T.  fold == 0: v = u (forward).  fold == 1: the virtual grid is the padded
 //                grid and v ranges over the positions that clamp onto u (data gradient).  The result has N channels,
 //                split over out1 (channels [0, D1)) and out2.
+template <typename T>
 __global__ void __launch_bounds__(256)
-conv3_small_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias, bf16* __restrict__ out1, int D1,
-                          bf16* __restrict__ out2, const bf16* __restrict__ add1, const bf16* __restrict__ add2, int B, int X,
+conv3_small_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias, T* __restrict__ out1, int D1,
+                          T* __restrict__ out2, const T* __restrict__ add1, const T* __restrict__ add2, int B, int X,
                           int Y, int Z, int N, int nsplit, int fold) {
     const int groups = N >> 3;
     const int64_t total = (int64_t)B * X * Y * Z * groups;
@@ -269,9 +311,9 @@ conv3_small_reduce_kernel(const float* __restrict__ slab, const float* __restric
     const int n = cg * 8;
     const int64_t vox = idx / groups;
     const bool first = n < D1;
-    bf16* dst = first ? out1 + vox * D1 + n : out2 + vox * (N - D1) + (n - D1);
-    const bf16* asrc = first ? (add1 ? add1 + vox * D1 + n : nullptr) : (add2 ? add2 + vox * (N - D1) + (n - D1) : nullptr);
-    Vec8<bf16> o;
+    T* dst = first ? out1 + vox * D1 + n : out2 + vox * (N - D1) + (n - D1);
+    const T* asrc = first ? (add1 ? add1 + vox * D1 + n : nullptr) : (add2 ? add2 + vox * (N - D1) + (n - D1) : nullptr);
+    Vec8<T> o;
     if (asrc) {
         o.load(asrc);
 #pragma unroll
@@ -284,11 +326,9 @@ conv3_small_reduce_kernel(const float* __restrict__ slab, const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static const bf16* small_zero_block(char* arena) { return reinterpret_cast<const bf16*>(arena); }  // first 64 B: zeros
-
 // Plan a launch; false if the small-grid kernel does not apply (grid too large, shapes, no arena, arena too small).
-static bool small_plan(SmallGeom& g, int B, int X, int Y, int Z, int K, int N, bool data_gradient, size_t arena_bytes,
-                       size_t& lds_bytes) {
+static bool small_plan(SmallGeom& g, int B, int X, int Y, int Z, int K, int N, bool data_gradient, bool split,
+                       size_t arena_bytes, size_t& lds_bytes) {
     static const int mode = getenv("TDX_CONV3_SMALL") ? atoi(getenv("TDX_CONV3_SMALL")) : 1;
     if (mode == 0) return false;
     if ((K % SM_KC) || (N % SM_BN) || K < 128) return false;
@@ -339,7 +379,7 @@ static bool small_plan(SmallGeom& g, int B, int X, int Y, int Z, int K, int N, b
     for (int sp = 1; sp <= 16 && sp * 2 <= std::max(nslices, 2); ++sp) {
         if ((size_t)sp * rows_total * N * 4 + 64 > arena_bytes) break;
         const double rounds = (double)ceil_div(base * sp, 256), per = (double)ceil_div(nslices, sp);
-        const double est = rounds * per * 3.5e-6 + (sp > 1 ? 2.0 * sp * rows_total * N * 4 / 5e12 : rows_total * N * 8.0 / 5e12);
+        const double est = rounds * per * (split ? 9e-6 : 3.5e-6) + (sp > 1 ? 2.0 * sp * rows_total * N * 4 / 5e12 : rows_total * N * 8.0 / 5e12);
         if (est < best * 0.97) { best = est; splits = sp; }
     }
     if ((size_t)splits * rows_total * N * 4 + 64 > arena_bytes) return false;
@@ -348,10 +388,10 @@ static bool small_plan(SmallGeom& g, int B, int X, int Y, int Z, int K, int N, b
     return true;
 }
 
-template <int MTW>
-static int small_go(const void* x1, int C1, const void* x2, int C2, const void* wp, float* slab, const bf16* zero16,
-                    const SmallGeom& g, size_t lds, hipStream_t st) {
-    auto kern = conv3_small_kernel<MTW>;
+template <int MTW, bool SPLIT>
+static int small_go(const void* x1, int C1, const void* x2, int C2, const void* wp, float* slab, const void* zero16,
+                    const SmallGeom& g, size_t lds, int64_t lo_offset, hipStream_t st) {
+    auto kern = conv3_small_kernel<MTW, SPLIT>;
     static size_t attr = 0;
     if (lds > attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -359,38 +399,49 @@ static int small_go(const void* x1, int C1, const void* x2, int C2, const void* 
         attr = lds;
     }
     const int ngroups = ceil_div(g.B, g.nbg) * g.gx;
-    hipLaunchKernelGGL(kern, dim3(g.N / SM_BN, ngroups, g.nsplit), dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2,
-                       (const bf16*)wp, slab, zero16, g);
+    hipLaunchKernelGGL(kern, dim3(g.N / SM_BN, ngroups, g.nsplit), dim3(256), lds, st, x1, C1, x2, C2, (const bf16*)wp, slab,
+                       zero16, g, lo_offset);
     return tdx_launch_status();
 }
 
+template <bool SPLIT>
+static int small_dispatch(int mtw, const void* x1, int C1, const void* x2, int C2, const void* wp, float* slab,
+                          const void* z16, const SmallGeom& g, size_t lds, int64_t lo, hipStream_t st) {
+    switch (mtw) {
+        case 1: case 2: case 3: return small_go<3, SPLIT>(x1, C1, x2, C2, wp, slab, z16, g, lds, lo, st);
+        case 4: return small_go<4, SPLIT>(x1, C1, x2, C2, wp, slab, z16, g, lds, lo, st);
+        case 5: return small_go<5, SPLIT>(x1, C1, x2, C2, wp, slab, z16, g, lds, lo, st);
+        case 6: return small_go<6, SPLIT>(x1, C1, x2, C2, wp, slab, z16, g, lds, lo, st);
+        default: return small_go<7, SPLIT>(x1, C1, x2, C2, wp, slab, z16, g, lds, lo, st);
+    }
+}
+
 // Forward (data_gradient == false: y = conv3([x1 | x2]) + bias, N = Cout) or data gradient (x1 = dy with K = C1
-// channels, x2 unused; result N channels split over out1 [0, D1) / out2, plus addends).  Returns TDX_ESHAPE when the
-// launch is not a small-grid case (the caller then takes the brick kernels).
+// channels, x2 unused; result N channels split over out1 [0, D1) / out2, plus addends).  split == false: bf16 tensors,
+// wp = the bf16 packed weight; split == true: fp32 tensors, wp = the split-precision packed weight (hi image, lo image).
+// Returns TDX_ESHAPE when the launch is not a small-grid case (the caller then takes the brick kernels).
 int conv3_small_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* out1, int D1,
                        void* out2, const void* add1, const void* add2, int B, int X, int Y, int Z, int N, bool data_gradient,
-                       hipStream_t st) {
+                       bool split, hipStream_t st) {
     char* arena = (char*)tdx_scratch_ptr();
     if (arena == nullptr) return TDX_ESHAPE;
     if ((C1 % SM_KC) || (C2 % SM_KC)) return TDX_ESHAPE;
     SmallGeom g;
     size_t lds = 0;
-    if (!small_plan(g, B, X, Y, Z, C1 + C2, N, data_gradient, tdx_scratch_bytes(), lds)) return TDX_ESHAPE;
+    if (!small_plan(g, B, X, Y, Z, C1 + C2, N, data_gradient, split, tdx_scratch_bytes(), lds)) return TDX_ESHAPE;
     float* slab = reinterpret_cast<float*>(arena + 64);
     const int rows = g.nbg * g.xs * g.Ev[1] * g.Ev[2];
     const int mtw = ceil_div(ceil_div(rows, 32), 4);
-    int rc;
-    const bf16* z16 = small_zero_block(arena);
-    switch (mtw) {
-        case 1: case 2: case 3: rc = small_go<3>(x1, C1, x2, C2, wp, slab, z16, g, lds, st); break;
-        case 4: rc = small_go<4>(x1, C1, x2, C2, wp, slab, z16, g, lds, st); break;
-        case 5: rc = small_go<5>(x1, C1, x2, C2, wp, slab, z16, g, lds, st); break;
-        case 6: rc = small_go<6>(x1, C1, x2, C2, wp, slab, z16, g, lds, st); break;
-        default: rc = small_go<7>(x1, C1, x2, C2, wp, slab, z16, g, lds, st); break;
-    }
+    const int64_t lo = (int64_t)27 * (C1 + C2) * N;  // elements between the hi and the lo weight image
+    const int rc = split ? small_dispatch<true>(mtw, x1, C1, x2, C2, wp, slab, arena, g, lds, lo, st)
+                         : small_dispatch<false>(mtw, x1, C1, x2, C2, wp, slab, arena, g, lds, 0, st);
     if (rc != TDX_OK) return rc;
     const int64_t total = (int64_t)B * X * Y * Z * (N / 8);
-    hipLaunchKernelGGL(conv3_small_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, slab, bias, (bf16*)out1, D1,
-                       (bf16*)out2, (const bf16*)add1, (const bf16*)add2, B, X, Y, Z, N, g.nsplit, data_gradient ? 1 : 0);
+    if (split)
+        hipLaunchKernelGGL(conv3_small_reduce_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, st, slab, bias, (float*)out1,
+                           D1, (float*)out2, (const float*)add1, (const float*)add2, B, X, Y, Z, N, g.nsplit, data_gradient ? 1 : 0);
+    else
+        hipLaunchKernelGGL(conv3_small_reduce_kernel<bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, st, slab, bias, (bf16*)out1,
+                           D1, (bf16*)out2, (const bf16*)add1, (const bf16*)add2, B, X, Y, Z, N, g.nsplit, data_gradient ? 1 : 0);
     return tdx_launch_status();
 }

@@ -732,41 +732,51 @@ def test_conv3_wgrad_split_merge_modes(grid):
         assert int(ws[: (27 * Ci * Co + Co) * 4].count_nonzero()) == 0
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f32s"])
 @pytest.mark.parametrize("case", [
     # B, C1, C2, Cout, grid -- the deep levels of the shipped model and ragged / tiny relatives
     (6, 512, 0, 512, (12, 4, 3)), (6, 256, 0, 512, (24, 8, 6)), (6, 512, 512, 256, (24, 8, 6)), (2, 128, 0, 32, (5, 3, 1)),
     (3, 256, 0, 64, (7, 9, 4)), (8, 512, 0, 512, (12, 4, 3)), (1, 160, 0, 96, (13, 7, 6)),
 ])
-def test_conv3_small_grid_kernel_vs_brick_kernels(case, monkeypatch):
+def test_conv3_small_grid_kernel_vs_brick_kernels(case, mode, monkeypatch):
     """The small-grid conv (packed M tiles, split K, reduce pass with the halo fold; tdx_conv3_small.hip) against the
     brick kernels + halo-shell kernel it replaces on the deep levels (arena registered vs not), forward with fused
-    statistics and data gradient with addends; and both against the fp64 oracle on the smallest case."""
+    statistics and data gradient with addends; and both against the fp64 oracle on the smallest case.  bf16 tensors,
+    and fp32 tensors with split-precision products (the f32s mode)."""
     from turbdiff_amd import _lib as L, ops
 
     B, C1, C2, Co, (X, Y, Z) = case
     d = dev()
     Ci = C1 + C2
+    dt, DT, IMPL = (torch.bfloat16, L.BF16, L.CONV_AUTO) if mode == "bf16" else (torch.float32, L.F32, L.CONV_SPLIT)
+    tols = [4e-3, 1e-3, 4e-3, 6e-3, 6e-3] if mode == "bf16" else [2e-5, 1e-5, 2e-5, 2e-5, 2e-5]
     g = torch.Generator(device=d).manual_seed(7)
     rn = lambda *s: torch.randn(*s, device=d, generator=g)
-    x1, x2 = rn(B, X, Y, Z, C1).bfloat16(), (rn(B, X, Y, Z, C2).bfloat16() if C2 else None)
+    x1, x2 = rn(B, X, Y, Z, C1).to(dt), (rn(B, X, Y, Z, C2).to(dt) if C2 else None)
     w = rn(Co, Ci, 3, 3, 3) * (2.0 / (27 * Ci)) ** 0.5
-    bias, gy = rn(Co), rn(B, X, Y, Z, Co).bfloat16()
+    bias, gy = rn(Co), rn(B, X, Y, Z, Co).to(dt)
     st = L.stream()
-    wf, wb = ops._packed_conv3(w, torch.bfloat16)
+    prev = L._conv_impl_override
+    if mode == "f32s":
+        L.set_conv_impl("split")  # fp32 weights packed as bf16 hi + lo images
+    try:
+        wf, wb = ops._packed_conv3(w, dt)
+    finally:
+        L.set_conv_impl(prev)
 
     def run():
-        y = torch.empty(B, X, Y, Z, Co, device=d, dtype=torch.bfloat16)
+        y = torch.empty(B, X, Y, Z, Co, device=d, dtype=dt)
         stats = torch.empty(B, 8, 2, device=d)
         ws = torch.zeros(L.query("tdx_gn_workspace_bytes", B, Co), dtype=torch.uint8, device=d)
         L.call("tdx_conv3_fwd_gn", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats), 8, 1e-5, L.ptr(ws),
-               B, X, Y, Z, Co, L.BF16, L.CONV_AUTO | L.WS_CLEAN, st)
+               B, X, Y, Z, Co, DT, IMPL | L.WS_CLEAN, st)
         assert int(ws.count_nonzero()) == 0
         y2 = torch.empty_like(y)
-        L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y2), B, X, Y, Z, Co, L.BF16, L.CONV_AUTO, st)
+        L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y2), B, X, Y, Z, Co, DT, IMPL, st)
         gx1, gx2 = torch.empty_like(x1), (torch.empty_like(x2) if C2 else None)
-        dws = torch.empty(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, Ci, L.BF16, 0), dtype=torch.uint8, device=d)
+        dws = torch.empty(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, Ci, DT, 0), dtype=torch.uint8, device=d)
         L.call("tdx_conv3_bwd_data_add", L.ptr(gy), L.ptr(wb), L.ptr(gx1), C1, L.ptr(gx2), C2, L.ptr(x1), L.ptr(x2), B, X, Y, Z, Co,
-               L.BF16, L.CONV_AUTO, L.ptr(dws), st)
+               DT, IMPL, L.ptr(dws), st)
         torch.cuda.synchronize()
         return y, stats, y2, gx1, gx2
 
@@ -783,16 +793,16 @@ def test_conv3_small_grid_kernel_vs_brick_kernels(case, monkeypatch):
     finally:
         L._SCRATCH.pop("active", None)
         L.ensure_scratch(d)
-    for n, a, b, tol in zip(["y", "stats", "y (plain fwd)", "gx1", "gx2"], small, brick, [4e-3, 1e-3, 4e-3, 6e-3, 6e-3]):
+    for n, a, b, tol in zip(["y", "stats", "y (plain fwd)", "gx1", "gx2"], small, brick, tols):
         if a is None:
             continue
         assert torch.isfinite(a.float()).all(), n
-        assert rel_l2(a.float(), b.float()) < tol, (n, case)
+        assert rel_l2(a.float(), b.float()) < tol, (n, case, mode)
     assert torch.equal(small[0], small[2])
     if X * Y * Z <= 20:  # the oracle on the smallest case: replicate-padded conv and its adjoint in fp64
         xr = torch.cat([x1] + ([x2] if C2 else []), dim=-1).double().cpu().permute(0, 4, 1, 2, 3).requires_grad_()
         yr = O.conv3_replicate(xr, w.double().cpu(), bias.double().cpu())
         yr.backward(gy.double().cpu().permute(0, 4, 1, 2, 3))
-        assert rel_l2(small[0].float().cpu().permute(0, 4, 1, 2, 3), yr) < 4e-3
+        assert rel_l2(small[0].float().cpu().permute(0, 4, 1, 2, 3), yr) < (4e-3 if mode == "bf16" else 2e-5)
         gx = torch.cat([small[3]] + ([small[4]] if C2 else []), dim=-1).float().cpu() - torch.cat([x1] + ([x2] if C2 else []), dim=-1).float().cpu()
-        assert rel_l2(gx.permute(0, 4, 1, 2, 3), xr.grad) < 1e-2
+        assert rel_l2(gx.permute(0, 4, 1, 2, 3), xr.grad) < (1e-2 if mode == "bf16" else 5e-5)
