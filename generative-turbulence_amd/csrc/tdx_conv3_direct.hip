@@ -45,13 +45,25 @@ conv3_pack_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16
         t[co][r] = w[((int64_t)(co0 + co) * Cin + ci0) * 27 + r];
     }
     __syncthreads();
-    // 27 taps x 256 (row, k) pairs; thread -> (row = tid / 16, k = tid % 16): 2-B stores, 32 B per row
-    const int row = tid >> 4, k = tid & 15;
-    for (int tap = 0; tap < 27; ++tap) {
-        if (wf)  // row = co, k = ci
-            wf[((((int64_t)(ci0 >> 4) * 27 + tap) * Cout + co0 + row) << 4) + k] = __float2bfloat16(t[row][k * 27 + tap]);
-        if (wb)  // row = ci, k = co
-            wb[((((int64_t)(co0 >> 4) * 27 + (26 - tap)) * Cin + ci0 + row) << 4) + k] = __float2bfloat16(t[k][row * 27 + tap]);
+    // per tap 16 rows x 2 halves of 8 packed values (one 16-B store each): 32 threads per tap, 8 taps per pass
+    const int row = (tid >> 1) & 15, half = tid & 1, tsub = tid >> 5;
+    for (int tap = tsub; tap < 27; tap += 8) {
+        if (wf) {  // row = co, k = ci
+            unsigned u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                u[j] = pack_bf16x2(t[row][(half * 8 + 2 * j) * 27 + tap], t[row][(half * 8 + 2 * j + 1) * 27 + tap]);
+            *reinterpret_cast<uint4*>(wf + ((((int64_t)(ci0 >> 4) * 27 + tap) * Cout + co0 + row) << 4) + half * 8) =
+                make_uint4(u[0], u[1], u[2], u[3]);
+        }
+        if (wb) {  // row = ci, k = co
+            unsigned u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                u[j] = pack_bf16x2(t[half * 8 + 2 * j][row * 27 + tap], t[half * 8 + 2 * j + 1][row * 27 + tap]);
+            *reinterpret_cast<uint4*>(wb + ((((int64_t)(co0 >> 4) * 27 + (26 - tap)) * Cin + ci0 + row) << 4) + half * 8) =
+                make_uint4(u[0], u[1], u[2], u[3]);
+        }
     }
 }
 
@@ -156,20 +168,27 @@ conv3_unpack_wgrad_kernel(float* __restrict__ dwp, float* __restrict__ dw, float
     const int tid = threadIdx.x;
     const int ci = tid >> 4, co = tid & 15;
     const bool ok = ci0 + ci < Cin && co0 + co < Cout;
-    for (int tap = 0; tap < 27; ++tap) {
-        float v = 0.f;
-        if (ok) {
-            const int64_t idx = ((int64_t)tap * Cin + ci0 + ci) * Cout + co0 + co;
-            if (nslab > 0) {  // the K-splits stored their partial tiles into slabs: add them up
-                const int64_t stride = (int64_t)27 * Cin * Cout;
-                for (int k = 0; k < nslab; ++k) v += slabs[k * stride + idx];
-            } else {
-                v = dwp[idx];
-                dwp[idx] = 0.f;
-            }
+    // all 27 loads first (the clearing stores below may alias them as far as the compiler knows: interleaved, every
+    // tap would wait for a full memory round trip)
+    float v[27];
+    const int64_t stride = (int64_t)27 * Cin * Cout, tstride = (int64_t)Cin * Cout;
+    const int64_t idx0 = (int64_t)(ci0 + ci) * Cout + co0 + co;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) v[tap] = 0.f;
+    if (ok) {
+        if (nslab > 0) {  // the K-splits stored their partial tiles into slabs: add them up
+            for (int k = 0; k < nslab; ++k)
+#pragma unroll
+                for (int tap = 0; tap < 27; ++tap) v[tap] += slabs[k * stride + tap * tstride + idx0];
+        } else {
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) v[tap] = dwp[tap * tstride + idx0];
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) dwp[tap * tstride + idx0] = 0.f;
         }
-        t[co][ci * 27 + tap] = v;
     }
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) t[co][ci * 27 + tap] = v[tap];
     __syncthreads();
     const int nci = min(16, Cin - ci0);
     for (int i = tid; i < 16 * nci * 27; i += 256) {

@@ -72,10 +72,24 @@ SIGNATURES = {
     "tdx_convg_apply": (_i, [_vp, _vp, _vp, _vp] + [_i] * 16 + [_vp]),
     "tdx_convg_fold_clamp": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_convg_bwd_weight": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
+    "tdx_film_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "tdx_film_bwd_workspace_bytes": (_sz, [_i, _i, _vp, _i]),
+    "tdx_film_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "tdx_opt_chunk_elems": (_i64, []),
     "tdx_grad_norm": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "tdx_radam_step": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
 }
+
+FILM_MAX_LAYERS = 32  # TDX_FILM_MAX_LAYERS
+
+
+class FilmLayer(C.Structure):  # TdxFilmLayer
+    _fields_ = [("weight", _vp), ("bias", _vp), ("out", _vp), ("channels", _i)]
+
+
+class FilmGrad(C.Structure):  # TdxFilmGrad
+    _fields_ = [("weight", _vp), ("grad_out", _vp), ("grad_weight", _vp), ("grad_bias", _vp), ("channels", _i)]
+
 
 _lib = None
 

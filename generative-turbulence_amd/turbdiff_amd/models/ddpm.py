@@ -130,13 +130,17 @@ class ResnetBlock(nn.Module):
         identity = isinstance(self.conv, nn.Identity)
         return self.block1._fused_act and self.block2._fused_act and not (identity and x2 is not None) and FUSE_BLOCKS
 
-    def forward(self, x, c, x2=None, partial=None, conv1=None):
+    def forward(self, x, c, x2=None, partial=None, conv1=None, films=None):
         """partial = (n_lead, init): inference only -- block1's conv runs over the leading n_lead channels
         of x and continues from `init`, the precomputed conv of the batch-shared remaining channels.
         conv1 = (input, weight, bias): block1's conv replaced by an equivalent conv on another input
-        (DenoisingModel.compose_first_conv); x still feeds the identity skip."""
-        film = self.project_onto_scale_shift(c)  # (B, 2*dim_out): [scale | shift]
-        scale, shift = film[:, : self.dim_out], film[:, self.dim_out :]
+        (DenoisingModel.compose_first_conv); x still feeds the identity skip.
+        films = {id(block): (2, B, dim_out) scale | shift}: the projections of all blocks computed up front in one
+        launch (DenoisingModel.film_table); without it the block projects `c` itself."""
+        film = films.get(id(self)) if films is not None else None
+        if film is None:
+            film = ops.film_projections(c, [self.project_onto_scale_shift])[0]  # (2, B, dim_out): scale, shift
+        scale, shift = film[0], film[1]
         identity = isinstance(self.conv, nn.Identity)
         if self.fused(x2):
             b1, b2 = self.block1, self.block2
@@ -145,11 +149,11 @@ class ResnetBlock(nn.Module):
                 return ops.resnet_block(x, None, scale, shift, (conv1[1], conv1[2]), (b1.norm.weight, b1.norm.bias),
                                         (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias), None,
                                         _norm_groups(b1.norm), b1.norm.eps, conv1_input=conv1[0],
-                                        conv1_real_channels=conv1[3] if len(conv1) > 3 else None)
+                                        conv1_real_channels=conv1[3] if len(conv1) > 3 else None, film=film)
             return ops.resnet_block(x, x2, scale, shift, (b1.conv.weight, b1.conv.bias), (b1.norm.weight, b1.norm.bias),
                                     (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias),
                                     None if identity else (self.conv.weight, self.conv.bias), _norm_groups(b1.norm),
-                                    b1.norm.eps, partial=partial)
+                                    b1.norm.eps, partial=partial, film=film)
         assert partial is None and conv1 is None
         h = self.block1(x, scale_shift=(scale, shift), x2=x2)
         if isinstance(self.conv, nn.Identity):
@@ -219,21 +223,21 @@ class UNet(nn.Module):
         self.downsampling_factor = downsampling_factor
         self.scale_factor = 1 / downsampling_factor
 
-    def forward(self, x, c, first_partial=None, first_conv=None):
+    def forward(self, x, c, first_partial=None, first_conv=None, films=None):
         skips = []
         for i, blk in enumerate(self.downsampling_blocks):
             if i == 0 and first_conv is not None:
-                x = blk(x, c, conv1=first_conv)
+                x = blk(x, c, conv1=first_conv, films=films)
             elif i == 0 and first_partial is not None:
-                x = blk(x, c, partial=first_partial)
+                x = blk(x, c, partial=first_partial, films=films)
             else:
-                x = blk(x, c)
+                x = blk(x, c, films=films)
             skip, x = ops.skip_and_resize(x, [max(int(s * self.scale_factor), 3) for s in x.shape[1:4]])
             skips.append(skip)
-        x = self.center_block(x, c=c)
+        x = self.center_block(x, c=c, films=films)
         for blk in self.upsampling_blocks:
             skip = skips.pop()
-            x = blk(ops.resize(x, skip.shape[1:4]), c, x2=skip)
+            x = blk(ops.resize(x, skip.shape[1:4]), c, x2=skip, films=films)
         return x
 
 
@@ -316,10 +320,28 @@ class DenoisingModel(nn.Module):
         mods += list(reversed(self.u_net.upsampling_blocks))
         mods += list(reversed(list(self.u_net.center_block)))
         mods += list(reversed(self.u_net.downsampling_blocks))
-        mods += [getattr(self, n) for n in ("encode_c_local", "encode_x", "geometry_embedding", "encode_c_global", "process_c")
-                 if hasattr(self, n)]
+        mods += [getattr(self, n) for n in ("encode_c_local", "encode_x") if hasattr(self, n)]
+        # the FiLM projections of all blocks are one autograd node (film_table): their gradients arrive together,
+        # after the last block's backward and right before the conditioning MLP's
+        film = {id(p) for m in self.modules() if isinstance(m, ResnetBlock) for p in m.project_onto_scale_shift.parameters()}
+        late = []
         for m in mods:
-            yield from reversed(list(m.parameters()))
+            for p in reversed(list(m.parameters())):
+                if id(p) in film:
+                    late.append(p)
+                else:
+                    yield p
+        yield from late
+        for n in ("geometry_embedding", "encode_c_global", "process_c"):
+            if hasattr(self, n):
+                yield from reversed(list(getattr(self, n).parameters()))
+
+    def film_table(self, c):
+        """{id(block): (2, B, dim_out) [scale, shift]} for every ResnetBlock, projected from the conditioning vector
+        in one launch (the reference projects inside each block, ddpm.py:191-192)."""
+        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock)]
+        films = ops.film_projections(c, [b.project_onto_scale_shift for b in blocks])
+        return {id(b): f for b, f in zip(blocks, films)}
 
     def set_compute_dtype(self, dtype: torch.dtype):
         """float32 (parity mode) or bfloat16 (activation storage + MFMA operands)."""
@@ -421,8 +443,9 @@ class DenoisingModel(nn.Module):
             if e is not None:
                 h = torch.cat((h, e.expand(B, -1, -1, -1, -1)), dim=-1)
         partial = getattr(encoded_local, "first_conv_partial", None) if not torch.is_grad_enabled() else None
-        h = self.u_net(h, c, first_partial=partial, first_conv=first_conv)
-        h = self.decode[0](h, c)
+        films = self.film_table(c)
+        h = self.u_net(h, c, first_partial=partial, first_conv=first_conv, films=films)
+        h = self.decode[0](h, c, films=films)
         if ops.decode_supported(h, self.decode[1].weight):
             return ops.decode(h, self.decode[1].weight, self.decode[1].bias)
         y = ops.conv1(h, self.decode[1].weight, self.decode[1].bias)

@@ -625,6 +625,76 @@ def randn_philox_batched(out: torch.Tensor, seed: int, stream_ids: torch.Tensor,
     return out
 
 
+# --------------------------------------------------------------------------- FiLM projections of all blocks
+
+
+class _FilmProjections(torch.autograd.Function):
+    """scale | shift of every ResnetBlock from the conditioning vector in ONE launch (tdx_film_fwd; the reference runs
+    nn.Linear(c_dim, 2 * dim_out) + chunk per block, ddpm.py:184,191-192), and the three gradients of all of them in
+    two (tdx_film_bwd).  Arguments: c (B, T), then weight, bias of every layer; results: one (2, B, C_i) f32 tensor
+    per layer, [0] = scale, [1] = shift."""
+
+    @staticmethod
+    def forward(ctx, c, *wb):
+        n = len(wb) // 2
+        c32 = c.detach().float().contiguous()
+        B, T = c32.shape
+        ws = [wb[2 * i].detach().float().contiguous() for i in range(n)]
+        bs = [None if wb[2 * i + 1] is None else wb[2 * i + 1].detach().float().contiguous() for i in range(n)]
+        outs = []
+        for lo in range(0, n, L.FILM_MAX_LAYERS):
+            hi = min(n, lo + L.FILM_MAX_LAYERS)
+            tab = (L.FilmLayer * (hi - lo))()
+            for j, i in enumerate(range(lo, hi)):
+                C2 = ws[i].shape[0]
+                assert ws[i].shape == (C2, T) and C2 % 2 == 0
+                out = torch.empty((2, B, C2 // 2), dtype=torch.float32, device=c.device)
+                tab[j] = L.FilmLayer(L.ptr(ws[i]), L.ptr(bs[i]), L.ptr(out), C2 // 2)
+                outs.append(out)
+            L.call("tdx_film_fwd", L.ptr(c32), B, T, tab, hi - lo, L.stream())
+        ctx.save_for_backward(c32, *ws)
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.c_dtype = c.dtype
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        c32, *ws = ctx.saved_tensors
+        n = len(ws)
+        B, T = c32.shape
+        dev = c32.device
+        grads, dc = [], None
+        for lo in range(0, n, L.FILM_MAX_LAYERS):
+            hi = min(n, lo + L.FILM_MAX_LAYERS)
+            tab = (L.FilmGrad * (hi - lo))()
+            chans = (L.C.c_int * (hi - lo))()
+            keep = []
+            for j, i in enumerate(range(lo, hi)):
+                C2 = ws[i].shape[0]
+                g = gs[i]
+                g = torch.zeros((2, B, C2 // 2), dtype=torch.float32, device=dev) if g is None else g.float().contiguous()
+                dw = torch.empty_like(ws[i])
+                db = torch.empty(C2, dtype=torch.float32, device=dev) if ctx.has_bias[i] else None
+                tab[j] = L.FilmGrad(L.ptr(ws[i]), L.ptr(g), L.ptr(dw), L.ptr(db), C2 // 2)
+                chans[j] = C2 // 2
+                keep.append(g)
+                grads += [dw, db]
+            part = _ws(L.query("tdx_film_bwd_workspace_bytes", B, T, chans, hi - lo), dev)
+            d = torch.empty_like(c32)
+            L.call("tdx_film_bwd", L.ptr(c32), B, T, tab, hi - lo, L.ptr(d), L.ptr(part), L.stream())
+            dc = d if dc is None else dc + d
+        return (dc.to(ctx.c_dtype), *grads)
+
+
+def film_projections(c: torch.Tensor, linears) -> list:
+    """[(2, B, C_i) f32 tensor: scale, shift] for each nn.Linear(c_dim, 2 * C_i) in `linears`, all in one launch."""
+    args = []
+    for lin in linears:
+        args += [lin.weight, lin.bias]
+    return list(_FilmProjections.apply(c, *args))
+
+
 # --------------------------------------------------------------------------- fused ResnetBlock
 
 
@@ -640,7 +710,7 @@ class _ResnetBlock(torch.autograd.Function):
     cuts the number of autograd nodes per block from 6-7 to 1."""
 
     @staticmethod
-    def forward(ctx, x1, x2, scale, shift, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps, partial=None, xc=None,
+    def forward(ctx, x1, x2, film, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps, partial=None, xc=None,
                 xc_real=None):
         """xc: optional separate input of block1's conv (w1 then has xc's channel count); the residual
         path still uses x1.  Used for the U-Net's first block, whose conv is composed with the 1x1
@@ -662,7 +732,8 @@ class _ResnetBlock(torch.autograd.Function):
         wf2, wb2 = _packed_conv3(w2, dt)
         f32c = lambda t: t.detach().float().contiguous()
         g1, be1, g2, be2 = f32c(g1), f32c(be1), f32c(g2), f32c(be2)
-        scale, shift = f32c(scale.reshape(B, Cout)), f32c(shift.reshape(B, Cout))
+        film = f32c(film.reshape(2, B, Cout))  # (scale | shift) of film_projections: dense (B, Cout) halves, no copies
+        scale, shift = film[0], film[1]
         gws = _clean_ws(L.query("tdx_gn_workspace_bytes", B, Cout), dev)
 
         def conv_gn(xa, Ca, xb, Cb, wf, bias, real=None):
@@ -705,7 +776,7 @@ class _ResnetBlock(torch.autograd.Function):
         y = torch.empty_like(h1)
         L.call("tdx_gn_apply", L.ptr(h2), L.ptr(st2), L.ptr(g2), L.ptr(be2), None, None, L.ptr(res), L.ptr(y), B, V, Cout,
                groups, 1, code, st)
-        ctx.save_for_backward(x1, x2, h1, st1, a1, h2, st2, scale, shift, g1, be1, g2, be2, wb1, wb2, wr2, xc)
+        ctx.save_for_backward(x1, x2, h1, st1, a1, h2, st2, film, g1, be1, g2, be2, wb1, wb2, wr2, xc)
         ctx.cfg = (groups, tuple(w1.shape), tuple(w2.shape), None if wr is None else tuple(wr.shape),
                    b1 is not None, b2 is not None, br is not None)
         ctx.xc_real = xc_real
@@ -714,7 +785,8 @@ class _ResnetBlock(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x1, x2, h1, st1, a1, h2, st2, scale, shift, g1, be1, g2, be2, wb1, wb2, wr2, xc = ctx.saved_tensors
+        x1, x2, h1, st1, a1, h2, st2, film, g1, be1, g2, be2, wb1, wb2, wr2, xc = ctx.saved_tensors
+        scale, shift = film[0], film[1]
         groups, w1s, w2s, wrs, hb1, hb2, hbr = ctx.cfg
         B, X, Y, Z, C1 = _grid(x1)
         C2 = 0 if x2 is None else x2.shape[-1]
@@ -744,7 +816,8 @@ class _ResnetBlock(torch.autograd.Function):
                L.ptr(dws), st, work=flops(Cout))
         del dh2
         # ---- block1: GroupNorm + FiLM + SiLU
-        dh1, dg1, dbe1, dscale, dshift = torch.empty_like(h1), f32(Cout), f32(Cout), f32(B, Cout), f32(B, Cout)
+        dh1, dg1, dbe1, dfilm = torch.empty_like(h1), f32(Cout), f32(Cout), f32(2, B, Cout)
+        dscale, dshift = dfilm[0], dfilm[1]
         L.call("tdx_gn_bwd", L.ptr(h1), L.ptr(da1), L.ptr(st1), L.ptr(g1), L.ptr(be1), L.ptr(scale), L.ptr(shift), L.ptr(dh1),
                L.ptr(dg1), L.ptr(dbe1), L.ptr(dscale), L.ptr(dshift), B, V, Cout, groups, 1, code, L.ptr(gws), st)
         del da1
@@ -756,11 +829,11 @@ class _ResnetBlock(torch.autograd.Function):
             L.call("tdx_conv3_bwd_weight", L.ptr(xc), Cc, None, 0, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
                    impl | WS_CLEAN, L.ptr(wws1), st, work=flops(ctx.xc_real or Cc))
             dxc = None
-            if ctx.needs_input_grad[17]:
+            if ctx.needs_input_grad[16]:
                 dxc = torch.empty_like(xc)
                 L.call("tdx_conv3_bwd_data", L.ptr(dh1), L.ptr(wb1), L.ptr(dxc), Cc, None, 0, 0, B, X, Y, Z, Cout, code, impl,
                        L.ptr(dws), st, work=flops(ctx.xc_real or Cc))
-            return (gy, None, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, dxc, None)
+            return (gy, None, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, dxc, None)
         L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
                impl | WS_CLEAN, L.ptr(wws1), st, work=flops(Cin))
         # ---- input gradient = conv1 data gradient + residual-path gradient
@@ -787,19 +860,23 @@ class _ResnetBlock(torch.autograd.Function):
                 L.call("tdx_conv1_bwd_weight", L.ptr(x2), C2, L.ptr(gy), Cout, dwt.data_ptr() + 4 * C1 * Cout, Cout, None,
                        B * V, code, st)
             dwr = dwt.t().reshape(wrs)
-        return (gx1, gx2, dscale, dshift, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None, None)
+        return (gx1, gx2, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None, None)
 
 
 def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, skip_wb, groups, eps=1e-5, partial=None,
-                 conv1_input=None, conv1_real_channels=None):
+                 conv1_input=None, conv1_real_channels=None, film=None):
     """Fused ResnetBlock; *_wb are (weight, bias) pairs, skip_wb is None for an identity skip.
-    Requires SiLU activations and bf16/f32 NDHWC inputs; scale/shift are (B, Cout).
+    Requires SiLU activations and bf16/f32 NDHWC inputs; scale/shift are (B, Cout), or film = the (2, B, Cout)
+    [scale, shift] tensor of film_projections (then scale and shift are ignored: no slicing copies either way).
     partial = (n_lead, init): no-grad only, see conv3_shared_tail.
     conv1_input: separate input tensor of block1's conv (conv1_wb then matches ITS channel count);
     conv1_real_channels: how many of its channels carry data (the rest is zero padding) -- bookkeeping for the
     kernel timers only."""
     wr, br = skip_wb if skip_wb is not None else (None, None)
-    return _ResnetBlock.apply(x1, x2, scale, shift, conv1_wb[0], conv1_wb[1], norm1_wb[0], norm1_wb[1], conv2_wb[0],
+    if film is None:
+        B, Cout = x1.shape[0], conv1_wb[0].shape[0]
+        film = torch.stack((scale.reshape(B, Cout).float(), shift.reshape(B, Cout).float()))
+    return _ResnetBlock.apply(x1, x2, film, conv1_wb[0], conv1_wb[1], norm1_wb[0], norm1_wb[1], conv2_wb[0],
                               conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps, partial, conv1_input,
                               conv1_real_channels)
 

@@ -325,6 +325,33 @@ int tdx_radam_step(const TdxOptTensor* table, const int* chunk_tensor, const int
                    const float* clip, int64_t step, float lr, float beta1, float beta2, float eps, int write_grad,
                    void* stream);
 
+/* ---- FiLM projections of all ResnetBlocks at once -------------------------------------------------
+ * Replaces, for every block of the U-Net in one launch, nn.Linear(c_dim, 2 * dim_out) on the conditioning vector and
+ * the chunk into (scale, shift) (reference models/ddpm.py:184,191-192), and in the backward its three gradients.
+ * c: (B, T) f32.  Layer i: weight (2 C_i, T), bias (2 C_i) or NULL, out (2, B, C_i) f32 -- out[0] = scale,
+ * out[1] = shift, the dense (B, C) operands of tdx_gn_apply / tdx_gn_bwd.  `layers` is a HOST array of n <=
+ * TDX_FILM_MAX_LAYERS entries (its pointers are device pointers); B * T <= 12288. */
+#define TDX_FILM_MAX_LAYERS 32
+typedef struct {
+    const float* weight;
+    const float* bias;
+    float* out;
+    int channels; /* C_i */
+} TdxFilmLayer;
+int tdx_film_fwd(const float* c, int B, int T, const TdxFilmLayer* layers, int n, void* stream);
+/* grad_out (2, B, C_i) -> grad_weight (2 C_i, T), grad_bias (2 C_i) or NULL; dc (B, T) = the sum over all layers of
+ * grad_out_i^T-stacked @ weight_i (overwritten).  Deterministic (fixed summation order).  workspace:
+ * tdx_film_bwd_workspace_bytes(B, T, channels, n) bytes of scratch. */
+typedef struct {
+    const float* weight;
+    const float* grad_out;
+    float* grad_weight;
+    float* grad_bias;
+    int channels;
+} TdxFilmGrad;
+size_t tdx_film_bwd_workspace_bytes(int B, int T, const int* channels, int n);
+int tdx_film_bwd(const float* c, int B, int T, const TdxFilmGrad* layers, int n, float* dc, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------ baseline conv variants
  * The conv layers of the reference's regression baselines, NDHWC, off the benchmark path:
  *   nn.Conv3d(dim, dim, 3, dilation=d, padding=d, padding_mode="replicate")        dilresnet.py:28-35

@@ -806,3 +806,42 @@ def test_conv3_small_grid_kernel_vs_brick_kernels(case, mode, monkeypatch):
         assert rel_l2(small[0].float().cpu().permute(0, 4, 1, 2, 3), yr) < (4e-3 if mode == "bf16" else 2e-5)
         gx = torch.cat([small[3]] + ([small[4]] if C2 else []), dim=-1).float().cpu() - torch.cat([x1] + ([x2] if C2 else []), dim=-1).float().cpu()
         assert rel_l2(gx.permute(0, 4, 1, 2, 3), xr.grad) < (1e-2 if mode == "bf16" else 5e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,chans", [(6, 32, (64, 64, 128, 256, 512, 512, 32)), (1, 96, (8,)), (19, 64, (40, 24, 512)),
+                                       (3, 32, tuple([16] * 37))])
+def test_film_projections_match_linear(B, T, chans):
+    """tdx_film_fwd / tdx_film_bwd (all ResnetBlocks' nn.Linear(c_dim, 2 C) + chunk in one launch, reference
+    ddpm.py:184,191-192) against F.linear in fp64: outputs, and the gradients of c, every weight and every bias; more
+    layers than one table holds; a layer whose output is unused gets zero gradients."""
+    from turbdiff_amd import ops
+
+    d = dev()
+    torch.manual_seed(3)
+    lins = [torch.nn.Linear(T, 2 * C).to(d) for C in chans]
+    c = torch.randn(B, T, device=d, requires_grad=True)
+    films = ops.film_projections(c, lins)
+    cr = c.detach().double().cpu().requires_grad_()
+    refs = [torch.nn.functional.linear(cr, l.weight.detach().double().cpu(), l.bias.detach().double().cpu()) for l in lins]
+    wr = [(l.weight.detach().double().cpu().requires_grad_(), l.bias.detach().double().cpu().requires_grad_()) for l in lins]
+    refs = [torch.nn.functional.linear(cr, w, b) for w, b in wr]
+    loss, loss_r = 0.0, 0.0
+    skip = len(chans) - 1 if len(chans) > 2 else None  # this layer's result does not reach the loss
+    for i, (f, r, C) in enumerate(zip(films, refs, chans)):
+        assert f.shape == (2, B, C) and f.dtype == torch.float32 and f.is_contiguous()
+        rr = torch.stack((r[:, :C], r[:, C:]))
+        assert rel_l2(f.detach().cpu(), rr.detach()) < 1e-6
+        if i == skip:
+            continue
+        m = torch.randn(2, B, C, generator=torch.Generator().manual_seed(i)).double()
+        loss = loss + (f * m.float().to(d)).sum()
+        loss_r = loss_r + (rr * m).sum()
+    loss.backward()
+    loss_r.backward()
+    assert rel_l2(c.grad.cpu(), cr.grad) < 1e-5
+    for i, (l, (w, b)) in enumerate(zip(lins, wr)):
+        if i == skip:
+            assert float(l.weight.grad.abs().max()) == 0.0 and float(l.bias.grad.abs().max()) == 0.0
+            continue
+        assert rel_l2(l.weight.grad.cpu(), w.grad) < 1e-5 and rel_l2(l.bias.grad.cpu(), b.grad) < 1e-5
