@@ -13,14 +13,14 @@ int conv1_mfma_fwd_launch(const void* x1, int C1, const void* x2, int C2, const 
                           const void* add, void* y, int64_t rows, int Cout, hipStream_t st);
 bool conv1_wgrad_mfma_supported(int Cin, int Cout);
 int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
-                            int64_t rows, hipStream_t st);
+                            int64_t rows, bool transposed, hipStream_t st);
 // fp32 MFMA versions (tdx_conv1_mfma_f32.hip)
 bool conv1_mfma_f32_supported(int C1, int C2, int Cout, const float* w, int ldw);
 int conv1_mfma_f32_fwd_launch(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
                               const void* add, void* y, int64_t rows, int Cout, hipStream_t st);
-bool conv1_wgrad_mfma_f32_supported(int Cin, int Cout, int ldw);
+bool conv1_wgrad_mfma_f32_supported(int Cin, int Cout);
 int conv1_wgrad_mfma_f32_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
-                                int64_t rows, hipStream_t st);
+                                int64_t rows, bool transposed, hipStream_t st);
 static bool conv1_force_direct() {
     const char* e = getenv("TDX_CONV1_IMPL");
     return e && e[0] == 'd';
@@ -121,7 +121,7 @@ extern "C" int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, con
 template <typename T>
 __global__ void __launch_bounds__(256)
 conv1_wgrad_kernel(const T* __restrict__ x, int Cin, const T* __restrict__ dy, int Cout, float* __restrict__ dw,
-                   int ldw, float* __restrict__ dbias, int64_t rows) {
+                   int ldw, float* __restrict__ dbias, int64_t rows, int transposed) {
     __shared__ float xs[C1_BK][C1_BM + 4];  // [row slice][ci]
     __shared__ float gs[C1_BK][C1_BN + 4];  // [row slice][co]
     const int64_t rbeg = (int64_t)blockIdx.x * C1W_ROWS;
@@ -171,29 +171,42 @@ conv1_wgrad_kernel(const T* __restrict__ x, int Cin, const T* __restrict__ dy, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int co = co0 + tx * 4 + j;
-            if (co < Cout) atomicAdd(&dw[(size_t)ci * ldw + co], acc[i][j]);
+            if (co < Cout) atomicAdd(&dw[transposed ? (size_t)co * ldw + ci : (size_t)ci * ldw + co], acc[i][j]);
         }
     }
     if (dbias && blockIdx.y == 0 && tid < C1_BN && co0 + tid < Cout) atomicAdd(&dbias[co0 + tid], bsum);
 }
 
+static int conv1_bwd_weight_impl(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
+                                 int64_t rows, int dtype, bool transposed, bool accumulate, hipStream_t st) {
+    if (!accumulate) {
+        // zero the block that is written (ldw may exceed the row length for sub-blocks)
+        const int nrow = transposed ? Cout : Cin, ncol = transposed ? Cin : Cout;
+        hipError_t e = hipMemset2DAsync(dw, (size_t)ldw * sizeof(float), 0, (size_t)ncol * sizeof(float), (size_t)nrow, st);
+        if (e != hipSuccess) return (int)e;
+        if (dbias) {
+            e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    if (dtype == TDX_BF16 && !conv1_force_direct() && conv1_wgrad_mfma_supported(Cin, Cout))
+        return conv1_wgrad_mfma_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st);
+    if (dtype == TDX_F32 && !conv1_force_direct() && conv1_wgrad_mfma_f32_supported(Cin, Cout))
+        return conv1_wgrad_mfma_f32_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st);
+    dim3 grid(ceil_div(rows, C1W_ROWS), ceil_div(Cin, C1_BM), ceil_div(Cout, C1_BN));
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_wgrad_kernel<T>), grid, dim3(256), 0, st, (const T*)x, Cin,
+                                                  (const T*)dy, Cout, dw, ldw, dbias, rows, transposed ? 1 : 0));
+    return tdx_launch_status();
+}
+
 extern "C" int tdx_conv1_bwd_weight(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw,
                                     float* dbias, int64_t rows, int dtype, void* stream) {
     TDX_CHECK_ARG(x && dy && dw && rows > 0 && Cin > 0 && Cout > 0 && ldw >= Cout);
-    hipStream_t st = as_stream(stream);
-    // zero the [Cin][ldw] block rows that are written (ldw may exceed Cout for sub-blocks)
-    hipError_t e = hipMemset2DAsync(dw, (size_t)ldw * sizeof(float), 0, (size_t)Cout * sizeof(float), (size_t)Cin, st);
-    if (e != hipSuccess) return (int)e;
-    if (dbias) {
-        e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (dtype == TDX_BF16 && !conv1_force_direct() && conv1_wgrad_mfma_supported(Cin, Cout))
-        return conv1_wgrad_mfma_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, st);
-    if (dtype == TDX_F32 && !conv1_force_direct() && conv1_wgrad_mfma_f32_supported(Cin, Cout, ldw))
-        return conv1_wgrad_mfma_f32_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, st);
-    dim3 grid(ceil_div(rows, C1W_ROWS), ceil_div(Cin, C1_BM), ceil_div(Cout, C1_BN));
-    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_wgrad_kernel<T>), grid, dim3(256), 0, st, (const T*)x, Cin,
-                                                  (const T*)dy, Cout, dw, ldw, dbias, rows));
-    return tdx_launch_status();
+    return conv1_bwd_weight_impl(x, Cin, dy, Cout, dw, ldw, dbias, rows, dtype, false, false, as_stream(stream));
+}
+
+extern "C" int tdx_conv1_bwd_weight_oc(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw,
+                                       float* dbias, int accumulate, int64_t rows, int dtype, void* stream) {
+    TDX_CHECK_ARG(x && dy && dw && rows > 0 && Cin > 0 && Cout > 0 && ldw >= Cin);
+    return conv1_bwd_weight_impl(x, Cin, dy, Cout, dw, ldw, dbias, rows, dtype, true, accumulate != 0, as_stream(stream));
 }

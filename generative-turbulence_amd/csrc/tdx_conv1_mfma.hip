@@ -202,7 +202,9 @@ bool conv1_wgrad_mfma_supported(int Cin, int Cout) { return (Cin % 32) == 0 && (
 
 #define C1W_PLANE (C1M_ROWS * 64)  // one [256][32] bf16 plane
 
-template <int MT, int NT>  // tile = (32 MT) ci x (32 NT) co
+// TR: the result is stored as dw[co][ci] (nn.Conv3d's own layout, row stride ldw): the MFMA is issued with its
+// operands swapped, so that a lane owns one ci and the 32 lanes of a half-wave still write one 128-B run.
+template <int MT, int NT, bool TR>  // tile = (32 MT) ci x (32 NT) co
 __global__ void __launch_bounds__(256)
 conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restrict__ dy, int Cout,
                         float* __restrict__ dw, int ldw, float* __restrict__ dbias, int64_t rows, int nsplit,
@@ -295,7 +297,8 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfv[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfv[n], af[m], acc[m][n], 0, 0, 0)
+                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfv[n], acc[m][n], 0, 0, 0);
         }
     }
     const int r = lane & 31, hh = lane >> 5;
@@ -305,8 +308,11 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int ci = ci0 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                atomicAdd(&dw[(size_t)ci * ldw + co0 + n * 32 + r], acc[m][n][i]);
+                const int q = (i & 3) + 8 * (i >> 2) + 4 * hh;  // the tile row this accumulator register holds
+                if (TR)
+                    atomicAdd(&dw[(size_t)(co0 + n * 32 + q) * ldw + ci0 + m * 32 + r], acc[m][n][i]);
+                else
+                    atomicAdd(&dw[(size_t)(ci0 + m * 32 + q) * ldw + co0 + n * 32 + r], acc[m][n][i]);
             }
     if (do_bias) {
         // threads with equal (tid & 3, (tid >> 2) % NT) hold partial sums of the same 8 channels
@@ -326,7 +332,7 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
 }
 
 int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
-                            int64_t rows, hipStream_t st) {
+                            int64_t rows, bool transposed, hipStream_t st) {
     const int MT = (Cin % 64 == 0) ? 2 : 1, NT = (Cout % 64 == 0) ? 2 : 1;
     const int n_ci = Cin / (32 * MT), n_co = Cout / (32 * NT);
     const int ntiles = n_ci * n_co;
@@ -337,13 +343,16 @@ int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, fl
     if (nsplit > nchunks) nsplit = (int)nchunks;
     if (nsplit < 1) nsplit = 1;
     dim3 grid((unsigned)(ntiles * nsplit));
-#define C1W_LAUNCH(M, N)                                                                                          \
-    hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<M, N>), grid, dim3(256), 0, st, (const bf16*)x, Cin, (const bf16*)dy, \
+#define C1W_LAUNCH(M, N, T)                                                                                          \
+    hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<M, N, T>), grid, dim3(256), 0, st, (const bf16*)x, Cin, (const bf16*)dy, \
                        Cout, dw, ldw, dbias, rows, nsplit, n_ci)
-    if (MT == 2 && NT == 2) C1W_LAUNCH(2, 2);
-    else if (MT == 2) C1W_LAUNCH(2, 1);
-    else if (NT == 2) C1W_LAUNCH(1, 2);
-    else C1W_LAUNCH(1, 1);
+#define C1W_PICK(T)                           \
+    if (MT == 2 && NT == 2) C1W_LAUNCH(2, 2, T); \
+    else if (MT == 2) C1W_LAUNCH(2, 1, T);       \
+    else if (NT == 2) C1W_LAUNCH(1, 2, T);       \
+    else C1W_LAUNCH(1, 1, T)
+    if (transposed) { C1W_PICK(true); } else { C1W_PICK(false); }
+#undef C1W_PICK
 #undef C1W_LAUNCH
     return tdx_launch_status();
 }

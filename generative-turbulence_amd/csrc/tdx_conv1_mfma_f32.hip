@@ -130,9 +130,9 @@ int conv1_mfma_f32_fwd_launch(const void* x1, int C1, const void* x2, int C2, co
 #define F1W_CI 128                // input channels per workgroup (4 waves x 32)
 #define F1W_XP (F1W_CI + 32)      // x tile pitch
 
-bool conv1_wgrad_mfma_f32_supported(int Cin, int Cout, int ldw) { return (Cin % 32) == 0 && (Cout % 32) == 0 && ldw >= Cout; }
+bool conv1_wgrad_mfma_f32_supported(int Cin, int Cout) { return (Cin % 32) == 0 && (Cout % 32) == 0; }
 
-template <int NT>
+template <int NT, bool TR>  // TR: dw[co][ci] (row stride ldw), MFMA operands swapped so that a lane owns one ci
 __global__ void __launch_bounds__(256, 2)
 conv1_f32_mfma_wgrad_kernel(const float* __restrict__ x, int Cin, const float* __restrict__ dy, int Cout,
                             float* __restrict__ dw, int ldw, float* __restrict__ dbias, int64_t rows, int64_t rows_per_split) {
@@ -201,7 +201,8 @@ conv1_f32_mfma_wgrad_kernel(const float* __restrict__ x, int Cin, const float* _
                 const float a = xa[2 * i * F1W_XP];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, gb[2 * i * GP + nt * 32], acc[nt], 0, 0, 0);
+                    acc[nt] = TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(gb[2 * i * GP + nt * 32], a, acc[nt], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(a, gb[2 * i * GP + nt * 32], acc[nt], 0, 0, 0);
             }
         }
     }
@@ -211,8 +212,11 @@ conv1_f32_mfma_wgrad_kernel(const float* __restrict__ x, int Cin, const float* _
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int ci = ci_blk + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                atomicAdd(&dw[(int64_t)ci * ldw + co0 + nt * 32 + r], acc[nt][i]);
+                const int q = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                if (TR)
+                    atomicAdd(&dw[(int64_t)(co0 + nt * 32 + q) * ldw + ci_blk + wave * 32 + r], acc[nt][i]);
+                else
+                    atomicAdd(&dw[(int64_t)(ci_blk + wave * 32 + q) * ldw + co0 + nt * 32 + r], acc[nt][i]);
             }
     }
     if (do_bias) {
@@ -231,7 +235,7 @@ conv1_f32_mfma_wgrad_kernel(const float* __restrict__ x, int Cin, const float* _
 }
 
 int conv1_wgrad_mfma_f32_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
-                                int64_t rows, hipStream_t st) {
+                                int64_t rows, bool transposed, hipStream_t st) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const int nblk = ceil_div(Cin, F1W_CI), nco = Cout / (32 * NT);
     // ~1024 workgroups overall (two per CU resident), each at least 8 slices long
@@ -243,11 +247,13 @@ int conv1_wgrad_mfma_f32_launch(const void* x, int Cin, const void* dy, int Cout
     rps = ceil_div(rps, (int64_t)F1W_RS) * F1W_RS;
     nsplit = ceil_div(rows, rps);
     dim3 grid((unsigned)nsplit, nblk, nco);
-    if (NT == 2)
-        hipLaunchKernelGGL(conv1_f32_mfma_wgrad_kernel<2>, grid, dim3(256), 0, st, (const float*)x, Cin, (const float*)dy, Cout,
-                           dw, ldw, dbias, rows, rps);
-    else
-        hipLaunchKernelGGL(conv1_f32_mfma_wgrad_kernel<1>, grid, dim3(256), 0, st, (const float*)x, Cin, (const float*)dy, Cout,
-                           dw, ldw, dbias, rows, rps);
+#define F1W_LAUNCH(N, T)                                                                                                  \
+    hipLaunchKernelGGL((conv1_f32_mfma_wgrad_kernel<N, T>), grid, dim3(256), 0, st, (const float*)x, Cin, (const float*)dy, \
+                       Cout, dw, ldw, dbias, rows, rps)
+    if (NT == 2 && transposed) F1W_LAUNCH(2, true);
+    else if (NT == 2) F1W_LAUNCH(2, false);
+    else if (transposed) F1W_LAUNCH(1, true);
+    else F1W_LAUNCH(1, false);
+#undef F1W_LAUNCH
     return tdx_launch_status();
 }

@@ -32,39 +32,73 @@ __global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ w
         if (wb) stf(wb + wp_index(lb, 26 - tap, co, ci, Cout, Cin), v);
     }
 }
-// Tiled variant for the case that both operands use the MFMA layout: a workgroup owns a
-// 16 (co) x 16 (ci) tile, reads its 16 runs of 16*27 contiguous floats, and writes, per tap, one
-// 512-B run of wf ([ci/16][tap][co][16 ci]) and one of wb ([co/16][26-tap][ci][16 co]).
-__global__ void __launch_bounds__(256)
-conv3_pack_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wb, int Cin, int Cout) {
-    __shared__ float t[16][16 * 27 + 1];  // [co][ci*27 + tap]
-    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
+// Tiled pack for the case that both operands use the MFMA layout: a workgroup owns a 16 (co) x 16 (ci) tile, reads
+// its 16 runs of 16*27 contiguous floats, and writes, per tap, one 512-B run of wf ([ci/16][tap][co][16 ci]) and one
+// of wb ([co/16][26-tap][ci][16 co]); per tap 16 rows x 2 halves of 8 packed values (one 16-B store each): 32 threads
+// per tap, 8 taps per pass.  SPLIT: fp32 tensors' split-precision operands, a hi and a lo image (hi = bf16(v),
+// lo = bf16(v - hi)) 27 Cin Cout elements apart.
+template <bool SPLIT>
+__device__ __forceinline__ void conv3_pack_tile(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wb,
+                                                int Cin, int Cout, int ci0, int co0, float (*t)[16 * 27 + 1]) {
     const int tid = threadIdx.x;
+    const int64_t n = (int64_t)Cout * Cin * 27;
     for (int i = tid; i < 16 * 432; i += 256) {
         const int co = i / 432, r = i - co * 432;
         t[co][r] = w[((int64_t)(co0 + co) * Cin + ci0) * 27 + r];
     }
     __syncthreads();
-    // per tap 16 rows x 2 halves of 8 packed values (one 16-B store each): 32 threads per tap, 8 taps per pass
     const int row = (tid >> 1) & 15, half = tid & 1, tsub = tid >> 5;
-    for (int tap = tsub; tap < 27; tap += 8) {
-        if (wf) {  // row = co, k = ci
-            unsigned u[4];
+    auto put = [&](bf16* dst, int64_t j, const float* v) {
+        unsigned h[4], l[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                u[j] = pack_bf16x2(t[row][(half * 8 + 2 * j) * 27 + tap], t[row][(half * 8 + 2 * j + 1) * 27 + tap]);
-            *reinterpret_cast<uint4*>(wf + ((((int64_t)(ci0 >> 4) * 27 + tap) * Cout + co0 + row) << 4) + half * 8) =
-                make_uint4(u[0], u[1], u[2], u[3]);
+        for (int q = 0; q < 4; ++q) {
+            h[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
+            if (SPLIT)
+                l[q] = pack_bf16x2(v[2 * q] - __uint_as_float(h[q] << 16), v[2 * q + 1] - __uint_as_float(h[q] & 0xffff0000u));
+        }
+        *reinterpret_cast<uint4*>(dst + j) = make_uint4(h[0], h[1], h[2], h[3]);
+        if (SPLIT) *reinterpret_cast<uint4*>(dst + n + j) = make_uint4(l[0], l[1], l[2], l[3]);
+    };
+    for (int tap = tsub; tap < 27; tap += 8) {
+        float v[8];
+        if (wf) {  // row = co, k = ci
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = t[row][(half * 8 + q) * 27 + tap];
+            put(wf, ((((int64_t)(ci0 >> 4) * 27 + tap) * Cout + co0 + row) << 4) + half * 8, v);
         }
         if (wb) {  // row = ci, k = co
-            unsigned u[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                u[j] = pack_bf16x2(t[half * 8 + 2 * j][row * 27 + tap], t[half * 8 + 2 * j + 1][row * 27 + tap]);
-            *reinterpret_cast<uint4*>(wb + ((((int64_t)(co0 >> 4) * 27 + (26 - tap)) * Cin + ci0 + row) << 4) + half * 8) =
-                make_uint4(u[0], u[1], u[2], u[3]);
+            for (int q = 0; q < 8; ++q) v[q] = t[half * 8 + q][row * 27 + tap];
+            put(wb, ((((int64_t)(co0 >> 4) * 27 + (26 - tap)) * Cin + ci0 + row) << 4) + half * 8, v);
         }
     }
+}
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(256)
+conv3_pack_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wb, int Cin, int Cout) {
+    __shared__ float t[16][16 * 27 + 1];  // [co][ci*27 + tap]
+    conv3_pack_tile<SPLIT>(w, wf, wb, Cin, Cout, blockIdx.x * 16, blockIdx.y * 16, t);
+}
+
+// the same over several weights in one launch (tdx_conv3_pack_weights): block -> (job, tile)
+#define PACK_MAX_JOBS 32
+struct PackTable {
+    const float* w[PACK_MAX_JOBS];
+    bf16* wf[PACK_MAX_JOBS];
+    bf16* wb[PACK_MAX_JOBS];
+    int Cin[PACK_MAX_JOBS], Cout[PACK_MAX_JOBS];
+    int first[PACK_MAX_JOBS + 1];  // first block of job i
+    int n;
+};
+template <bool SPLIT>
+__global__ void __launch_bounds__(256)
+conv3_pack_tiled_many_kernel(PackTable tab) {
+    __shared__ float t[16][16 * 27 + 1];
+    int j = 0;
+    while (j + 1 < tab.n && (int)blockIdx.x >= tab.first[j + 1]) ++j;
+    const int tile = blockIdx.x - tab.first[j], ncx = tab.Cin[j] / 16;
+    conv3_pack_tile<SPLIT>(tab.w[j], tab.wf[j], tab.wb[j], tab.Cin[j], tab.Cout[j], (tile % ncx) * 16, (tile / ncx) * 16, t);
 }
 
 // split-precision operands (tdx_conv3_mfma_split.hip): hi = bf16(v), lo = bf16(v - hi), two MFMA-layout images
@@ -92,38 +126,6 @@ __global__ void conv3_pack_split_kernel(const float* __restrict__ w, bf16* __res
     }
 }
 
-// tiled variant of the split pack (both operands split, Cin % 16 == 0 and Cout % 16 == 0): as
-// conv3_pack_tiled_kernel, writing a hi and a lo image
-__global__ void __launch_bounds__(256)
-conv3_pack_split_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wb, int Cin, int Cout) {
-    __shared__ float t[16][16 * 27 + 1];  // [co][ci*27 + tap]
-    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * 16;
-    const int tid = threadIdx.x;
-    const int64_t n = (int64_t)Cout * Cin * 27;
-    for (int i = tid; i < 16 * 432; i += 256) {
-        const int co = i / 432, r = i - co * 432;
-        t[co][r] = w[((int64_t)(co0 + co) * Cin + ci0) * 27 + r];
-    }
-    __syncthreads();
-    const int row = tid >> 4, k = tid & 15;
-    for (int tap = 0; tap < 27; ++tap) {
-        {   // wf: row = co, k = ci
-            const float v = t[row][k * 27 + tap];
-            const bf16 hi = __float2bfloat16(v);
-            const int64_t j = ((((int64_t)(ci0 >> 4) * 27 + tap) * Cout + co0 + row) << 4) + k;
-            wf[j] = hi;
-            wf[n + j] = __float2bfloat16(v - __bfloat162float(hi));
-        }
-        {   // wb: row = ci, k = co
-            const float v = t[k][row * 27 + tap];
-            const bf16 hi = __float2bfloat16(v);
-            const int64_t j = ((((int64_t)(co0 >> 4) * 27 + (26 - tap)) * Cin + ci0 + row) << 4) + k;
-            wb[j] = hi;
-            wb[n + j] = __float2bfloat16(v - __bfloat162float(hi));
-        }
-    }
-}
-
 extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream) {
     TDX_CHECK_ARG(w && (wf || wb) && Cin > 0 && Cout > 0);
     const int64_t n = (int64_t)Cout * Cin * 27;
@@ -133,7 +135,7 @@ extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin
         void* sf = (wf && conv3_mfma_split_supported(Cin, 0, Cout)) ? wf : nullptr;
         void* sb = (wb && conv3_mfma_split_supported(Cout, 0, Cin)) ? wb : nullptr;
         if (sf && sb) {
-            hipLaunchKernelGGL(conv3_pack_split_tiled_kernel, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
+            hipLaunchKernelGGL(conv3_pack_tiled_kernel<true>, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
                                (bf16*)sf, (bf16*)sb, Cin, Cout);
         } else if (sf || sb) {
             int grid = (int)min((int64_t)1024, (n + 255) / 256);
@@ -147,7 +149,7 @@ extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin
     }
     const int lf = conv3_layout_kc(dtype, Cin, Cout), lb = conv3_layout_kc(dtype, Cout, Cin);
     if (dtype == TDX_BF16 && (lf || !wf) && (lb || !wb) && (Cin % 16) == 0 && (Cout % 16) == 0) {
-        hipLaunchKernelGGL(conv3_pack_tiled_kernel, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
+        hipLaunchKernelGGL(conv3_pack_tiled_kernel<false>, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
                            (bf16*)wf, (bf16*)wb, Cin, Cout);
         return tdx_launch_status();
     }
@@ -155,6 +157,91 @@ extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv3_pack_kernel<T>), dim3(grid), dim3(256), 0, as_stream(stream),
                                                   w, (T*)wf, (T*)wb, Cin, Cout, lf, lb));
     return tdx_launch_status();
+}
+
+// Several weights in one call: the jobs whose both operands take the tiled kernel (the MFMA layouts, Cin % 16 ==
+// Cout % 16 == 0 -- every 3x3x3 conv of the U-Net but the first) go out in launches of up to PACK_MAX_JOBS, the rest
+// one by one through tdx_conv3_pack_weight.
+extern "C" int tdx_conv3_pack_weights(const TdxPackJob* jobs, int n, int dtype, void* stream) {
+    TDX_CHECK_ARG(jobs && n > 0);
+    PackTable tab;
+    tab.n = 0;
+    tab.first[0] = 0;
+    const bool split = dtype == TDX_F32_SPLIT;
+    auto flush = [&]() -> int {
+        if (tab.n == 0) return TDX_OK;
+        if (split)
+            hipLaunchKernelGGL(conv3_pack_tiled_many_kernel<true>, dim3(tab.first[tab.n]), dim3(256), 0, as_stream(stream), tab);
+        else
+            hipLaunchKernelGGL(conv3_pack_tiled_many_kernel<false>, dim3(tab.first[tab.n]), dim3(256), 0, as_stream(stream), tab);
+        tab.n = 0;
+        return tdx_launch_status();
+    };
+    for (int i = 0; i < n; ++i) {
+        const TdxPackJob& j = jobs[i];
+        TDX_CHECK_ARG(j.w && j.wf && j.wb && j.Cin > 0 && j.Cout > 0);
+        bool tiled = (j.Cin % 16) == 0 && (j.Cout % 16) == 0;
+        if (split)
+            tiled = tiled && conv3_mfma_split_supported(j.Cin, 0, j.Cout) && conv3_mfma_split_supported(j.Cout, 0, j.Cin);
+        else
+            tiled = tiled && dtype == TDX_BF16 && conv3_layout_kc(dtype, j.Cin, j.Cout) && conv3_layout_kc(dtype, j.Cout, j.Cin);
+        if (!tiled) {
+            int rc = tdx_conv3_pack_weight(j.w, j.wf, j.wb, j.Cin, j.Cout, dtype, stream);
+            if (rc != TDX_OK) return rc;
+            continue;
+        }
+        const int k = tab.n++;
+        tab.w[k] = j.w; tab.wf[k] = (bf16*)j.wf; tab.wb[k] = (bf16*)j.wb; tab.Cin[k] = j.Cin; tab.Cout[k] = j.Cout;
+        tab.first[k + 1] = tab.first[k] + (j.Cin / 16) * (j.Cout / 16);
+        if (tab.n == PACK_MAX_JOBS) {
+            int rc = flush();
+            if (rc != TDX_OK) return rc;
+        }
+    }
+    return flush();
+}
+
+// Transposed copies of several fp32 matrices in one launch (the 1x1 conv weights (Cout, Cin) -> the [Cin][Cout]
+// operand of tdx_conv1_fwd): dst[c][r] = src[r][c].
+struct TransposeTable {
+    const float* src[PACK_MAX_JOBS];
+    float* dst[PACK_MAX_JOBS];
+    int rows[PACK_MAX_JOBS], cols[PACK_MAX_JOBS];
+    int first[PACK_MAX_JOBS + 1];
+    int n;
+};
+__global__ void __launch_bounds__(256)
+transpose_many_kernel(TransposeTable tab) {
+    __shared__ float t[32][33];
+    int j = 0;
+    while (j + 1 < tab.n && (int)blockIdx.x >= tab.first[j + 1]) ++j;
+    const int R = tab.rows[j], C = tab.cols[j];
+    const int tile = blockIdx.x - tab.first[j], ntc = (C + 31) / 32;
+    const int r0 = (tile / ntc) * 32, c0 = (tile % ntc) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < C) t[i][tx] = tab.src[j][(int64_t)(r0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) tab.dst[j][(int64_t)(c0 + i) * R + r0 + tx] = t[tx][i];
+}
+extern "C" int tdx_transpose_many(const TdxTransposeJob* jobs, int n, void* stream) {
+    TDX_CHECK_ARG(jobs && n > 0);
+    for (int lo = 0; lo < n; lo += PACK_MAX_JOBS) {
+        TransposeTable tab;
+        tab.n = min(PACK_MAX_JOBS, n - lo);
+        tab.first[0] = 0;
+        for (int k = 0; k < tab.n; ++k) {
+            const TdxTransposeJob& j = jobs[lo + k];
+            TDX_CHECK_ARG(j.src && j.dst && j.rows > 0 && j.cols > 0);
+            tab.src[k] = j.src; tab.dst[k] = j.dst; tab.rows[k] = j.rows; tab.cols[k] = j.cols;
+            tab.first[k + 1] = tab.first[k] + ceil_div(j.rows, 32) * ceil_div(j.cols, 32);
+        }
+        hipLaunchKernelGGL(transpose_many_kernel, dim3(tab.first[tab.n]), dim3(256), 0, as_stream(stream), tab);
+        int rc = tdx_launch_status();
+        if (rc != TDX_OK) return rc;
+    }
+    return TDX_OK;
 }
 
 // dwp [27][Cin][Cout] f32 -> dw (Cout, Cin, 27) f32, through a 16 (ci) x 16 (co) LDS tile so that

@@ -368,25 +368,28 @@ gn_bwd_group_kernel(const float* __restrict__ partial, double* __restrict__ acc,
         gsum[2 * i + 1] = (float)((sB[0] + sB[1] + sB[2] + sB[3]) / n);
     }
 }
-__global__ void gn_bwd_param_kernel(const double* __restrict__ acc, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, const float* __restrict__ scale,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dscale,
-                                    float* __restrict__ dshift, int B, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double dg = 0.0, db = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const double P = acc[((size_t)b * C + c) * 2], Q = acc[((size_t)b * C + c) * 2 + 1];
-        const double f = scale ? 1.0 + (double)scale[(size_t)b * C + c] : 1.0;
-        dg += f * Q;
-        db += f * P;
-        if (dscale) {
-            dshift[(size_t)b * C + c] = (float)P;
-            dscale[(size_t)b * C + c] = (float)((double)gamma[c] * Q + (double)beta[c] * P);
+// Parameter gradients from the channel sums: dgamma / dbeta summed over the samples, dscale / dshift per sample.
+// Runs as the prologue of ONE workgroup of the apply pass (block (0, 0)) instead of as a launch of its own: at 22
+// GroupNorm backwards per training step the launch count is what these tiny kernels cost.
+__device__ __forceinline__ void gn_bwd_params(const double* __restrict__ acc, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, const float* __restrict__ scale,
+                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                              float* __restrict__ dscale, float* __restrict__ dshift, int B, int C) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double dg = 0.0, db = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const double P = acc[((size_t)b * C + c) * 2], Q = acc[((size_t)b * C + c) * 2 + 1];
+            const double f = scale ? 1.0 + (double)scale[(size_t)b * C + c] : 1.0;
+            dg += f * Q;
+            db += f * P;
+            if (dscale) {
+                dshift[(size_t)b * C + c] = (float)P;
+                dscale[(size_t)b * C + c] = (float)((double)gamma[c] * Q + (double)beta[c] * P);
+            }
         }
+        dgamma[c] = (float)dg;
+        dbeta[c] = (float)db;
     }
-    dgamma[c] = (float)dg;
-    dbeta[c] = (float)db;
 }
 
 template <typename T, bool ACT>
@@ -394,7 +397,9 @@ __global__ void __launch_bounds__(GN_THREADS)
 gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ gsum, T* __restrict__ dx, int64_t V,
-                    int C, int G) {
+                    int C, int G, const double* __restrict__ acc, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                    float* __restrict__ dscale, float* __restrict__ dshift) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) gn_bwd_params(acc, gamma, beta, scale, dgamma, dbeta, dscale, dshift, gridDim.y, C);
     const int b = blockIdx.y;
     const int L = C >> 3;
     const int rows = GN_THREADS / L;
@@ -471,15 +476,13 @@ extern "C" int tdx_gn_bwd(const void* x, const void* dy, const float* stats, con
                                                       (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift,
                                                       partial, V, C, G));
     hipLaunchKernelGGL(gn_bwd_group_kernel, dim3(B * G), dim3(256), 0, st, partial, acc, gamma, scale, gsum, nblk, C, G, V);
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, acc, gamma, beta, scale, dgamma,
-                       dbeta, dscale, dshift, B, C);
     if (act)
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, true>), grid, dim3(GN_THREADS), 0, st,
                                                       (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, gsum,
-                                                      (T*)dx, V, C, G));
+                                                      (T*)dx, V, C, G, acc, dgamma, dbeta, dscale, dshift));
     else
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, false>), grid, dim3(GN_THREADS), 0, st,
                                                       (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, gsum,
-                                                      (T*)dx, V, C, G));
+                                                      (T*)dx, V, C, G, acc, dgamma, dbeta, dscale, dshift));
     return tdx_launch_status();
 }

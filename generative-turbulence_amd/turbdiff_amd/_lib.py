@@ -32,6 +32,8 @@ SIGNATURES = {
     "tdx_nvc_to_ncv": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _vp]),
     "tdx_cast": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "tdx_conv3_pack_weight": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tdx_conv3_pack_weights": (_i, [_vp, _i, _i, _vp]),
+    "tdx_transpose_many": (_i, [_vp, _i, _vp]),
     "tdx_conv3_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_fwd_gn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_fwd_partial": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -42,6 +44,7 @@ SIGNATURES = {
     "tdx_conv3_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "tdx_conv1_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "tdx_conv1_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i64, _i, _vp]),
+    "tdx_conv1_bwd_weight_oc": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     "tdx_encode_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "tdx_encode_bwd": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),
     "tdx_decode_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
@@ -85,6 +88,14 @@ FILM_MAX_LAYERS = 32  # TDX_FILM_MAX_LAYERS
 
 class FilmLayer(C.Structure):  # TdxFilmLayer
     _fields_ = [("weight", _vp), ("bias", _vp), ("out", _vp), ("channels", _i)]
+
+
+class PackJob(C.Structure):  # TdxPackJob
+    _fields_ = [("w", _vp), ("wf", _vp), ("wb", _vp), ("Cin", _i), ("Cout", _i)]
+
+
+class TransposeJob(C.Structure):  # TdxTransposeJob
+    _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i), ("cols", _i)]
 
 
 class FilmGrad(C.Structure):  # TdxFilmGrad

@@ -16,6 +16,7 @@ in the model's compute dtype (float32 or bfloat16 storage, fp32 accumulation).
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from functools import partial
 
@@ -138,7 +139,10 @@ class ResnetBlock(nn.Module):
         films = {id(block): (2, B, dim_out) scale | shift}: the projections of all blocks computed up front in one
         launch (DenoisingModel.film_table); without it the block projects `c` itself."""
         film = films.get(id(self)) if films is not None else None
-        if film is None:
+        if film is None and os.environ.get("TDX_FILM", "1") == "0":  # A/B switch: the per-block torch ops
+            f = self.project_onto_scale_shift(c)
+            film = torch.stack((f[:, : self.dim_out], f[:, self.dim_out :]))
+        elif film is None:
             film = ops.film_projections(c, [self.project_onto_scale_shift])[0]  # (2, B, dim_out): scale, shift
         scale, shift = film[0], film[1]
         identity = isinstance(self.conv, nn.Identity)
@@ -336,9 +340,25 @@ class DenoisingModel(nn.Module):
             if hasattr(self, n):
                 yield from reversed(list(getattr(self, n).parameters()))
 
+    def prefetch_weights(self, skip_first_conv: bool):
+        """Packed operands of all 3x3x3 weights and transposed copies of all 1x1 weights the forward is about to
+        ask for, refreshed in one launch each (ops.prefetch_weights) instead of one launch per layer on first use."""
+        conv3, conv1 = [], []
+        first = self.u_net.downsampling_blocks[0].block1.conv.weight if skip_first_conv else None
+        for m in self.modules():
+            if isinstance(m, Block) and m.conv.weight is not first:
+                conv3.append(m.conv.weight)
+            elif isinstance(m, ResnetBlock) and not isinstance(m.conv, nn.Identity):
+                conv1.append(m.conv.weight)
+            elif isinstance(m, Attention):
+                conv1 += [m.to_qkv.weight, m.to_out.weight]
+        ops.prefetch_weights(conv3, conv1, self.compute_dtype)
+
     def film_table(self, c):
         """{id(block): (2, B, dim_out) [scale, shift]} for every ResnetBlock, projected from the conditioning vector
         in one launch (the reference projects inside each block, ddpm.py:191-192)."""
+        if os.environ.get("TDX_FILM", "1") == "0":
+            return None
         blocks = [m for m in self.modules() if isinstance(m, ResnetBlock)]
         films = ops.film_projections(c, [b.project_onto_scale_shift for b in blocks])
         return {id(b): f for b, f in zip(blocks, films)}
@@ -443,6 +463,7 @@ class DenoisingModel(nn.Module):
             if e is not None:
                 h = torch.cat((h, e.expand(B, -1, -1, -1, -1)), dim=-1)
         partial = getattr(encoded_local, "first_conv_partial", None) if not torch.is_grad_enabled() else None
+        self.prefetch_weights(skip_first_conv=first_conv is not None)
         films = self.film_table(c)
         h = self.u_net(h, c, first_partial=partial, first_conv=first_conv, films=films)
         h = self.decode[0](h, c, films=films)

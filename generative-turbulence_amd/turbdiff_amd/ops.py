@@ -242,6 +242,50 @@ def _packed_conv3_cin_slice(weight: torch.Tensor, lo: int, hi: int, dtype: torch
     return wf
 
 
+def _cache_fresh(key, weight) -> bool:
+    hit = _pack_cache.get(key)
+    return hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr()
+
+
+def prefetch_weights(conv3_weights, conv1_weights, dtype: torch.dtype) -> None:
+    """Refresh the packed operands of all given 3x3x3 weights (as _packed_conv3 would, one by one) and the transposed
+    copies of all given 1x1 weights (as _conv1_wt would) in ONE launch each, for those whose cached copy is stale --
+    after an optimiser step that is every weight, and a model forward would otherwise start with ~30 tiny launches.
+    The later _packed_conv3 / _conv1_wt calls then hit the cache."""
+    if os.environ.get("TDX_PREFETCH", "1") == "0":  # A/B switch: every layer packs on first use
+        return
+    code = L.pack_code(dtype)
+    jobs, keep = [], []
+    for w in conv3_weights:
+        key = (id(w), dtype, code)
+        if _cache_fresh(key, w):
+            continue
+        Cout, Cin = w.shape[0], w.shape[1]
+        src = w.detach().contiguous()
+        wf = torch.empty(27 * Cin * Cout, dtype=dtype, device=w.device)
+        wb = torch.empty(27 * Cin * Cout, dtype=dtype, device=w.device)
+        jobs.append(L.PackJob(L.ptr(src), L.ptr(wf), L.ptr(wb), Cin, Cout))
+        keep.append(src)
+        _pack_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), wf, wb)
+    if jobs:
+        L.call("tdx_conv3_pack_weights", (L.PackJob * len(jobs))(*jobs), len(jobs), code, L.stream())
+    jobs = []
+    for w in conv1_weights:
+        key = (id(w), "wt")
+        if _cache_fresh(key, w):
+            continue
+        Cout = w.shape[0]
+        src = w.detach().reshape(Cout, -1).float().contiguous()
+        wt = torch.empty((src.shape[1], Cout), dtype=torch.float32, device=w.device)
+        jobs.append(L.TransposeJob(L.ptr(src), L.ptr(wt), Cout, src.shape[1]))
+        keep.append(src)
+        _pack_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), wt, None)
+    if jobs:
+        L.call("tdx_transpose_many", (L.TransposeJob * len(jobs))(*jobs), len(jobs), L.stream())
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+
+
 def conv3_partial_supported(x, weight, n_lead: int) -> bool:
     """tdx_conv3_fwd_partial: bf16 MFMA path on the leading n_lead input channels."""
     return (x.dtype == torch.bfloat16 and n_lead % 16 == 0 and weight.shape[0] % 32 == 0 and x.shape[-1] % 8 == 0
@@ -341,6 +385,20 @@ def _conv1_wt(weight: torch.Tensor) -> torch.Tensor:
     return wt
 
 
+def _conv1_weight_grad(x1, C1, x2, C2, gy, Cout, has_bias, rows, code, st):
+    """(dW (Cout, C1 + C2), dbias (Cout) or None) of a 1x1 conv in nn.Conv3d's own layout (tdx_conv1_bwd_weight_oc):
+    one zeroed allocation for both, no transposition afterwards."""
+    Cin = C1 + C2
+    off = (Cout * Cin + 63) // 64 * 64  # the bias gradient starts on a 256-B boundary
+    buf = torch.zeros(off + (Cout if has_bias else 0), dtype=torch.float32, device=gy.device)
+    gw = buf[: Cout * Cin].view(Cout, Cin)
+    gb = buf[off:] if has_bias else None
+    L.call("tdx_conv1_bwd_weight_oc", L.ptr(x1), C1, L.ptr(gy), Cout, gw.data_ptr(), Cin, L.ptr(gb), 1, rows, code, st)
+    if x2 is not None:
+        L.call("tdx_conv1_bwd_weight_oc", L.ptr(x2), C2, L.ptr(gy), Cout, gw.data_ptr() + 4 * C1, Cin, None, 1, rows, code, st)
+    return gw, gb
+
+
 class _Conv1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, weight, bias, add):
@@ -381,12 +439,8 @@ class _Conv1(torch.autograd.Function):
             gx2 = torch.empty_like(x2)
             L.call("tdx_conv1_fwd", L.ptr(gy), Cout, None, 0, w2.data_ptr() + 4 * C1, Cin, None, None, L.ptr(gx2), rows, C2, code, st)
         if ctx.needs_input_grad[2]:
-            gwt = torch.empty((Cin, Cout), dtype=torch.float32, device=dev)
-            gb = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
-            L.call("tdx_conv1_bwd_weight", L.ptr(x1), C1, L.ptr(gy), Cout, gwt.data_ptr(), Cout, L.ptr(gb), rows, code, st)
-            if x2 is not None:
-                L.call("tdx_conv1_bwd_weight", L.ptr(x2), C2, L.ptr(gy), Cout, gwt.data_ptr() + 4 * C1 * Cout, Cout, None, rows, code, st)
-            gw = gwt.t().reshape(ctx.wshape)
+            gw, gb = _conv1_weight_grad(x1, C1, x2, C2, gy, Cout, ctx.has_bias, rows, code, st)
+            gw = gw.view(ctx.wshape)
         return gx1, gx2, gw, gb, (gy if ctx.has_add else None)
 
 
@@ -853,13 +907,8 @@ class _ResnetBlock(torch.autograd.Function):
             if x2 is not None:
                 L.call("tdx_conv1_fwd", L.ptr(gy), Cout, None, 0, wr2.data_ptr() + 4 * C1, Cin, None, L.ptr(t2), L.ptr(gx2),
                        B * V, C2, code, st)
-            dwt = f32(Cin, Cout)
-            dbr = f32(Cout) if hbr else None
-            L.call("tdx_conv1_bwd_weight", L.ptr(x1), C1, L.ptr(gy), Cout, dwt.data_ptr(), Cout, L.ptr(dbr), B * V, code, st)
-            if x2 is not None:
-                L.call("tdx_conv1_bwd_weight", L.ptr(x2), C2, L.ptr(gy), Cout, dwt.data_ptr() + 4 * C1 * Cout, Cout, None,
-                       B * V, code, st)
-            dwr = dwt.t().reshape(wrs)
+            dwr, dbr = _conv1_weight_grad(x1, C1, x2, C2, gy, Cout, hbr, B * V, code, st)
+            dwr = dwr.view(wrs)
         return (gx1, gx2, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None, None)
 
 

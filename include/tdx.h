@@ -87,6 +87,24 @@ int tdx_cast(const void* x, void* y, int64_t n, int dtype_in, int dtype_out, voi
  * kernels (K % 8 == 0, N % 32 == 0), else [27][K][N]; dtype = TDX_F32_SPLIT: two bf16 images (hi, lo) of the
  * bf16 MFMA layout in the fp32 operand's buffer where K % 16 == 0 and N % 32 == 0, else the fp32 layouts. */
 int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream);
+/* The same for n weights (`jobs`: HOST array; wf and wb both required): the weights whose two operands use the
+ * MFMA layouts are packed by one launch per 32 jobs -- after an optimiser step a training step re-packs all its
+ * 3x3x3 weights, and 21 launches of ~12 us were what that cost. */
+typedef struct {
+    const float* w;
+    void* wf;
+    void* wb;
+    int Cin, Cout;
+} TdxPackJob;
+int tdx_conv3_pack_weights(const TdxPackJob* jobs, int n, int dtype, void* stream);
+/* dst[c][r] = src[r][c] (f32) for n matrices in one launch (`jobs`: HOST array): the [Cin][Cout] operands of
+ * tdx_conv1_fwd from nn.Conv3d(k=1) weights (Cout, Cin). */
+typedef struct {
+    const float* src;
+    float* dst;
+    int rows, cols; /* of src */
+} TdxTransposeJob;
+int tdx_transpose_many(const TdxTransposeJob* jobs, int n, void* stream);
 
 /* y[b,v,:] = bias + sum_tap sum_ci x[b, clamp(v+tap), ci] * wf[tap][ci][:]
  * The input may be the channel concatenation of two tensors (x1: C1 channels, x2: C2
@@ -152,6 +170,11 @@ int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, const float* w
  * Overwrites (buffers are zeroed inside).  x has Cin channels (call twice for a concat). */
 int tdx_conv1_bwd_weight(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
                          int64_t rows, int dtype, void* stream);
+/* The same sums stored as dw[co][ci] ([Cout][ldw] f32, ldw >= Cin) -- nn.Conv3d's own weight layout, so the result
+ * IS the parameter gradient (for a concat call twice, the second time with dw + C1).  accumulate != 0: adds into
+ * dw / dbias as they are (the caller zeroed them, e.g. as one allocation) instead of zeroing inside. */
+int tdx_conv1_bwd_weight_oc(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
+                            int accumulate, int64_t rows, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ model boundary ------ */
 /* encode_x / encode_c_local (ddpm.py:433,436,495-501) fused with NCDHW -> NDHWC and the

@@ -845,3 +845,75 @@ def test_film_projections_match_linear(B, T, chans):
             assert float(l.weight.grad.abs().max()) == 0.0 and float(l.bias.grad.abs().max()) == 0.0
             continue
         assert rel_l2(l.weight.grad.cpu(), w.grad) < 1e-5 and rel_l2(l.bias.grad.cpu(), b.grad) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16", "f32s", "f32"])
+def test_prefetch_weights_equals_one_by_one(mode):
+    """ops.prefetch_weights (tdx_conv3_pack_weights + tdx_transpose_many: all weights of a model in one launch each)
+    leaves exactly the cache entries _packed_conv3 / _conv1_wt build one by one -- bit for bit, for the MFMA layouts,
+    the shapes that fall back to the plain pack kernel, and more weights than one launch table holds."""
+    from turbdiff_amd import _lib as L, ops
+
+    d = dev()
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    prev = L._conv_impl_override
+    L.set_conv_impl("split" if mode == "f32s" else None)
+    try:
+        g = torch.Generator(device=d).manual_seed(11)
+        shapes = [(64, 64), (32, 128), (512, 256), (16, 48), (24, 8), (4, 64)] + [(32, 32)] * 35
+        w3 = [torch.randn(co, ci, 3, 3, 3, device=d, generator=g) for co, ci in shapes]
+        w1 = [torch.randn(co, ci, 1, 1, 1, device=d, generator=g) for co, ci in [(64, 32), (96, 40), (7, 33), (512, 1024)]]
+        ref3 = [tuple(t.clone() for t in ops._packed_conv3(w, dt)) for w in w3]
+        ref1 = [ops._conv1_wt(w).clone() for w in w1]
+        ops._pack_cache.clear()
+        ops.prefetch_weights(w3, w1, dt)
+        for w, (rf, rb) in zip(w3, ref3):
+            hit = ops._pack_cache[(id(w), dt, L.pack_code(dt))]
+            assert torch.equal(hit[3].view(torch.uint8), rf.view(torch.uint8)) and torch.equal(hit[4].view(torch.uint8), rb.view(torch.uint8))
+            got = ops._packed_conv3(w, dt)
+            assert got[0] is hit[3] and got[1] is hit[4]  # the later per-layer call is a cache hit
+        for w, r in zip(w1, ref1):
+            assert torch.equal(ops._conv1_wt(w), r)
+        with torch.no_grad():  # an in-place update makes that entry stale: it alone is packed again
+            w3[1].add_(1.0)
+        ops.prefetch_weights(w3, w1, dt)
+        assert torch.equal(ops._packed_conv3(w3[1], dt)[0].view(torch.uint8), _fresh_pack(w3[1], dt)[0].view(torch.uint8))
+    finally:
+        L.set_conv_impl(prev)
+        ops._pack_cache.clear()
+
+
+def _fresh_pack(w, dt):
+    from turbdiff_amd import _lib as L
+
+    Cout, Cin = w.shape[:2]
+    wf = torch.empty(27 * Cin * Cout, dtype=dt, device=w.device)
+    wb = torch.empty_like(wf)
+    L.call("tdx_conv3_pack_weight", L.ptr(w.detach().contiguous()), L.ptr(wf), L.ptr(wb), Cin, Cout, L.pack_code(dt), L.stream())
+    return wf, wb
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("C1,C2,Cout", [(64, 0, 128), (256, 256, 128), (32, 0, 4), (40, 24, 72), (1024, 0, 256)])
+def test_conv1_weight_gradient_in_parameter_layout(dt, C1, C2, Cout):
+    """tdx_conv1_bwd_weight_oc: dW stored as (Cout, Cin) -- the parameter's own layout -- and the bias gradient, against
+    the fp64 sums and against tdx_conv1_bwd_weight's [Cin][Cout] result; two-input form writes column blocks."""
+    from turbdiff_amd import _lib as L, ops
+
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(5)
+    rows = 6 * 11 * 7 * 5
+    x1 = torch.randn(rows, C1, device=d, generator=g).to(dt)
+    x2 = torch.randn(rows, C2, device=d, generator=g).to(dt) if C2 else None
+    gy = torch.randn(rows, Cout, device=d, generator=g).to(dt)
+    gw, gb = ops._conv1_weight_grad(x1, C1, x2, C2, gy, Cout, True, rows, L.dtype_code(dt), L.stream())
+    x = torch.cat([x1] + ([x2] if C2 else []), dim=1).double().cpu()
+    ref = gy.double().cpu().t() @ x
+    tol = 1e-5 if dt == torch.float32 else 1e-5  # fp32 accumulation of exact products either way
+    assert gw.shape == (Cout, C1 + C2) and gw.is_contiguous()
+    assert rel_l2(gw.cpu(), ref) < tol and rel_l2(gb.cpu(), gy.double().cpu().sum(0)) < tol
+    old = torch.empty(C1, Cout, device=d)
+    L.call("tdx_conv1_bwd_weight", L.ptr(x1), C1, L.ptr(gy), Cout, L.ptr(old), Cout, None, rows, L.dtype_code(dt), L.stream())
+    assert rel_l2(gw[:, :C1].t().cpu(), old.cpu()) < 1e-6

@@ -32,7 +32,8 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+STACKS = len(sys.argv) > 2 and sys.argv[2] == 'stacks'
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=STACKS, record_shapes=STACKS) as prof:
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -50,3 +51,19 @@ tot = sum(v[1] for v in rows.values()) / 2
 print(f"kernels < 8 us: {sum(v[0] for v in rows.values()) / 2:.0f} launches, {tot:.0f} us per step")
 for (op, kern), (n, t) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"{n / 2:6.1f} x {t / n:5.1f} us = {t / 2:7.1f} us/step   {op[:38]:38s} {kern}")
+
+if STACKS:  # where do the aten::copy_ / fill_ / add launches come from?  (python tools/small_kernel_census.py bf16 stacks)
+    sites = defaultdict(int)
+    for e in ev:
+        if e.device_type == torch.autograd.DeviceType.CUDA or not e.kernels or not e.name.startswith("aten::"):
+            continue
+        if all(k.duration >= 8.0 for k in e.kernels):
+            continue
+        frames = [f for f in (e.stack or []) if "turbdiff_amd" in f or "bench.py" in f or "autograd" in f][:3]
+        par, chain = e.cpu_parent, []
+        while par is not None and len(chain) < 3:
+            chain.append(par.name)
+            par = par.cpu_parent
+        sites[(e.name, str(e.input_shapes)[:60] + " " + " <- ".join(chain) + " " + " <- ".join(f.split("/")[-1][:60] for f in frames))] += 1
+    for (op, where), n in sorted(sites.items(), key=lambda kv: -kv[1])[:40]:
+        print(f"{n / 2:6.1f}  {op:18s} {where}")
