@@ -295,6 +295,10 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
 int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
                             int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs,
                             int* nslab_out) {
+    {   // deep U-Net levels: packed-K kernel (tdx_conv3_wgrad_small.hip); TDX_ESHAPE = not such a case
+        int rs = conv3_wgrad_small_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st, slabs, max_slabs, nslab_out);
+        if (rs != TDX_ESHAPE) return rs;
+    }
     const int Cin = C1 + C2;
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     // local axes: brick 4 x 8 x 8; the short axis goes where it leaves the fewest bricks

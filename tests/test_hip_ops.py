@@ -917,3 +917,47 @@ def test_conv1_weight_gradient_in_parameter_layout(dt, C1, C2, Cout):
     old = torch.empty(C1, Cout, device=d)
     L.call("tdx_conv1_bwd_weight", L.ptr(x1), C1, L.ptr(gy), Cout, L.ptr(old), Cout, None, rows, L.dtype_code(dt), L.stream())
     assert rel_l2(gw[:, :C1].t().cpu(), old.cpu()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # B, C1, C2, Cout, grid -- the deep levels of the shipped model and ragged / tiny relatives
+    (6, 512, 0, 512, (12, 4, 3)), (6, 256, 0, 512, (24, 8, 6)), (6, 512, 512, 256, (24, 8, 6)), (6, 256, 0, 256, (24, 8, 6)),
+    (2, 128, 0, 32, (5, 3, 1)), (3, 256, 0, 96, (7, 9, 4)), (8, 512, 0, 512, (12, 4, 3)), (1, 160, 0, 64, (13, 7, 6)),
+    (5, 128, 128, 64, (3, 17, 15)),
+])
+def test_conv3_weight_gradient_small_grid_kernel_vs_brick_kernel(case, monkeypatch):
+    """The packed-K weight-gradient kernel of the deep levels (tdx_conv3_wgrad_small.hip) against the brick kernel it
+    replaces there (row gate closed vs open) and against the fp64 sums on the smallest cases: weight and bias gradient,
+    slab and atomic merges, two inputs, ragged last slab / last sample group, K rows that are not a multiple of 16; the
+    workspace is left zero both ways."""
+    from turbdiff_amd import _lib as L
+
+    B, C1, C2, Co, (X, Y, Z) = case
+    d = dev()
+    Ci = C1 + C2
+    g = torch.Generator(device=d).manual_seed(9)
+    rn = lambda *s: torch.randn(*s, device=d, generator=g)
+    x1, x2 = rn(B, X, Y, Z, C1).bfloat16(), (rn(B, X, Y, Z, C2).bfloat16() if C2 else None)
+    gy = rn(B, X, Y, Z, Co).bfloat16()
+    st = L.stream()
+    ws = torch.zeros(L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, L.CONV_AUTO), dtype=torch.uint8, device=d)
+
+    def run(rows):
+        monkeypatch.setenv("TDX_WGRAD_SMALL_ROWS", str(rows))
+        dw, db = torch.empty(Co, Ci, 3, 3, 3, device=d), torch.empty(Co, device=d)
+        L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(dw), L.ptr(db), B, X, Y, Z, Co, L.BF16,
+               L.CONV_AUTO | L.WS_CLEAN, L.ptr(ws), st)
+        torch.cuda.synchronize()
+        assert int(ws[: (27 * Ci * Co + Co) * 4].count_nonzero()) == 0
+        return dw, db
+
+    small, brick = run(1 << 30), run(0)
+    assert torch.isfinite(small[0]).all() and torch.isfinite(small[1]).all()
+    assert rel_l2(small[0], brick[0]) < 2e-6 and rel_l2(small[1], brick[1]) < 2e-6
+    if B * X * Y * Z <= 1000:
+        xr = torch.cat([x1] + ([x2] if C2 else []), dim=-1).double().cpu().permute(0, 4, 1, 2, 3)
+        w = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        bz = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+        O.conv3_replicate(xr, w, bz).backward(gy.double().cpu().permute(0, 4, 1, 2, 3))
+        assert rel_l2(small[0].cpu(), w.grad) < 1e-5 and rel_l2(small[1].cpu(), bz.grad) < 1e-5
