@@ -70,12 +70,17 @@ def new_denoiser(timesteps=500):
                           dim=32, u_net_levels=4, norm_type="group")
 
 
-def build_model(device, timesteps=500):
+def build_model(device, dtype=None, timesteps=500):
+    """The BASELINE configs[1] diffusion; dtype (torch.bfloat16 / torch.float32) selects the compute dtype right
+    away (tools/*.py), None leaves it to set_mode."""
     from turbdiff_amd.models.ddpm import GaussianDiffusion
 
     diff = GaussianDiffusion(new_denoiser(timesteps), timesteps=timesteps, beta_schedule="log-snr-linear", loss_type="l2",
                              noise_bcs=True)
-    return diff.to(device)
+    diff = diff.to(device)
+    if dtype is not None:
+        diff.model.set_compute_dtype(dtype)
+    return diff
 
 
 def set_mode(diff, mode):
