@@ -228,6 +228,22 @@ def kernel_table(kern, K):
             for k, v in kern.items()}
 
 
+def self_launch(n):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>` as a CHILD process
+    on a free loopback port; returns its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,9 +262,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-parity-modes", action="store_true", help="skip the f32s / f32 legs of extra.parity_modes")
-    ap.add_argument("--torch-baseline", action="store_true",
-                    help="also time the same step through stock PyTorch-ROCm ops (MIOpen); adds extra.torch_rocm_reference")
+    ap.add_argument("--no-torch-baseline", action="store_true",
+                    help="skip the stock PyTorch-ROCm leg (BASELINE configs[1]: 'HIP Conv3d vs PyTorch-ROCm Conv3d': the same "
+                         "step through MIOpen conv3d / ATen ops, 2 steps bf16 autocast + 1 step fp32 -> extra.torch_rocm_reference)")
+    ap.add_argument("--torch-baseline", action="store_true", help="(default since round 3; kept for old command lines)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run) BEFORE anything in this process touches the GPU, relay rank 0's line, exit with
+        # the launcher's code.  Nothing is exec'd from a process that holds a GPU context.
+        sys.exit(self_launch(args.gpus))
 
     from turbdiff_amd import _lib, parallel
 
@@ -303,6 +327,7 @@ def main():
         return v
 
     ddp = parallel.BucketedDataParallel(diff, compress=args.compress)
+    bwd_events = []  # N > 1: (start, end) events around backward() of every timed step
 
     def run_mode(mode, steps, warmup):
         """`steps` timed training steps in `mode` -> (elapsed s (max over ranks), merged conv-kernel times, last loss)."""
@@ -312,7 +337,14 @@ def main():
 
         def train_step():
             loss, _ = diff(x, C, md, None)
-            loss.backward()
+            if ddp.timing:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                loss.backward()
+                ev[1].record()
+                bwd_events.append(ev)
+            else:
+                loss.backward()
             ddp.finish()
             if not fused_opt:
                 torch.nn.utils.clip_grad_norm_(diff.parameters(), 0.1)
@@ -322,6 +354,9 @@ def main():
 
         for _ in range(warmup):
             train_step()
+        ddp.timing = world > 1
+        bwd_events.clear()
+        ddp.exposed_ms()
         timer = _lib.KernelTimer(CONV_CALLS)
         _lib.TIMER = timer
         barrier()
@@ -331,6 +366,7 @@ def main():
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         _lib.TIMER = None
+        ddp.timing = False
         kern = merged_kernel_times(timer)
         return elapsed, kern, loss.item(), train_step
 
@@ -367,6 +403,10 @@ def main():
 
     # ---- N > 1: how much of the gradient all-reduce hides behind backward
     if world > 1 and not args.no_extra:
+        # HIP events of the timed steps themselves: backward's span on the compute stream, and what finish() then
+        # still had to wait for (the part of the all-reduce backward did not hide)
+        exposed_ev = ddp.exposed_ms()
+        bwd_ms = [a.elapsed_time(b) for a, b in bwd_events]
         ddp.enabled = False
         barrier()
         t0 = time.perf_counter()
@@ -383,9 +423,12 @@ def main():
         barrier()
         t_comm = max_over_ranks(time.perf_counter() - t0) / K
         t_step = elapsed / K
-        exposed = max(t_step - t_nocomm, 0.0)
+        exposed = max_over_ranks(sum(exposed_ev) / max(len(exposed_ev), 1)) * 1e-3
         extra["overlap"] = {"ms_step": 1e3 * t_step, "ms_step_without_allreduce": 1e3 * t_nocomm,
                             "ms_allreduce_alone": 1e3 * t_comm, "ms_exposed": 1e3 * exposed,
+                            "ms_backward": sum(bwd_ms) / max(len(bwd_ms), 1),
+                            "method": "HIP events on the compute stream around backward() and around finish()'s waits, "
+                                      "mean over the timed steps, max over ranks",
                             "hidden_fraction": (1.0 - exposed / t_comm) if t_comm > 0 else None,
                             "buckets": ddp.bucket_layout(), "compress": args.compress,
                             "payload_MB": sum(b for _, b in (ddp.bucket_layout() or [])) / 1e6}
@@ -396,8 +439,8 @@ def main():
         for m in ("f32s", "f32"):
             if m == args.dtype:
                 continue
-            k2 = max(2, min(K, 3))
-            el, kn, _, _ = run_mode(m, k2, 1)
+            k2 = 10
+            el, kn, _, _ = run_mode(m, k2, 2)
             d = {"ms_per_step": 1e3 * el / k2, "voxels_per_s": B * V * k2 / el, "steps": k2,
                  "roofline": roofline_block(kn, m, B, k2), "kernels": kernel_table(kn, k2)}
             if accuracy is not None:
@@ -448,14 +491,14 @@ def main():
     if extra:
         out["extra"] = extra
 
-    if args.torch_baseline and world == 1:
+    if world == 1 and not args.no_torch_baseline and not args.no_extra:
         del diff
         torch.cuda.empty_cache()
         ref = {}
         for amp in (True, False):
             torch.cuda.reset_peak_memory_stats()
             try:
-                ref["bf16_autocast" if amp else "fp32"] = torch_rocm_baseline(B, dev, amp)
+                ref["bf16_autocast" if amp else "fp32"] = torch_rocm_baseline(B, dev, amp, steps=2 if amp else 1)
             except Exception as e:  # noqa: BLE001 -- a baseline that cannot run is reported, not fatal
                 ref["bf16_autocast" if amp else "fp32"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out.setdefault("extra", {})["torch_rocm_reference"] = ref

@@ -47,6 +47,13 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
                       void* d1 = nullptr, int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr,
                       const void* a2 = nullptr, const Conv3Ext* ext = nullptr);
 
+// persistent LDS-DMA ring kernel (tdx_conv3_ring.hip; bf16): forward or main term of the data gradient on grids of whole
+// 8 x 8 x 8 bricks that fill the chip; TDX_ESHAPE = not such a case, take conv3_mfma_launch (results are bit-identical)
+bool conv3_ring_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z);
+int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y, int B, int X,
+                      int Y, int Z, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr, void* d1 = nullptr,
+                      int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr, const void* a2 = nullptr);
+
 // small-grid conv (tdx_conv3_small.hip; bf16 tensors, or fp32 tensors with split-precision products when split): forward
 // or data gradient (then x1 = dy, result split over out1 / out2 with addends, halo fold included); TDX_ESHAPE = not a
 // small-grid case, take the brick kernels.  Needs the scratch arena.

@@ -578,6 +578,9 @@ extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, con
         int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false,
                                     false, as_stream(stream));
         if (rs != TDX_ESHAPE) return rs;
+        // the two finest levels: persistent LDS-DMA ring kernel (same arithmetic, bit for bit)
+        rs = conv3_ring_launch(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, false, as_stream(stream));
+        if (rs != TDX_ESHAPE) return rs;
         return conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));
     }
     return conv3_direct_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, dtype, false, as_stream(stream));
@@ -631,7 +634,8 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
         if (e != hipSuccess) return (int)e;
     }
     Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
-    int rc = conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, st, acc);
+    int rc = conv3_ring_launch(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, false, st, acc);
+    if (rc == TDX_ESHAPE) rc = conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, st, acc);
     if (rc != TDX_OK) return rc;
     return gn_finalize_launch(acc, stats, B, Cout, G, (int64_t)X * Y * Z, eps, TDX_GN_REPLICAS, st);
 }
@@ -686,7 +690,9 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
         // deep U-Net levels: adjoint on the padded grid by the small-grid kernel, halo fold in its reduce pass
         rc = conv3_small_launch(dy, Cout, nullptr, 0, wb, nullptr, dx1, C1, dx2, add1, add2, B, X, Y, Z, Cin, true, false, st);
         if (rc != TDX_ESHAPE) return rc;
-        rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2);
+        rc = conv3_ring_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, B, X, Y, Z, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2);
+        if (rc == TDX_ESHAPE)
+            rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2);
         if (rc != TDX_OK) return rc;
         return conv3_shell_launch(dy, wb, dx1, C1, dx2, B, X, Y, Z, Cout, Cin, 0, st);
     } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT &&

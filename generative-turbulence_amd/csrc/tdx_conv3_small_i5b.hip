@@ -1,0 +1,3 @@
+// One instantiation of the small-grid conv kernel (tdx_conv3_small_kernel.h): 5 M tiles per wave, bf16 tensors.
+#include "tdx_conv3_small_kernel.h"
+SMALL_INSTANCE(5, false, conv3_small_go_5b)

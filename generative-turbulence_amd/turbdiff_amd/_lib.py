@@ -35,6 +35,7 @@ SIGNATURES = {
     "tdx_conv3_pack_weights": (_i, [_vp, _i, _i, _vp]),
     "tdx_transpose_many": (_i, [_vp, _i, _vp]),
     "tdx_conv3_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tdx_conv3_uses_ring": (_i, [_i] * 7),
     "tdx_conv3_fwd_gn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_fwd_partial": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_bwd_data_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),

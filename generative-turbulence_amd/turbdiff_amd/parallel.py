@@ -102,6 +102,8 @@ class BucketedDataParallel:
         self._launched: set[int] = set()
         self._seen: set[int] = set()
         self.stats = {"wait_s": 0.0, "steps": 0}
+        self.timing = False                            # True: finish() brackets its waits with events on the compute stream
+        self._wait_events: list = []
         if self.active and broadcast:
             with torch.no_grad():
                 for p in self.params:
@@ -225,16 +227,33 @@ class BucketedDataParallel:
                         self._stage(i)
                 self._launch(b)
         t0 = time.perf_counter()
+        timed = self.timing and self._flat and self._flat[0].is_cuda
+        if timed:
+            # what backward did not hide: between these two events the compute stream only waits for the collectives
+            # (and widens the bf16 wire buffers); everything enqueued before e0 is backward work
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w, b in self._work:
             w.wait()
             if self.compress == "bf16":
                 self._flat[b].copy_(self._wire[b])
+        if timed:
+            e1.record()
+            self._wait_events.append((e0, e1))
         self.stats["wait_s"] += time.perf_counter() - t0
         self.stats["steps"] += 1
         self._work.clear()
         self._launched.clear()
         self._seen.clear()
         self._pending = [len(b) for b in self._buckets]
+
+    def exposed_ms(self) -> list:
+        """Per-step GPU time the compute stream spent waiting for the gradient all-reduces inside finish() since the
+        last call (needs ``timing = True``; synchronises)."""
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self._wait_events]
+        self._wait_events.clear()
+        return out
 
     def allreduce_only(self):
         """Launch and wait for one all-reduce per bucket on whatever the buckets hold (bench.py's

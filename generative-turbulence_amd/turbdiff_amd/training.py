@@ -108,15 +108,17 @@ class DiffusionTrainer(nn.Module):
     keywords ``config.py:74-101`` forwards), plus ``gradient_clip_val`` (the trainer's, train.yaml:30-31),
     ``u_net_levels`` (hard-coded 4 in the reference, diffusion.py:120) and ``compute_mode``."""
 
+    # defaults = the reference constructor's own (diffusion.py:42-70), NOT the shipped YAML's: a caller that relies on
+    # defaults gets the same task from both; the shipped configuration is SHIPPED_CONFIG / from_config
     def __init__(self, data_dir=None, samples_root=None, dim: int = 32, cell_type_embedding_type: str = "learned",
-                 cell_type_embedding_dim: int = 4, normalization_mode: str = "mean-std", variables=("u", "p"),
-                 beta_schedule: str = "log-snr-linear", timesteps: int = 500, learning_rate: float = 1e-4,
-                 min_learning_rate: float = 1e-6, lr_decay: str | None = "exp", max_train_steps: int = 1000,
-                 loss: str = "l2", cell_type_features: bool = True, cell_pos_features: bool = False,
-                 clip_denoised: bool = False, noise_bcs: bool = True, learned_variances: bool = False,
+                 cell_type_embedding_dim: int = 4, normalization_mode: str = "mean-std", variables=tuple(Variable),
+                 beta_schedule: str = "sigmoid", timesteps: int = 100, learning_rate: float = 1e-3,
+                 min_learning_rate: float = 1e-3, lr_decay: str | None = None, max_train_steps: int = 1000,
+                 loss: str = "l1", cell_type_features: bool = True, cell_pos_features: bool = False,
+                 clip_denoised: bool = False, noise_bcs: bool = False, learned_variances: bool = False,
                  elbo_weight: float | None = None, detach_elbo_mean: bool = True, time_embedding: str = "nyquist",
-                 actfn: str = "silu", optimizer: str = "radam", norm_type: str = "group",
-                 with_geometry_embedding: bool = False, *, gradient_clip_val: float = 0.1, u_net_levels: int = 4,
+                 actfn: str = "silu", optimizer: str = "adam", norm_type: str = "instance",
+                 with_geometry_embedding: bool = True, *, gradient_clip_val: float = 0.1, u_net_levels: int = 4,
                  compute_dtype: torch.dtype | None = None, compute_mode: str | None = None, n_features: int | None = None):
         super().__init__()
         self.data_dir, self.samples_root = data_dir, samples_root
@@ -160,6 +162,11 @@ class DiffusionTrainer(nn.Module):
         self._opt = self._sched = None
         self.ddp = None  # set to a parallel.BucketedDataParallel(self) for multi-GPU training
         self.stats = None
+
+    # the model group of the shipped run configuration (config/model/diffusion.yaml:1-41), as keywords
+    SHIPPED_CONFIG = dict(dim=32, variables=("u", "p"), beta_schedule="log-snr-linear", timesteps=500, learning_rate=1e-4,
+                          min_learning_rate=1e-6, lr_decay="exp", loss="l2", noise_bcs=True, optimizer="radam",
+                          norm_type="group", with_geometry_embedding=False)
 
     # the keys config.py:74-101 reads off ``config.model`` and forwards under the same name
     CONFIG_KEYS = ("dim", "cell_type_embedding_type", "cell_type_embedding_dim", "normalization_mode", "beta_schedule",

@@ -113,6 +113,12 @@ int tdx_transpose_many(const TdxTransposeJob* jobs, int n, void* stream);
 int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, const void* wf, const float* bias, void* y,
                   int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* stream);
 
+/* Which bf16 matrix-core kernel serves this shape (same call, same results bit for bit; a host needs this only for
+ * bookkeeping, e.g. bench.py's per-kernel roofline): 1 = the persistent LDS-DMA ring kernel (tdx_conv3_ring.hip: grids
+ * of whole 8x8x8 bricks that fill the chip, i.e. the two finest U-Net levels), 0 = the brick / small-grid kernels.
+ * For a data gradient pass the layer's (Cout, 0, Cin) as (C1, C2, Cout). */
+int tdx_conv3_uses_ring(int C1, int C2, int Cout, int B, int X, int Y, int Z);
+
 /* Same convolution, additionally producing the GroupNorm(G, Cout, eps) statistics of its own
  * output -- stats [B][G][2] = (mean, rstd), as tdx_gn_stats would -- from per-channel moments
  * accumulated in the conv epilogue (Block.conv -> Block.norm, ddpm.py:169-170), which saves the

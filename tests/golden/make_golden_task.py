@@ -61,6 +61,22 @@ def build_reference_task(run):
         return Dm.DiffusionTraining(**kw), False
 
 
+def build_reference_defaults():
+    import turbdiff.models.diffusion as Dm
+
+    class _NoMetrics(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    kw = dict(data_dir=Path("data/shapes/data"), samples_root=Path("data/samples/explore/debug"))
+    try:
+        return Dm.DiffusionTraining(**kw), True
+    except Exception:
+        Dm.SampleMetricsCollection = _NoMetrics
+        Dm.SampleStore = lambda *a, **k: None
+        return Dm.DiffusionTraining(**kw), False
+
+
 def main():
     install_stubs()
     sys.path.insert(0, str(REF))
@@ -76,11 +92,16 @@ def main():
         "no_cell_types": {"cell_type_features": False, "cell_pos_features": True, "optimizer": "adamw"},
     }
     cases = {}
-    for name, over in variants.items():
+    for name, over in list(variants.items()) + [("ctor_defaults", None)]:
         run = json.loads(json.dumps(base))
-        run["model"].update(over)
         torch.manual_seed(0)
-        task, with_metrics = build_reference_task(run)
+        if over is None:
+            # the constructor's OWN defaults (diffusion.py:42-70): only the two required paths are passed
+            run = None
+            task, with_metrics = build_reference_defaults()
+        else:
+            run["model"].update(over)
+            task, with_metrics = build_reference_task(run)
         cfg = task.configure_optimizers()
         opt = cfg["optimizer"]
         factors = None

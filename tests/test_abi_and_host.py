@@ -144,7 +144,7 @@ def test_trainer_state_dict_has_the_reference_tasks_149_keys():
             k, shp = line.split("\t")
             want[k] = eval(shp)
     assert len(want) == 149
-    task = DiffusionTrainer(dim=32, timesteps=500)
+    task = DiffusionTrainer(**DiffusionTrainer.SHIPPED_CONFIG)
     have = {k: tuple(v.shape) for k, v in task.state_dict().items()}
     assert have == want
     task.load_state_dict({k: torch.zeros(s) for k, s in want.items()}, strict=True)
@@ -196,6 +196,29 @@ def test_trainer_from_config_matches_reference_task(case):
     else:
         for step, f in want["lr_factors"].items():
             assert abs(sched.lr_lambdas[0](int(step)) - f) <= 1e-15 * max(1.0, abs(f)), step
+
+
+def test_trainer_constructor_defaults_are_the_reference_constructors():
+    """DiffusionTrainer() with NO keywords against the reference's DiffusionTraining built with only its two required
+    paths (diffusion.py:42-70 defaults: sigmoid schedule, T = 100, l1, Adam at 1e-3 without decay, instance norm,
+    geometry embedding, all 8 variables, noise_bcs off): same state_dict, optimiser, hyper-parameters."""
+    from turbdiff_amd.training import DiffusionTrainer
+
+    want = _task_cases()["ctor_defaults"]["expect"]
+    task = DiffusionTrainer()
+    got = {k: list(v.shape) for k, v in task.state_dict().items()}
+    assert got == want["state_dict"]
+    assert list(got) == list(want["state_dict"]) or sorted(got) == sorted(want["state_dict"])
+    assert sum(p.numel() for p in task.parameters()) == want["n_parameters"]
+    assert task.max_train_steps == want["max_train_steps"]
+    assert task.conditioning.local_conditioning_dim == want["local_conditioning_dim"]
+    assert [v.name for v in task.variables] == want["variables"]
+    for k, v in want["attrs"].items():
+        assert getattr(task, k) == v, k
+    assert task.model.model.with_geometry_embedding and not task.model.noise_bcs
+    task.fused_optimizer = False
+    opt, sched = task.configure_optimizers()
+    assert type(opt).__name__ == want["optimizer"] and opt.param_groups[0]["lr"] == want["lr"] and sched is None
 
 
 def test_trainer_from_config_accepts_the_model_group_and_overrides():

@@ -168,7 +168,7 @@ def test_trainer_runs_from_dataset_sampler_and_stager():
     ds = OpenFOAMDataset(InMemoryRepository([(meta, np.arange(8) * 0.1, fields)]), stats, discard_first_seconds=-1.0)
     sampler = OpenFOAMSampler(ds, batch_size=2, shuffle=True, rank=1, world_size=2, seed=5)
     torch.manual_seed(0)
-    tr = DiffusionTrainer(dim=8, timesteps=10, u_net_levels=2, variables=("u", "p"), normalization_mode="mean-std",
+    tr = DiffusionTrainer(**{**DiffusionTrainer.SHIPPED_CONFIG, "dim": 8, "timesteps": 10}, u_net_levels=2, normalization_mode="mean-std",
                           max_train_steps=10).to("cuda:0")
     losses = [tr.fit_step(b).item() for b in DeviceStager((ds[i] for i in sampler), "cuda:0")]
     assert len(losses) == len(sampler) == 2 and all(np.isfinite(losses))

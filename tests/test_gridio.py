@@ -218,7 +218,7 @@ def test_trainer_takes_openfoam_batches():
     case = load_case("A")
     vs, meta, data, stats = build(case, dev())
     torch.manual_seed(0)
-    tr = DiffusionTrainer(dim=8, timesteps=10, u_net_levels=2, variables=("u", "p"),
+    tr = DiffusionTrainer(**{**DiffusionTrainer.SHIPPED_CONFIG, "dim": 8, "timesteps": 10}, u_net_levels=2,
                           normalization_mode="u:norm-max;p:abs-max").to(dev())
     batch = OpenFOAMBatch(data, stats)
     mean, std = stats.normalizers(vs, "u:norm-max;p:abs-max")

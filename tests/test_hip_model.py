@@ -399,7 +399,7 @@ def test_trainer_training_step_and_sample(golden):
     g = golden("model_cfg1")
     d = dev()
     torch.manual_seed(3)
-    task = DiffusionTrainer(dim=8, timesteps=10, u_net_levels=2, max_train_steps=20).to(d)
+    task = DiffusionTrainer(**{**DiffusionTrainer.SHIPPED_CONFIG, "dim": 8, "timesteps": 10}, u_net_levels=2, max_train_steps=20).to(d)
     task.model.model.load_state_dict(g.sub("sd/"))
     X, Y, Z = g["x"].shape[-3:]
     gen = torch.Generator().manual_seed(11)

@@ -7,7 +7,7 @@ import bench
 from turbdiff_amd.training import DiffusionTrainer
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-task = DiffusionTrainer(dim=32, timesteps=500, compute_dtype=torch.bfloat16).to(dev)
+task = DiffusionTrainer(**DiffusionTrainer.SHIPPED_CONFIG, compute_dtype=torch.bfloat16).to(dev)
 x, c, idx = bench.synthetic_inputs(6, dev)
 W, H, D = bench.GRID
 batch = SimpleNamespace(x=x * 2.0 + 0.5, cell_idx=idx, cell_types=torch.randint(0, 6, (W, H, D), device=dev),
