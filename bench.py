@@ -171,15 +171,20 @@ def torch_rocm_baseline(B, dev, amp, steps=2):
     return res
 
 
+# forward instantiations of the matrix-core conv kernels in a rocprofv3 kernel name (ZERO_PAD / ZP template argument false)
+FWD_KERNEL_PATTERNS = {
+    "bf16": r"conv3_ring_kernel<\d, false>|conv3_mfma_kernel<\d, (true|false), false,",  # <NT, ZP> | <NT, XT, ZERO_PAD, PERM, EXT>
+    "f32": r"conv3_mfma_f32_kernel<\d, false,", "f32s": r"conv3_mfma_split_kernel<\d, false,"}
+
+
 def measured_traffic(mode="bf16"):
-    """HBM bytes per launch of the mode's forward conv kernel from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json, produced by tools/collect_profiles.sh at B = 6): the newest file that holds
-    launches of that kernel; (None, None) if there is none."""
+    """HBM bytes per launch of the mode's forward brick / ring conv kernels from the committed rocprofv3 PMC passes
+    (profiles/*_traffic.json, produced by tools/collect_profiles.sh at B = 6): the newest file that holds launches of
+    those kernels; (None, None, 0) if there is none.  Same launches as roofline.algorithmic_bytes_per_launch: the forward
+    conv calls served by the brick / ring kernels (the deep levels' small-grid launches are a different kernel)."""
     import re
 
-    # forward instantiations = ZERO_PAD template argument false
-    pat = {"bf16": r"conv3_mfma_kernel<\d, (true|false), false,",  # <NT, XT, ZERO_PAD, PERM, EXT>
-           "f32": r"conv3_mfma_f32_kernel<\d, false,", "f32s": r"conv3_mfma_split_kernel<\d, false,"}[mode]
+    pat = FWD_KERNEL_PATTERNS[mode]
     for f in sorted((ROOT / "profiles").glob("*_traffic.json"), reverse=True):  # rNN tags: newest round first
         data = json.loads(f.read_text())
         num = den = 0.0
@@ -189,38 +194,55 @@ def measured_traffic(mode="bf16"):
                 num += n * (k["read_bytes_per_launch"] + k["write_bytes_per_launch"])
                 den += n
         if den:
-            return num / den, f"profiles/{f.name}"
-    return None, None
+            return num / den, f"profiles/{f.name}", int(den)
+    return None, None, 0
 
 
 CONV_CALLS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add", "tdx_conv3_bwd_weight"}
 
 
-def merged_kernel_times(timer):
-    kern = timer.summary()
+def merged_kernel_times(timer, where=None):
+    kern = timer.summary(where)
     # tdx_conv3_fwd_gn = the same conv kernel with the GroupNorm statistics in its epilogue
     # (+ an 8 us finalize kernel inside the bracket): count it as a forward launch
     for alias, name in (("tdx_conv3_fwd_gn", "tdx_conv3_fwd"), ("tdx_conv3_bwd_data_add", "tdx_conv3_bwd_data")):
         if alias in kern:
-            f = kern.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+            f = kern.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0, "bytes": 0.0})
             g = kern.pop(alias)
             for k in f:
                 f[k] += g[k]
     return kern
 
 
-def roofline_block(kern, mode, B, K):
-    kf = kern.get("tdx_conv3_fwd")
-    if not kf or kf["ms"] <= 0:
+def roofline_block(timer, mode, B, K):
+    """The dominant kernel = the matrix-core 3x3x3 conv, forward launches.  achieved / frac / traffic /
+    algorithmic_bytes_per_launch all refer to the SAME launches: the tdx_conv3_fwd(_gn) calls served by the brick and
+    ring kernels (on the shipped model 16 of the 22 forward convs of a step; the 6 deep-level launches run the
+    small-grid kernel and are reported, together with everything, under all_forward_launches)."""
+    from turbdiff_amd import _lib
+
+    main = merged_kernel_times(timer, lambda m: m.get("kind") in (_lib.KERNEL_BRICK, _lib.KERNEL_RING)).get("tdx_conv3_fwd")
+    every = merged_kernel_times(timer).get("tdx_conv3_fwd")
+    if not main or main["ms"] <= 0:
+        main = every
+    if not main or main["ms"] <= 0:
         return None
-    ach = kf["work"] / (kf["ms"] * 1e-3) / 1e12
-    traffic, tsrc = measured_traffic(mode)
+    ach = main["work"] / (main["ms"] * 1e-3) / 1e12
+    ach_all = every["work"] / (every["ms"] * 1e-3) / 1e12
+    traffic, tsrc, tn = measured_traffic(mode)
+    ring = merged_kernel_times(timer, lambda m: m.get("kind") == _lib.KERNEL_RING).get("tdx_conv3_fwd")
     return {"bound": "mfma", "achieved": ach, "peak": PEAK[mode], "unit": "TFLOP/s", "frac": ach / PEAK[mode],
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
-            "traffic_source": tsrc, "algorithmic_bytes_per_launch": CONV_BYTES[mode] * B / 22,
-            "kernel": KERNEL[mode] + " (all tdx_conv3_fwd launches)", "launches": kf["launches"],
-            "avg_launch_ms": kf["ms"] / kf["launches"],
-            "conv_bandwidth_roofline_frac": (CONV_BYTES[mode] * B * K / (kf["ms"] * 1e-3)) / 8e12}
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE), same launches",
+            "traffic_source": tsrc, "traffic_launches_sampled": tn,
+            "algorithmic_bytes_per_launch": main["bytes"] / main["launches"] if main["bytes"] else None,
+            "kernel": ("conv3_ring_kernel + conv3_mfma_kernel" if mode == "bf16" else KERNEL[mode]) +
+                      " (tdx_conv3_fwd launches on the brick / ring kernels)",
+            "launches": main["launches"], "avg_launch_ms": main["ms"] / main["launches"],
+            "ring_kernel": ({"launches": ring["launches"], "achieved": ring["work"] / (ring["ms"] * 1e-3) / 1e12,
+                             "frac": ring["work"] / (ring["ms"] * 1e-3) / 1e12 / PEAK[mode]} if ring and ring["ms"] > 0 else None),
+            "all_forward_launches": {"launches": every["launches"], "achieved": ach_all, "frac": ach_all / PEAK[mode],
+                                     "ms_per_step": every["ms"] / K},
+            "conv_bandwidth_roofline_frac": (CONV_BYTES[mode] * B * K / (every["ms"] * 1e-3)) / 8e12}
 
 
 def kernel_table(kern, K):
@@ -368,9 +390,9 @@ def main():
         _lib.TIMER = None
         ddp.timing = False
         kern = merged_kernel_times(timer)
-        return elapsed, kern, loss.item(), train_step
+        return elapsed, (kern, timer), loss.item(), train_step
 
-    elapsed, kern, last_loss, train_step = run_mode(args.dtype, K, Wm)
+    elapsed, (kern, timer), last_loss, train_step = run_mode(args.dtype, K, Wm)
     value = world * B * V * K / elapsed
     out = {
         "metric": "U-Net fwd+bwd voxels/sec (DDPM training step, 192x64x48x4)",
@@ -392,7 +414,7 @@ def main():
         "loss": last_loss,
     }
     if rank == 0:
-        rb = roofline_block(kern, args.dtype, B, K)
+        rb = roofline_block(timer, args.dtype, B, K)
         if rb:
             out["roofline"] = rb
         out["kernels"] = kernel_table(kern, K)
@@ -440,9 +462,9 @@ def main():
             if m == args.dtype:
                 continue
             k2 = 10
-            el, kn, _, _ = run_mode(m, k2, 2)
+            el, (kn, tm), _, _ = run_mode(m, k2, 2)
             d = {"ms_per_step": 1e3 * el / k2, "voxels_per_s": B * V * k2 / el, "steps": k2,
-                 "roofline": roofline_block(kn, m, B, k2), "kernels": kernel_table(kn, k2)}
+                 "roofline": roofline_block(tm, m, B, k2), "kernels": kernel_table(kn, k2)}
             if accuracy is not None:
                 d["rel_l2_vs_cpu_oracle"] = accuracy[m]
             pm[m] = d

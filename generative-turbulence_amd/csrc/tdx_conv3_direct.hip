@@ -586,6 +586,20 @@ extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, con
     return conv3_direct_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, dtype, false, as_stream(stream));
 }
 
+// Which kernel family tdx_conv3_fwd / tdx_conv3_fwd_gn run for this call (mirrors the dispatch above)
+extern "C" int tdx_conv3_fwd_kernel(int C1, int C2, int Cout, int B, int X, int Y, int Z, int dtype, int impl) {
+    impl &= 0xff;
+    if (dtype == TDX_F32 && impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(C1 + C2, 0, Cout))
+        return conv3_small_applies(C1, C2, B, X, Y, Z, Cout, false, true) ? TDX_KERNEL_SMALL : TDX_KERNEL_BRICK;
+    if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT && conv3_mfma_f32_supported(C1, C2, Cout)) return TDX_KERNEL_BRICK;
+    if (impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout))) {
+        if (!mfma_ok(dtype, C1, C2, Cout)) return TDX_KERNEL_DIRECT;
+        if (conv3_small_applies(C1, C2, B, X, Y, Z, Cout, false, false)) return TDX_KERNEL_SMALL;
+        return conv3_ring_supported(C1, C2, Cout, B, X, Y, Z) ? TDX_KERNEL_RING : TDX_KERNEL_BRICK;
+    }
+    return TDX_KERNEL_DIRECT;
+}
+
 extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, const void* wf, const float* bias,
                                 void* y, float* stats, int G, float eps, void* gn_workspace, int B, int X, int Y, int Z,
                                 int Cout, int dtype, int impl, void* stream) {

@@ -7,43 +7,46 @@
 // each instead of the 3.5 k they take alone on the SIMDs, because the two co-resident workgroups fall into step: both
 // in their MFMA phase, then both staging.  The matrix pipe idles half the time with no resource saturated.
 //
-// This kernel keeps the matrix-core loop of the brick kernel (same LDS images, fragment addresses, MFMA order: results
-// are bit-identical) and changes everything around it:
-//   * ONE persistent 8-wave workgroup per CU walks its own list of 8 x 8 x 8 bricks (512 voxels: wave w = x plane w,
-//     two 32-voxel M tiles x NT 32-channel N tiles per wave).  No prologue per brick: the next brick's first slice is
-//     already in flight while the current brick computes.
-//   * Staging is LDS-DMA only (global_load_lds_dwordx4: no staging registers, no ds_write phase).  A K slice's brick
-//     (10 x 10 x 10 halo'd voxels x 16 channels, 38 KiB pieces) is double-buffered; its weights arrive in three 9-tap
-//     groups (one per tap x offset) through a ring of RG_WSLOTS slots, two units ahead of their use.  A "unit" = one
-//     (slice, tap group) = 36 (NT = 2) MFMAs per wave behind ONE s_barrier; the DMA instructions of the units ahead
-//     are issued between the MFMAs of the current one.  Arrival is tracked with counted s_waitcnt vmcnt(N): every wave
-//     issues the same number of DMA instructions per unit (missing pieces are dummies into a scratch KiB), so N is a
-//     compile-time constant per (tap group, first-slice-after-an-epilogue) case.
-//   * The weights are re-streamed from L2 once per 512 voxels instead of once per 256.
-//   * Epilogue per brick: accumulators (+ bias) -> bf16 -> a wave-private 4 KiB LDS tile (in the brick buffer that
-//     just became free) -> whole 128-B voxel rows to HBM; GroupNorm moments are accumulated in registers ACROSS the
-//     bricks of a sample and flushed (LDS reduce over the 8 waves + one f64 atomic per channel and moment) only when
-//     the sample changes: two flushes per workgroup instead of one per brick.
+// Structure:
+//   * ONE persistent 8-wave workgroup per CU walks its own list of bricks.  A brick is 8 MT/2 x 8 x 8 voxels; wave w
+//     owns MT/2 x planes = MT 32-voxel M tiles x NT 32-channel N tiles, MT x NT = 4 (64-wide output tiles: 8 x 8 x 8
+//     bricks, 2 x 2; 32-wide ones: 16 x 8 x 8 bricks, 4 x 1, so that a weight fragment still feeds four MFMAs).  No
+//     prologue per brick: the next brick's first operands are in flight while the current brick computes.
+//   * K is walked in units of EIGHT input channels x ALL taps: one v_mfma_f32_32x32x16_bf16 contracts the 8 channels of
+//     tap 2p (k = 0-7, lanes 0-31) and of tap 2p + 1 (k = 8-15, lanes 32-63), 14 steps per unit with a 28th tap whose
+//     x operand is a zeroed LDS entry (+3.7 % MFMAs).  That makes a unit's operands small -- brick: one 16-B entry per
+//     halo voxel (19 / 34 KiB), weights: 28 taps x BN x 16 B (28 / 14 KiB) -- so two brick buffers, a ring of three
+//     weight slots AND dedicated output tiles fit the CU's 160 KiB, and a unit is 56 MFMAs per wave behind ONE
+//     s_barrier.  (First version: 16 channels x 9 taps = 36-MFMA units.  Its stamps, profiles/r10_ring_stamps.txt,
+//     showed that the two waves of a SIMD do not interleave their MFMAs: the older one wins every arbitration, runs its
+//     unit alone at 40 cycles per MFMA, then waits ~1000 cycles at the barrier while the younger one does the same.
+//     Hence longer units and fragment reads TWO K steps ahead, so that a wave alone keeps the pipe at 32 cycles per MFMA.)
+//   * Staging is LDS-DMA only (global_load_lds_dwordx4: no staging registers, no ds_write phase), ONE instruction
+//     behind each of the first K steps: the next unit's brick, then the weights of the unit after it.  Arrival is
+//     tracked with counted s_waitcnt vmcnt(N): every wave issues the same number of DMA instructions per unit
+//     (missing pieces are dummies into a scratch KiB), so N is a compile-time constant.
+//   * Epilogue per brick, no barrier: accumulators (started from the bias) -> bf16 -> a wave-private LDS tile -> whole
+//     voxel rows to HBM; GroupNorm moments are accumulated in registers ACROSS the bricks of a sample and flushed (LDS
+//     reduce over the 8 waves + one f64 atomic per channel and moment) only when the sample changes.
 //   * Workgroup -> bricks: every XCD owns one contiguous range of bricks (halo voxels shared through one L2); inside
 //     an XCD the 32 workgroups interleave, and the N tiles of one brick run on neighbouring workgroups at the same time.
 //
-// Used when the grid fills 8 x 8 x 8 bricks well (tdx_conv3_ring_supported); everything else stays on the brick kernel.
+// Same products and the same fp32 accumulation as the brick kernel up to summation order (taps in pairs, bias first).
+// Used when the grid is made of whole bricks and fills the chip (conv3_ring_supported); everything else stays on the
+// brick kernel.
 #include "tdx_common.h"
 #include "tdx_conv3.h"
 #include <stdlib.h>
+#include <algorithm>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define RG_HY 10
 #define RG_SZ 12                        // padded z stride of the LDS brick image (conflict-free 16-B fragment reads)
-#define RG_ENT (10 * 10 * RG_SZ)        // 1200 entries per half plane
-#define RG_APIECES 19                   // 1-KiB DMA pieces per half plane (1216 entries)
-#define RG_APLANE (RG_APIECES * 1024)
-#define RG_ABUF (2 * RG_APLANE)         // one brick slice: channels 0-7 | 8-15
-#define RG_BPW 5                        // brick pieces per wave and slice (8 x 5 = 40 >= 38)
-#define RG_WSLOTS 3                     // weight-group ring (lookahead 2 units)
+#define RG_WSLOTS 3                     // weight ring (lookahead 2 units)
 #define RG_WAVES 8
+#define RG_STEPS 14                     // K steps per unit: tap pairs (2p, 2p + 1); tap 27 is the zero dummy
 
 struct RingArgs {
     const bf16* x1; const bf16* x2; int C1, C2;
@@ -60,12 +63,12 @@ struct RingArgs {
 // Inline assembly, not the builtin: the compiler would order every later ds_read behind the copy with vmcnt(0).
 __device__ __forceinline__ void rg_dma(const void* gsrc, unsigned lds) {
     lds = __builtin_amdgcn_readfirstlane(lds);
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
 }
 // the same with a uniform 64-bit base and a 32-bit per-lane byte offset
 __device__ __forceinline__ void rg_dma_off(const void* sbase, unsigned voff, unsigned lds) {
     lds = __builtin_amdgcn_readfirstlane(lds);
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
 }
 #define RG_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 __device__ __forceinline__ void rg_barrier() {
@@ -75,9 +78,10 @@ __device__ __forceinline__ void rg_barrier() {
 }
 
 // Diagnostic builds only (tools/micro/ring_stamp.hip defines RG_STAMPS): s_memtime stamps of bricks RG_STAMP_B0 .. +1
-// of every wave, kept in spare LDS and dumped to A.stamps at the end; the product build carries none of it.
+// of every wave, kept in LDS (the statistics scratch: such builds run without the statistics flush) and dumped to
+// A.stamps at the end; the product build carries none of it.
 #ifdef RG_STAMPS
-#define RG_NSTAMP 160
+#define RG_NSTAMP 64
 #define RG_T()                                                                                        \
     do {                                                                                              \
         if (ord >= RG_STAMP_B0 && ord < RG_STAMP_B0 + 2) {                                            \
@@ -96,32 +100,51 @@ __device__ __forceinline__ int rg_tile_addr(int v, int c) {  // wave-private [32
     return v * 64 + ((c ^ ((v >> 1) & 3)) << 4);
 }
 
+template <int NT>
+struct RingShape {
+    static constexpr int BN = NT * 32;
+    static constexpr int MT = 4 / NT;                       // M tiles per wave
+    static constexpr int XP = MT / 2;                       // x planes per wave
+    static constexpr int BX = 8 * XP;                       // brick extent along x
+    static constexpr int ENT = (BX + 2) * RG_HY * RG_SZ;    // LDS entries of a brick image (16 B = 8 channels of a voxel)
+    static constexpr int APIECES = (ENT + 63) / 64;         // 1-KiB DMA pieces: 19 / 34
+    static constexpr int ABUF = APIECES * 1024;
+    static constexpr int BPW = (APIECES + RG_WAVES - 1) / RG_WAVES;  // brick pieces per wave and unit: 3 / 5
+    static constexpr int WPIECES = 28 * BN * 16 / 1024;     // 28 / 14
+    static constexpr int WSLOT = WPIECES * 1024;
+    static constexpr int WPW = (WPIECES + RG_WAVES - 1) / RG_WAVES;  // weight pieces per wave and unit: 4 / 2
+    static constexpr int TILE = 32 * BN * 2;                // wave-private output tile: 4 / 2 KiB
+    static constexpr int CH = BN / 8;                       // 16-B chunks per output row
+    static constexpr int VPI = 64 / CH;                     // voxels per store instruction
+    static constexpr int NST = MT * (32 / VPI);             // global stores per wave and brick: 8 / 8
+    static constexpr size_t LDS = (size_t)2 * ABUF + (size_t)RG_WSLOTS * WSLOT + (size_t)RG_WAVES * TILE + 1024 /* dummy sink */ +
+                                  64 /* zero entry */ + BN * 4 /* bias */ + (size_t)RG_WAVES * BN * 2 * 4 /* statistics */;
+};
+
 template <int NT, bool ZP>
 __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
-    constexpr int BN = NT * 32;
-    constexpr int WPIECES = (9 * BN * 16 + 1023) / 1024;  // per half plane of a 9-tap group: 9 / 5
-    constexpr int WPLANE = WPIECES * 1024;
-    constexpr int WSLOT = 2 * WPLANE;
-    constexpr int WPW = (2 * WPIECES + RG_WAVES - 1) / RG_WAVES;  // weight pieces per wave and unit: 3 / 2
-    constexpr int CH = BN / 8;                            // 16-B chunks per output row
-    constexpr int VPI = 64 / CH;                          // voxels per store instruction
-    constexpr int NST = 2 * (32 / VPI);                   // global stores per wave and brick: 8 / 4
+    typedef RingShape<NT> S;
+    constexpr int BN = S::BN, MT = S::MT, XP = S::XP, BPW = S::BPW, WPW = S::WPW, CH = S::CH, VPI = S::VPI, NST = S::NST;
+    static_assert(BPW + WPW < RG_STEPS, "one DMA instruction per K step");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    unsigned char* sA = smem;                             // [2][RG_ABUF]
-    unsigned char* sW = smem + 2 * RG_ABUF;               // [RG_WSLOTS][WSLOT]
-    unsigned char* sD = sW + RG_WSLOTS * WSLOT;           // 1 KiB sink of the dummy pieces
-    float* sBias = reinterpret_cast<float*>(sD + 1024);   // [BN]
-    float* sRed = sBias + BN;                             // [RG_WAVES][BN][2]
-#ifdef RG_STAMPS
-    unsigned long long* sStamp = reinterpret_cast<unsigned long long*>(sRed + RG_WAVES * BN * 2);
-    int nst = 0;
-#endif
+    unsigned char* sA = smem;                                   // [2][ABUF]
+    unsigned char* sW = sA + 2 * S::ABUF;                       // [RG_WSLOTS][WSLOT]: [28 taps][BN] x 16 B
+    unsigned char* sT = sW + RG_WSLOTS * S::WSLOT;              // [RG_WAVES][TILE]
+    unsigned char* sD = sT + RG_WAVES * S::TILE;                // 1 KiB sink of the dummy pieces
+    unsigned char* sZ = sD + 1024;                              // 64 B of zeros: x operand of the 28th tap
+    float* sBias = reinterpret_cast<float*>(sZ + 64);           // [BN]
+    float* sRed = sBias + BN;                                   // [RG_WAVES][BN][2]
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
-    const unsigned ldsA = lds0, ldsW = lds0 + 2 * RG_ABUF, ldsD = ldsW + RG_WSLOTS * WSLOT;
+    const unsigned ldsA = lds0, ldsW = lds0 + 2 * S::ABUF, ldsD = ldsW + RG_WSLOTS * S::WSLOT + RG_WAVES * S::TILE;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
+#ifdef RG_STAMPS
+    // NT = 2: the statistics scratch is exactly 8 waves x 64 stamps; NT = 1: behind it (ring_go adds the bytes)
+    unsigned long long* sStamp = reinterpret_cast<unsigned long long*>(NT == 2 ? sRed : sRed + RG_WAVES * BN * 2);
+    int nst = 0;
+#endif
 
     // ---- this workgroup's bricks: XCD x owns [lo, hi); its 32 workgroups = (32 / ntn) brick lanes x ntn N tiles
     const int hw = blockIdx.x, xcd = hw & 7, slot = hw >> 3;
@@ -131,56 +154,66 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
     const int nmine = hi - lo > kx ? (hi - lo - kx + KX - 1) / KX : 0;
     if (nmine == 0) return;
     const int n0 = ntile * BN;
-    const int Cin = A.C1 + A.C2, nsl = Cin >> 4;
+    const int Cin = A.C1 + A.C2, nun = Cin >> 3;  // units per brick
     const int YZ = A.Y * A.Z, V = A.X * YZ;
 
     if (tid < BN) sBias[tid] = A.bias ? A.bias[n0 + tid] : 0.f;
+    if (tid < 16) reinterpret_cast<unsigned*>(sZ)[tid] = 0u;
     rg_barrier();
 
     // ---- per-lane DMA geometry (fixed for the kernel)
-    // brick piece i of this wave: pi = wave * 5 + i -> (half, entries 64 q .. 64 q + 63)
-    int hxyz[RG_BPW];
+    // brick piece i of this wave: pi = wave * BPW + i -> entries 64 pi .. 64 pi + 63 of the image
+    int hxyz[BPW];
 #pragma unroll
-    for (int i = 0; i < RG_BPW; ++i) {
-        const int pi = min(wave * RG_BPW + i, 2 * RG_APIECES - 1);
-        const int e = min((pi % RG_APIECES) * 64 + lane, RG_ENT - 1);
+    for (int i = 0; i < BPW; ++i) {
+        const int pi = min(wave * BPW + i, S::APIECES - 1);
+        const int e = min(pi * 64 + lane, S::ENT - 1);
         const int hx = e / (RG_HY * RG_SZ), rem = e - hx * (RG_HY * RG_SZ);
         const int hy = rem / RG_SZ, hz = min(rem - hy * RG_SZ, 9);
-        hxyz[i] = hx | (hy << 8) | (hz << 16) | ((pi / RG_APIECES) << 24);
+        hxyz[i] = hx | (hy << 8) | (hz << 16);
     }
-    // weight piece j of this wave: pj = wave * WPW + j -> (half, entries 64 p ..): lane byte offset inside the group
+    // weight piece j of this wave: pj = wave * WPW + j -> entries 64 pj .. of [28 taps][BN]; tap 27 copies tap 26 (its x
+    // operand is zero; the weights only have to be finite).  Byte offset inside the 16-channel slice of the packed operand
     unsigned wlane[WPW];
 #pragma unroll
     for (int j = 0; j < WPW; ++j) {
-        const int pj = min(wave * WPW + j, 2 * WPIECES - 1);
-        const int half = pj / WPIECES, e = min((pj % WPIECES) * 64 + lane, 9 * BN - 1);
-        wlane[j] = (unsigned)(((e / BN) * A.Cout + (e % BN)) * 32 + half * 16);
+        const int pj = min(wave * WPW + j, S::WPIECES - 1);
+        const int e = pj * 64 + lane;
+        wlane[j] = (unsigned)((min(e / BN, 26) * A.Cout + (e % BN)) * 32);
     }
 
-    // ---- fragment geometry (as tdx_conv3_mfma.hip): M tile mt of wave w: x = w, y = 4 mt + (r & 3), z = r >> 2
-    int a_h[2];
+    // ---- fragment geometry: M tile mt of wave w: x plane w XP + mt / 2, y = 4 (mt % 2) + (r & 3), z = r >> 2;
+    // K step p: lanes 0-31 read tap 2p, lanes 32-63 tap 2p + 1 (the 28th: the zero entry)
+    int a_h[MT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) a_h[mt] = ((wave + 1) * RG_HY + (4 * mt + (r & 3) + 1)) * RG_SZ + ((r >> 2) + 1);
+    for (int mt = 0; mt < MT; ++mt)
+        a_h[mt] = (((wave * XP + mt / 2 + 1) * RG_HY + (4 * (mt % 2) + (r & 3) + 1)) * RG_SZ + ((r >> 2) + 1)) * 16;
+    int xo[RG_STEPS];
+#pragma unroll
+    for (int p = 0; p < RG_STEPS; ++p) {
+        const int t = min(2 * p + hh, 26);
+        xo[p] = (((t / 9 - 1) * RG_HY + ((t / 3) % 3 - 1)) * RG_SZ + (t % 3 - 1)) * 16;
+    }
     int b_off[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b_off[nt] = hh * WPLANE + (nt * 32 + r) * 16;
+    for (int nt = 0; nt < NT; ++nt) b_off[nt] = (hh * BN + nt * 32 + r) * 16;
 
     // ---- issue cursors
-    int vox[RG_BPW];       // source voxel (inside the sample, clamped; -1: zero) of this lane's pieces, for `vb`'s brick
-    int vb_b = 0;          // sample of the brick `vox` describes
+    int vox[BPW];          // source voxel (inside the sample, clamped; -1: zero) of this lane's pieces, for the planned brick
+    int vb_b = 0;          // sample of the planned brick
     auto brick_coords = [&](int ord, int& b, int& o0, int& o1, int& o2) {
         int id = lo + kx + KX * ord;
         const int bz = id % A.nbz; id /= A.nbz;
         const int by = id % A.nby; id /= A.nby;
         const int bx = id % A.nbx; id /= A.nbx;
-        b = id; o0 = bx * 8; o1 = by * 8; o2 = bz * 8;
+        b = id; o0 = bx * S::BX; o1 = by * 8; o2 = bz * 8;
     };
     auto plan_brick = [&](int ord) {
         int b, o0, o1, o2;
         brick_coords(min(ord, nmine - 1), b, o0, o1, o2);
         vb_b = b;
 #pragma unroll
-        for (int i = 0; i < RG_BPW; ++i) {
+        for (int i = 0; i < BPW; ++i) {
             int s0 = o0 + (hxyz[i] & 0xff) - 1, s1 = o1 + ((hxyz[i] >> 8) & 0xff) - 1, s2 = o2 + ((hxyz[i] >> 16) & 0xff) - 1;
             bool ok = true;
             if (ZP) ok = s0 >= 0 && s0 < A.X && s1 >= 0 && s1 < A.Y && s2 >= 0 && s2 < A.Z;
@@ -188,36 +221,27 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
             vox[i] = ok ? (s0 * A.Y + s1) * A.Z + s2 : -1;
         }
     };
-    // piece i of brick slice s of the planned brick -> buffer `buf` (one LDS-DMA instruction)
-    auto issue_brick_piece = [&](int s, int buf, int i) {
-        const int k0 = s << 4;
+    // piece i of the planned brick's 8-channel slice c8 -> buffer `buf` (one LDS-DMA instruction)
+    auto issue_brick_piece = [&](int c8, int buf, int i) {
+        const int k0 = c8 << 3;
         const bf16* xs; int Cs, kk;
         if (k0 < A.C1) { xs = A.x1; Cs = A.C1; kk = k0; } else { xs = A.x2; Cs = A.C2; kk = k0 - A.C1; }
         const bf16* base = xs + ((int64_t)vb_b * V) * Cs + kk;  // uniform
-        const int pi = wave * RG_BPW + i;
-        const int half = hxyz[i] >> 24;
-        const unsigned dst = pi < 2 * RG_APIECES ? ldsA + buf * RG_ABUF + half * RG_APLANE + (pi % RG_APIECES) * 1024 : ldsD;
+        const int pi = wave * BPW + i;
+        const unsigned dst = pi < S::APIECES ? ldsA + buf * S::ABUF + pi * 1024 : ldsD;
         if (ZP) {
-            const bf16* src = vox[i] >= 0 ? base + (int64_t)vox[i] * Cs + half * 8 : reinterpret_cast<const bf16*>(A.zeros);
+            const bf16* src = vox[i] >= 0 ? base + (int64_t)vox[i] * Cs : reinterpret_cast<const bf16*>(A.zeros);
             rg_dma(src, dst);
         } else {
-            rg_dma_off(base, (unsigned)(vox[i] * Cs + half * 8) * 2u, dst);
+            rg_dma_off(base, (unsigned)(vox[i] * Cs) * 2u, dst);
         }
     };
-    // piece j of weight group (slice s, tap x offset g) -> ring slot
-    auto issue_weight_piece = [&](int s, int g, int wslot, int j) {
-        const bf16* base = A.wp + ((int64_t)(s * 27 + g * 9) * A.Cout + n0) * 16;  // uniform
+    // piece j of the weights of 8-channel slice c8 -> ring slot
+    auto issue_weight_piece = [&](int c8, int wslot, int j) {
+        const bf16* base = A.wp + ((int64_t)((c8 >> 1) * 27) * A.Cout + n0) * 16 + (c8 & 1) * 8;  // uniform
         const int pj = wave * WPW + j;
-        const unsigned dst = pj < 2 * WPIECES ? ldsW + wslot * WSLOT + (pj / WPIECES) * WPLANE + (pj % WPIECES) * 1024 : ldsD;
+        const unsigned dst = pj < S::WPIECES ? ldsW + wslot * S::WSLOT + pj * 1024 : ldsD;
         rg_dma_off(base, wlane[j], dst);
-    };
-    auto issue_brick = [&](int s, int buf) {
-#pragma unroll
-        for (int i = 0; i < RG_BPW; ++i) issue_brick_piece(s, buf, i);
-    };
-    auto issue_weights = [&](int s, int g, int wslot) {
-#pragma unroll
-        for (int j = 0; j < WPW; ++j) issue_weight_piece(s, g, wslot, j);
     };
 
     // ---- GroupNorm moments of this workgroup's bricks of the current sample (lane: chunk lane % CH, 8 channels)
@@ -254,18 +278,22 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
         for (int e = 0; e < 4; ++e) p1[e] = p2[e] = f32x2{0.f, 0.f};
     };
 
-    // ---- prologue: brick 0 / slice 0, weight units 0 and 1
+    // ---- prologue: brick 0 / slice 0 and the weights of units 0 and 1
     plan_brick(0);
-    issue_brick(0, 0);
-    issue_weights(0, 0, 0);
-    issue_weights(0, 1, 1);
-    // cursors of what is issued next: brick slice instance qi (slice qs of brick qb), weight unit uw (slice ws, group wg)
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) issue_brick_piece(0, 0, i);
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) issue_weight_piece(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) issue_weight_piece(1 % nun, 1, j);
+    // cursors of what is issued next: slice qs of the planned brick qb; weights of unit uw (slice ws)
     int qs = 1, qb = 0;
-    if (qs == nsl) { qs = 0; qb = 1; plan_brick(1); }
-    int ws = 0, wg = 2, uw = 2;
-    int q = 0, u = 0;  // slice instance / unit being computed
+    if (qs == nun) { qs = 0; qb = 1; plan_brick(1); }
+    int ws = 2 % nun, uw = 2;
+    int u = 0;  // unit being computed
+    bool stores_behind = false;  // the previous brick's epilogue stores were issued after this unit's operands
 
-    f32x16 acc[NT][2];
+    f32x16 acc[NT][MT];
 
     for (int ord = 0; ord < nmine; ++ord) {
         int b, o0, o1, o2;
@@ -277,85 +305,87 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
             for (int j = 0; j < 4; ++j) {
                 const float4 bv = *reinterpret_cast<const float4*>(sBias + nt * 32 + 8 * j + 4 * hh);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     acc[nt][mt][4 * j] = bv.x; acc[nt][mt][4 * j + 1] = bv.y; acc[nt][mt][4 * j + 2] = bv.z; acc[nt][mt][4 * j + 3] = bv.w;
                 }
             }
 
-        for (int s = 0; s < nsl; ++s, ++q) {
-            const unsigned char* bufA = sA + (q & 1) * RG_ABUF + hh * RG_APLANE;
-#pragma unroll
-            for (int g = 0; g < 3; ++g, ++u) {
-                // ---- arrival of this unit's weights (and, at g = 0, of the slice's brick): counted waits, see header.
-                // `after` = stores of the previous brick's epilogue sit between the awaited copies and the youngest ones
-                const bool first = ord == 0 && s == 0;   // nothing but the prologue's copies is in flight: drain
-                const bool after = s == 0;
-                RG_T();  // unit top
-                if (first) RG_VMCNT(0);
-                else if (g == 0) { if (after) RG_VMCNT(WPW + NST); else RG_VMCNT(WPW); }
-                else if (g == 1) { if (after) RG_VMCNT(WPW + RG_BPW + NST); else RG_VMCNT(WPW + RG_BPW); }
-                else RG_VMCNT(WPW + RG_BPW);
-                RG_T();  // this wave's copies have landed
-                rg_barrier();
-                RG_T();  // everybody's have
+        for (int c8 = 0; c8 < nun; ++c8, ++u) {
+            // ---- arrival of this unit's brick (issued one unit ago) and weights (two units ago): the only younger
+            // copies are the weights of the next unit; the stores of a brick's epilogue sit behind its successor's
+            // first unit's operands
+            RG_T();  // unit top
+            if (stores_behind) RG_VMCNT(WPW + NST); else RG_VMCNT(WPW);
+            stores_behind = false;
+            RG_T();  // this wave's copies have landed
+            rg_barrier();
+            RG_T();  // everybody's have
 
-                const unsigned char* slotW = sW + (u % RG_WSLOTS) * WSLOT;
-                const unsigned char* xa[2];
+            const unsigned char* bufA = sA + (u & 1) * S::ABUF;
+            const unsigned char* slotW = sW + (u % RG_WSLOTS) * S::WSLOT;
+            const unsigned char* xa[MT];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) xa[mt] = bufA + (a_h[mt] + (g - 1) * RG_HY * RG_SZ) * 16;
+            for (int mt = 0; mt < MT; ++mt) xa[mt] = bufA + a_h[mt];
 
-                bf16x8 xf[2][2], wf[2][NT];
-                auto read_frags = [&](int t9, int fb) {
-                    const int toff = ((t9 / 3 - 1) * RG_SZ + (t9 % 3 - 1)) * 16;
+            // fragments are read TWO K steps ahead of the MFMAs that use them (three register sets): one wave alone has
+            // to keep the matrix pipe busy -- the two waves of a SIMD take turns, they do not interleave
+            bf16x8 xf[3][MT], wf[3][NT];
+            auto read_frags = [&](int p, int fb) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) xf[fb][mt] = *reinterpret_cast<const bf16x8*>(xa[mt] + toff);
+                for (int mt = 0; mt < MT; ++mt) {
+                    const unsigned char* src = xa[mt] + xo[p];
+                    if (p == RG_STEPS - 1) src = hh ? sZ : src;  // the 28th tap multiplies zeros
+                    xf[fb][mt] = *reinterpret_cast<const bf16x8*>(src);
+                }
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) wf[fb][nt] = *reinterpret_cast<const bf16x8*>(slotW + t9 * (BN * 16) + b_off[nt]);
-                };
-                read_frags(0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);
+                for (int nt = 0; nt < NT; ++nt) wf[fb][nt] = *reinterpret_cast<const bf16x8*>(slotW + p * (2 * BN * 16) + b_off[nt]);
+            };
+            read_frags(0, 0);
+            read_frags(1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MT + NT), 0);
 #pragma unroll
-                for (int t9 = 0; t9 < 9; ++t9) {
-                    if (t9 + 1 < 9) read_frags(t9 + 1, (t9 + 1) & 1);
+            for (int p = 0; p < RG_STEPS; ++p) {
+#if defined(RG_ABL) && (RG_ABL & 2)     // (ablation: no fragment reads after the first two steps)
+                if (false)
+#endif
+                if (p + 2 < RG_STEPS) read_frags(p + 2, (p + 2) % 3);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t9 & 1][nt], xf[t9 & 1][mt], acc[nt][mt], 0, 0, 0);
-                    if (t9 + 1 < 9) {
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[p % 3][nt], xf[p % 3][mt], acc[nt][mt], 0, 0, 0);
+                if (p + 2 < RG_STEPS) {
 #pragma unroll
-                        for (int k = 0; k < 2 * NT; ++k) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                            if (k < 2 + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-                    } else {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+                    for (int k = 0; k < 4; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (k < MT + NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
-                    // the copies of the units ahead ride between the taps' MFMAs, ONE LDS-DMA instruction per tap (a burst
-                    // of them stalls both waves of a SIMD in the address queue while the matrix pipe drains): weights
-                    // of unit u + 2 behind taps 0 .. WPW - 1, the next slice's brick (g = 0 only) behind the following 5
-                    if (t9 < WPW) issue_weight_piece(ws, wg, uw % RG_WSLOTS, t9);
-                    if (t9 == WPW - 1) {
-                        ++uw;
-                        if (++wg == 3) { wg = 0; if (++ws == nsl) ws = 0; }
-                    }
-                    if (g == 0 && t9 >= WPW && t9 < WPW + RG_BPW) issue_brick_piece(qs, (q + 1) & 1, t9 - WPW);
-                    if (g == 0 && t9 == 8) {
-                        if (++qs == nsl) { qs = 0; ++qb; plan_brick(qb); }
-                    }
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                }
+                // the copies of the units ahead ride between the K steps, ONE LDS-DMA instruction per step (a burst of
+                // them stalls the wave in the address queue while the matrix pipe drains): the next unit's brick behind
+                // steps 0 .. BPW - 1, the weights of the unit after it behind the following WPW
+#if !defined(RG_ABL) || !(RG_ABL & 1)  // (diagnostic ablation builds drop the copies: timing only)
+                if (p < BPW) issue_brick_piece(qs, (u + 1) & 1, p);
+                if (p >= BPW && p < BPW + WPW) issue_weight_piece(ws, uw % RG_WSLOTS, p - BPW);
+#endif
+                if (p == BPW + WPW) {
+                    ++uw;
+                    if (++ws == nun) ws = 0;
+                    if (++qs == nun) { qs = 0; ++qb; plan_brick(qb); }
                 }
             }
         }
 
-        // ---------------- epilogue of the brick.  Lane (r, hh) of wave w holds, for M tile mt, voxel
-        // (w, 4 mt + (r & 3), r >> 2) and channels nt*32 + 8 j + 4 hh + (0..3) in accumulator registers 4 j .. 4 j + 3.
+        // ---------------- epilogue of the brick (no barrier: wave-private tiles).  Lane (r, hh) of wave w holds, for
+        // M tile mt, voxel (w XP + mt / 2, 4 (mt % 2) + (r & 3), r >> 2) and channels nt*32 + 8 j + 4 hh + (0..3) in
+        // accumulator registers 4 j .. 4 j + 3.
         RG_T();  // last MFMA issued
-        rg_barrier();  // every wave is done with the last slice's brick buffer: it now holds the output tiles
-        RG_T();
-        unsigned char* tile = sA + ((q - 1) & 1) * RG_ABUF + wave * 4096;
+        unsigned char* tile = sT + wave * S::TILE;
         const int last_b = b;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const int vw = (r & 3) * 8 + (r >> 2);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -369,51 +399,52 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
 #pragma unroll
             for (int i = 0; i < 32 / VPI; ++i) {
                 const int v = lane / CH + VPI * i, cidx = lane % CH;
-                const int c0 = o0 + wave, c1 = o1 + 4 * mt + (v >> 3), c2 = o2 + (v & 7);
-                if (c0 < A.X && c1 < A.Y && c2 < A.Z) {
-                    uint4 val = *reinterpret_cast<const uint4*>(tile + rg_tile_addr<BN>(v, cidx));
-                    const int64_t ov = (int64_t)b * V + c0 * YZ + c1 * A.Z + c2;
-                    const int n = n0 + cidx * 8;
-                    if (ZP) {
-                        // data gradient: dx split over the two inputs of a concatenated conv, plus the gradient that
-                        // arrives over the block's residual path
-                        const bool lo1 = n < A.D1;
-                        bf16* dst = lo1 ? A.d1 + ov * A.D1 + n : A.d2 + ov * (A.Cout - A.D1) + (n - A.D1);
-                        const bf16* asrc = lo1 ? (A.a1 ? A.a1 + ov * A.D1 + n : nullptr)
-                                               : (A.a2 ? A.a2 + ov * (A.Cout - A.D1) + (n - A.D1) : nullptr);
-                        if (asrc) {
-                            Vec8<bf16> va, vb;
-                            va.load(reinterpret_cast<const bf16*>(&val));
-                            vb.load(asrc);
+                const int c0 = o0 + wave * XP + mt / 2, c1 = o1 + 4 * (mt % 2) + (v >> 3), c2 = o2 + (v & 7);
+                uint4 val = *reinterpret_cast<const uint4*>(tile + rg_tile_addr<BN>(v, cidx));
+                const int64_t ov = (int64_t)b * V + c0 * YZ + c1 * A.Z + c2;
+                const int n = n0 + cidx * 8;
+                if (ZP) {
+                    // data gradient: dx split over the two inputs of a concatenated conv, plus the gradient that
+                    // arrives over the block's residual path
+                    const bool lo1 = n < A.D1;
+                    bf16* dst = lo1 ? A.d1 + ov * A.D1 + n : A.d2 + ov * (A.Cout - A.D1) + (n - A.D1);
+                    const bf16* asrc = lo1 ? (A.a1 ? A.a1 + ov * A.D1 + n : nullptr)
+                                           : (A.a2 ? A.a2 + ov * (A.Cout - A.D1) + (n - A.D1) : nullptr);
+                    if (asrc) {
+                        Vec8<bf16> va, vb;
+                        va.load(reinterpret_cast<const bf16*>(&val));
+                        vb.load(asrc);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) va.v[e] += vb.v[e];
-                            va.store(dst);
-                        } else {
-                            *reinterpret_cast<uint4*>(dst) = val;
-                        }
+                        for (int e = 0; e < 8; ++e) va.v[e] += vb.v[e];
+                        va.store(dst);
                     } else {
-                        *reinterpret_cast<uint4*>(A.y + ov * A.Cout + n) = val;
-                        if (A.gn_acc != nullptr) {
-                            const unsigned wds[4] = {val.x, val.y, val.z, val.w};
+                        *reinterpret_cast<uint4*>(dst) = val;
+                    }
+                } else {
+                    *reinterpret_cast<uint4*>(A.y + ov * A.Cout + n) = val;
+                    if (A.gn_acc != nullptr) {
+                        const unsigned wds[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const f32x2 lh = {__uint_as_float(wds[e] << 16), __uint_as_float(wds[e] & 0xffff0000u)};
-                                p1[e] += lh;
-                                p2[e] = __builtin_elementwise_fma(lh, lh, p2[e]);
-                            }
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x2 lh = {__uint_as_float(wds[e] << 16), __uint_as_float(wds[e] & 0xffff0000u)};
+                            p1[e] += lh;
+                            p2[e] = __builtin_elementwise_fma(lh, lh, p2[e]);
                         }
                     }
                 }
             }
         }
+        stores_behind = true;
         RG_T();  // epilogue stores issued
+#ifndef RG_STAMPS
         if (!ZP && A.gn_acc != nullptr) {
             int nb = -1;
             if (ord + 1 < nmine) { int t0, t1, t2; brick_coords(ord + 1, nb, t0, t1, t2); }
             if (nb != last_b) flush_stats(last_b);
         }
+#endif
     }
-    RG_VMCNT(0);  // the dummy / wrapped copies of the last units must not outlive the workgroup's LDS
+    RG_VMCNT(0);  // the wrapped copies of the last units must not outlive the workgroup's LDS
 #ifdef RG_STAMPS
     if (lane == 0 && A.stamps != nullptr) {
         unsigned long long* rec = A.stamps + ((size_t)blockIdx.x * RG_WAVES + wave) * (RG_NSTAMP + 1);
@@ -427,16 +458,20 @@ bool conv3_ring_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z) 
     const char* env = getenv("TDX_CONV3_RING");  // A/B switch, read per call: 0 off, 1 auto (default), 2 whenever legal
     const int mode = env ? atoi(env) : 1;
     if (mode == 0 || !conv3_mfma_supported(C1, C2, Cout)) return false;
+    const int NT = Cout % 64 == 0 ? 2 : 1, bx = NT == 2 ? 8 : 16;
     // whole bricks only: the counted vmcnt waits assume that every wave issues all of its epilogue stores
-    if ((X % 8) || (Y % 8) || (Z % 8)) return false;
-    const int ntn = Cout % 64 == 0 ? Cout / 64 : Cout / 32;
+    if ((X % bx) || (Y % 8) || (Z % 8)) return false;
+    const int ntn = Cout / (32 * NT);
     if (ntn > 32 || (32 % ntn) != 0) return false;
     if ((int64_t)X * Y * Z * 1024 >= (1ll << 31)) return false;  // 32-bit per-lane byte offsets
     if (mode == 2) return true;
-    // persistent one-workgroup-per-CU launch: the grid must fill the 8 x 8 x 8 bricks and give every CU several of them
-    const int64_t nb = (int64_t)B * ceil_div(X, 8) * ceil_div(Y, 8) * ceil_div(Z, 8);
-    const double fill = (double)B * X * Y * Z / (512.0 * nb);
-    return fill >= 0.9 && nb * ntn >= 3 * 256;
+    // 32-wide output tiles: every 8-channel unit re-fetches a 16-B piece of each halo voxel's row, one cache line per
+    // lane; with rows of 128 B and more (C >= 64 per input tensor) that address traffic arrives late (128 -> 32 at
+    // 192 x 64 x 48: 1.07 ms against the brick kernel's 0.85; 32 -> 32: 0.212 against 0.227)
+    if (NT == 1 && std::max(C1, C2) > 32) return false;
+    // persistent one-workgroup-per-CU launch: every CU should get several bricks
+    const int64_t nb = (int64_t)B * (X / bx) * (Y / 8) * (Z / 8);
+    return nb * ntn >= 3 * 256;
 }
 
 #ifdef RG_STAMPS
@@ -445,11 +480,9 @@ static unsigned long long* rg_stamp_buffer = nullptr;
 
 template <int NT, bool ZP>
 static int ring_go(const RingArgs& a, hipStream_t st) {
-    constexpr int BN = NT * 32;
-    constexpr int WPIECES = (9 * BN * 16 + 1023) / 1024;
-    size_t lds = (size_t)2 * RG_ABUF + (size_t)RG_WSLOTS * 2 * WPIECES * 1024 + 1024 + BN * 4 + RG_WAVES * BN * 2 * 4;
+    size_t lds = RingShape<NT>::LDS;
 #ifdef RG_STAMPS
-    lds += (size_t)RG_WAVES * RG_NSTAMP * 8;
+    if (NT == 1) lds += (size_t)RG_WAVES * RG_NSTAMP * 8;
 #endif
     auto kern = conv3_ring_kernel<NT, ZP>;
     static bool attr_set = false;
@@ -474,7 +507,7 @@ int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void
     a.x1 = (const bf16*)x1; a.x2 = (const bf16*)x2; a.C1 = C1; a.C2 = C2;
     a.wp = (const bf16*)wp; a.bias = bias; a.y = (bf16*)y;
     a.B = B; a.X = X; a.Y = Y; a.Z = Z; a.Cout = Cout;
-    a.nbx = ceil_div(X, 8); a.nby = ceil_div(Y, 8); a.nbz = ceil_div(Z, 8); a.ntn = Cout / (32 * NT);
+    a.nbx = X / (NT == 2 ? 8 : 16); a.nby = Y / 8; a.nbz = Z / 8; a.ntn = Cout / (32 * NT);
     a.gn_acc = gn_acc;
     a.d1 = (bf16*)d1; a.d2 = (bf16*)d2; a.D1 = D1; a.a1 = (const bf16*)a1; a.a2 = (const bf16*)a2;
     a.zeros = tdx_scratch_ptr();

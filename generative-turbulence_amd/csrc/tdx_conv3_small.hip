@@ -168,6 +168,15 @@ static int small_dispatch(int mtw, SMALL_GO_ARGS) {
 #undef GO
 }
 
+// would conv3_small_launch take this call? (bookkeeping: tdx_conv3_fwd_kernel)
+bool conv3_small_applies(int C1, int C2, int B, int X, int Y, int Z, int N, bool data_gradient, bool split) {
+    if (tdx_scratch_ptr() == nullptr || (C1 % SM_KC) || (C2 % SM_KC)) return false;
+    SmallGeom g;
+    size_t lds = 0;
+    if (!small_plan(g, B, X, Y, Z, C1 + C2, N, data_gradient, split, tdx_scratch_bytes(), lds)) return false;
+    return ceil_div(ceil_div(g.nbg * g.xs * g.Ev[1] * g.Ev[2], 32), 4) <= SM_MAX_TILES / 4;
+}
+
 // Forward (data_gradient == false: y = conv3([x1 | x2]) + bias, N = Cout) or data gradient (x1 = dy with K = C1
 // channels, x2 unused; result N channels split over out1 [0, D1) / out2, plus addends).  split == false: bf16 tensors,
 // wp = the bf16 packed weight; split == true: fp32 tensors, wp = the split-precision packed weight (hi image, lo image).

@@ -134,6 +134,15 @@ static int film_rows(const int* channels, int n, int* first) {
     return first[n];
 }
 
+#define FILM_MAX_LDS (160 * 1024)  // the conditioning vectors of the whole batch sit in LDS (a CU's full 160 KiB at most)
+static inline size_t film_bwd_lds(int B, int T) {
+    return ((size_t)B * T + (size_t)FILM_ROWS * (B + 1) + (size_t)FILM_ROWS * (T + 1)) * sizeof(float);
+}
+// 1 if tdx_film_fwd AND tdx_film_bwd take a batch of B conditioning vectors of T features (else project per block)
+extern "C" int tdx_film_supported(int B, int T) {
+    return B > 0 && T > 0 && (size_t)B * T * sizeof(float) <= FILM_MAX_LDS && film_bwd_lds(B, T) <= FILM_MAX_LDS;
+}
+
 extern "C" int tdx_film_fwd(const float* c, int B, int T, const TdxFilmLayer* layers, int n, void* stream) {
     TDX_CHECK_ARG(c && layers && B > 0 && T > 0 && n > 0 && n <= TDX_FILM_MAX_LAYERS);
     FilmFwdTable tab;
@@ -147,7 +156,15 @@ extern "C" int tdx_film_fwd(const float* c, int B, int T, const TdxFilmLayer* la
     const int rows = film_rows(channels, n, tab.first);
     if (rows <= 0) return TDX_EINVAL;
     const size_t lds = (size_t)B * T * sizeof(float);
-    if (lds > 48 * 1024) return TDX_ESHAPE;
+    if (lds > FILM_MAX_LDS) return TDX_ESHAPE;  // hosts check tdx_film_supported first (ops.film_projections falls back)
+    if (lds > 48 * 1024) {
+        static size_t attr = 0;
+        if (lds > attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)film_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILM_MAX_LDS);
+            if (e != hipSuccess) return (int)e;
+            attr = FILM_MAX_LDS;
+        }
+    }
     hipLaunchKernelGGL(film_fwd_kernel, dim3(ceil_div(rows, FILM_ROWS)), dim3(FILM_ROWS), lds, as_stream(stream), tab, c, B, T);
     return tdx_launch_status();
 }
@@ -174,8 +191,16 @@ extern "C" int tdx_film_bwd(const float* c, int B, int T, const TdxFilmGrad* lay
     tab.n = n;
     const int rows = film_rows(channels, n, tab.first);
     if (rows <= 0) return TDX_EINVAL;
-    const size_t lds = ((size_t)B * T + (size_t)FILM_ROWS * (B + 1) + (size_t)FILM_ROWS * (T + 1)) * sizeof(float);
-    if (lds > 48 * 1024) return TDX_ESHAPE;
+    const size_t lds = film_bwd_lds(B, T);
+    if (lds > FILM_MAX_LDS) return TDX_ESHAPE;
+    if (lds > 48 * 1024) {
+        static size_t attr = 0;
+        if (lds > attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)film_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FILM_MAX_LDS);
+            if (e != hipSuccess) return (int)e;
+            attr = FILM_MAX_LDS;
+        }
+    }
     const int nblocks = ceil_div(rows, FILM_ROWS);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(film_bwd_kernel, dim3(nblocks), dim3(FILM_ROWS), lds, st, tab, c, (float*)workspace, B, T);

@@ -36,6 +36,7 @@ SIGNATURES = {
     "tdx_transpose_many": (_i, [_vp, _i, _vp]),
     "tdx_conv3_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_uses_ring": (_i, [_i] * 7),
+    "tdx_conv3_fwd_kernel": (_i, [_i] * 9),
     "tdx_conv3_fwd_gn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_fwd_partial": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_bwd_data_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "tdx_convg_apply": (_i, [_vp, _vp, _vp, _vp] + [_i] * 16 + [_vp]),
     "tdx_convg_fold_clamp": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_convg_bwd_weight": (_i, [_vp, _vp, _vp, _vp] + [_i] * 15 + [_vp]),
+    "tdx_film_supported": (_i, [_i, _i]),
     "tdx_film_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "tdx_film_bwd_workspace_bytes": (_sz, [_i, _i, _vp, _i]),
     "tdx_film_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
@@ -127,29 +129,43 @@ def load() -> C.CDLL:
     return _lib
 
 
-_SCRATCH = {}  # device index -> arena tensor (kept alive for the life of the process); "active" -> registered index
+_SCRATCH = {}  # (device index, stream handle) -> arena tensor (kept alive for the life of the process); "active" -> key
 SCRATCH_BYTES = int(os.environ.get("TDX_SCRATCH_MB", "96")) << 20
+# entry points that may use the arena (K-split slabs of the small-grid kernels, the zero block of the DMA kernels)
+ARENA_USERS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_fwd_partial", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add",
+               "tdx_conv3_bwd_weight"}
 
 
-def ensure_scratch(device) -> None:
-    """Hand the library its scratch arena on `device` (tdx_set_scratch: K-split slabs of the small-grid conv kernel
-    on the deep U-Net levels).  One process drives one GPU; a process that touches several registers the arena of the
-    device it is launching on.  TDX_SCRATCH_MB=0: no arena (those layers then run on the brick kernels)."""
-    idx = torch.device(device).index
+def ensure_scratch(device=None) -> None:
+    """Hand the library its scratch arena for (`device`, the CURRENT stream) -- tdx_set_scratch: K-split slabs of the
+    small-grid conv kernels on the deep U-Net levels, zero block of the LDS-DMA kernels.  The library keeps ONE arena
+    pointer per process and its kernels get it as a launch argument, so the binding is per launch: every stream that
+    launches convs owns its own arena (a hipGraph captured on a side stream keeps replaying on that stream's arena while
+    eager work on another stream uses another: no sharing, no race), and `call` re-binds whenever the launching stream
+    changes.  TDX_SCRATCH_MB=0: no arena (those layers then run on the brick kernels)."""
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
-    if _SCRATCH.get("active") == idx:
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    if _SCRATCH.get("active") == key:
         return
     if SCRATCH_BYTES <= 0:
         load().tdx_set_scratch(None, 0)
-        _SCRATCH["active"] = idx
+        _SCRATCH["active"] = key
         return
-    buf = _SCRATCH.get(idx)
+    buf = _SCRATCH.get(key)
     if buf is None:
-        buf = _SCRATCH[idx] = torch.zeros(SCRATCH_BYTES, dtype=torch.uint8, device=torch.device("cuda", idx))
+        with torch.cuda.device(idx):
+            buf = _SCRATCH[key] = torch.zeros(SCRATCH_BYTES, dtype=torch.uint8, device=torch.device("cuda", idx))
     rc = load().tdx_set_scratch(buf.data_ptr(), buf.numel())
     if rc != 0:
         raise RuntimeError(f"tdx_set_scratch failed: {rc}")
-    _SCRATCH["active"] = idx
+    _SCRATCH["active"] = key
+
+
+def scratch_arena(device=None):
+    """The arena tensor bound to (`device`, current stream), or None (tests)."""
+    ensure_scratch(device)
+    return _SCRATCH.get(_SCRATCH["active"])
 
 
 def dtype_code(dt: torch.dtype) -> int:
@@ -192,7 +208,8 @@ def ptr(t: torch.Tensor | None):
         raise RuntimeError("tdx kernels need device tensors (no CPU path exists in the product)")
     if not t.is_contiguous():
         raise RuntimeError("tdx kernels need contiguous tensors")
-    if _SCRATCH.get("active") != t.device.index:
+    act = _SCRATCH.get("active")
+    if act is None or act[0] != t.device.index:
         ensure_scratch(t.device)
     return t.data_ptr()
 
@@ -210,31 +227,39 @@ class KernelTimer:
 
     def __init__(self, names):
         self.names = set(names)
-        self.records = []  # (name, start_event, end_event, work)
+        self.records = []  # (name, start_event, end_event, work, meta)
         self.pending_work = 0.0
 
-    def summary(self):
+    def summary(self, where=None):
+        """{name: launches / ms / work / bytes}; `where(meta)` selects records (meta = what the caller attached:
+        e.g. the kernel family and the algorithmic bytes of a conv call)."""
         torch.cuda.synchronize()
         out = {}
-        for name, s, e, work in self.records:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+        for name, s, e, work, meta in self.records:
+            if where is not None and not where(meta or {}):
+                continue
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["work"] += work
+            d["bytes"] += (meta or {}).get("bytes", 0.0)
         return out
 
 
 TIMER: KernelTimer | None = None
 
 
-def call(name: str, *args, work: float = 0.0):
+def call(name: str, *args, work: float = 0.0, meta=None):
+    """meta: None, a dict, or a zero-argument callable returning one (evaluated only while a timer is attached)."""
+    if name in ARENA_USERS:
+        ensure_scratch()  # the arena of the launching stream
     t = TIMER
     if t is not None and name in t.names:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         rc = getattr(load(), name)(*args)
         e.record()
-        t.records.append((name, s, e, work))
+        t.records.append((name, s, e, work, meta() if callable(meta) else meta))
     else:
         rc = getattr(load(), name)(*args)
     if rc != 0:
@@ -243,3 +268,15 @@ def call(name: str, *args, work: float = 0.0):
 
 def query(name: str, *args) -> int:
     return int(getattr(load(), name)(*args))
+
+
+KERNEL_DIRECT, KERNEL_BRICK, KERNEL_SMALL, KERNEL_RING = 0, 1, 2, 3  # TDX_KERNEL_* (tdx_conv3_fwd_kernel)
+
+
+def conv3_fwd_meta(C1, C2, Cout, B, X, Y, Z, dt, real=None):
+    """Bookkeeping of one forward conv call for the timers: the kernel family that serves it and its algorithmic HBM
+    bytes (input + output + weights once; `real` = input channels that carry data)."""
+    es = 2 if dt == torch.bfloat16 else 4
+    cin = real or (C1 + C2)
+    return {"kind": query("tdx_conv3_fwd_kernel", C1, C2, Cout, B, X, Y, Z, dtype_code(dt), conv_impl()),
+            "bytes": float((cin + Cout) * B * X * Y * Z * es + 27 * cin * Cout * es)}

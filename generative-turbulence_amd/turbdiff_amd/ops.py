@@ -326,11 +326,12 @@ class _Conv3(torch.autograd.Function):
             ws = _clean_ws(L.query("tdx_gn_workspace_bytes", B, Cout), x1.device)
             L.call("tdx_conv3_fwd_gn", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats),
                    gn_groups, float(gn_eps), L.ptr(ws), B, X, Y, Z, Cout, L.dtype_code(dt), L.conv_impl() | WS_CLEAN,
-                   L.stream(), work=flops)
+                   L.stream(), work=flops, meta=lambda: L.conv3_fwd_meta(C1, C2, Cout, B, X, Y, Z, dt))
             ctx.mark_non_differentiable(stats)
             return y, stats
         L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Cout,
-               L.dtype_code(dt), L.conv_impl(), L.stream(), work=flops)
+               L.dtype_code(dt), L.conv_impl(), L.stream(), work=flops,
+               meta=lambda: L.conv3_fwd_meta(C1, C2, Cout, B, X, Y, Z, dt))
         return y
 
     @staticmethod
@@ -743,6 +744,15 @@ class _FilmProjections(torch.autograd.Function):
 
 def film_projections(c: torch.Tensor, linears) -> list:
     """[(2, B, C_i) f32 tensor: scale, shift] for each nn.Linear(c_dim, 2 * C_i) in `linears`, all in one launch."""
+    B, T = c.shape
+    if not L.query("tdx_film_supported", B, T):
+        # batches whose conditioning vectors do not fit the kernels' LDS (B * T * 4 > 160 KiB, i.e. hundreds of
+        # samples): the reference's own per-block nn.Linear + chunk (ddpm.py:191-192) through torch
+        out = []
+        for lin in linears:
+            f = torch.nn.functional.linear(c.float(), lin.weight.float(), lin.bias.float())
+            out.append(torch.stack(f.chunk(2, dim=1)))
+        return out
     args = []
     for lin in linears:
         args += [lin.weight, lin.bias]
@@ -797,7 +807,8 @@ class _ResnetBlock(torch.autograd.Function):
             stats = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
             L.call("tdx_conv3_fwd_gn", L.ptr(xa), Ca, L.ptr(xb), Cb, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats), groups,
                    float(eps), L.ptr(gws), B, X, Y, Z, Cout, code, impl | WS_CLEAN, st,
-                   work=54.0 * (real or (Ca + Cb)) * Cout * B * V)
+                   work=54.0 * (real or (Ca + Cb)) * Cout * B * V,
+                   meta=lambda: L.conv3_fwd_meta(Ca, Cb, Cout, B, X, Y, Z, dt, real))
             return y, stats
 
         if partial is not None:

@@ -83,7 +83,11 @@ class GraphSampler:
             self._step()
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # capture on the warm-up stream: the conv kernels' scratch arena is bound per stream (_lib.ensure_scratch), the
+        # warm-up step created this stream's, so nothing is allocated inside the capture and the replayed graph never
+        # shares an arena with eager work on another stream
+        self._capture_stream = s
+        with torch.cuda.graph(self.graph, stream=s):
             self._step()
         self.x_t.copy_(state[0]); self.t.copy_(state[1]); self.offset.copy_(state[2])
         # The graph has the addresses of the packed weight operands (ops._pack_cache) baked in.  Keep those

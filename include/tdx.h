@@ -118,6 +118,13 @@ int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, const void* wf
  * of whole 8x8x8 bricks that fill the chip, i.e. the two finest U-Net levels), 0 = the brick / small-grid kernels.
  * For a data gradient pass the layer's (Cout, 0, Cin) as (C1, C2, Cout). */
 int tdx_conv3_uses_ring(int C1, int C2, int Cout, int B, int X, int Y, int Z);
+/* Kernel family that tdx_conv3_fwd / tdx_conv3_fwd_gn run for a call with these arguments (same bookkeeping purpose):
+ * vector-ALU, brick MFMA kernels (tdx_conv3_mfma*.hip), small-grid kernel (tdx_conv3_small.hip), ring kernel. */
+#define TDX_KERNEL_DIRECT 0
+#define TDX_KERNEL_BRICK 1
+#define TDX_KERNEL_SMALL 2
+#define TDX_KERNEL_RING 3
+int tdx_conv3_fwd_kernel(int C1, int C2, int Cout, int B, int X, int Y, int Z, int dtype, int impl);
 
 /* Same convolution, additionally producing the GroupNorm(G, Cout, eps) statistics of its own
  * output -- stats [B][G][2] = (mean, rstd), as tdx_gn_stats would -- from per-channel moments
@@ -365,7 +372,12 @@ typedef struct {
     const float* weight;
     const float* bias;
     float* out;
-    int channels; /* C_i */
+    int channels; /* 1 if tdx_film_fwd and tdx_film_bwd take a batch of B conditioning vectors of T features (they keep the batch's
+ * vectors in LDS: B*T*4 bytes forward, (B*T + 64*(B+1) + 64*(T+1))*4 backward, at most 160 KiB); otherwise a host
+ * projects per block with its own GEMM (turbdiff_amd.ops.film_projections does), as ddpm.py:191-192 does. */
+int tdx_film_supported(int B, int T);
+
+/* C_i */
 } TdxFilmLayer;
 int tdx_film_fwd(const float* c, int B, int T, const TdxFilmLayer* layers, int n, void* stream);
 /* grad_out (2, B, C_i) -> grad_weight (2 C_i, T), grad_bias (2 C_i) or NULL; dc (B, T) = the sum over all layers of

@@ -781,8 +781,7 @@ def test_conv3_small_grid_kernel_vs_brick_kernels(case, mode, monkeypatch):
         return y, stats, y2, gx1, gx2
 
     monkeypatch.setenv("TDX_CONV3_SMALL_ROWS", "30000")  # also the 24 x 8 x 6 shapes, which the product leaves to the brick kernels
-    L.ensure_scratch(d)
-    arena = L._SCRATCH[d.index]
+    arena = L.scratch_arena(d)
     arena[64:].zero_()
     small = run()
     assert int(arena[64:].count_nonzero()) > 0, "the small-grid kernel did not run"
@@ -818,9 +817,11 @@ def test_conv3_small_grid_kernel_vs_brick_kernels(case, mode, monkeypatch):
 ])
 def test_conv3_ring_kernel_vs_brick_kernel(case, monkeypatch):
     """The persistent LDS-DMA ring kernel (tdx_conv3_ring.hip) against the brick kernel it replaces on the two finest
-    levels: same MFMA order, so the forward output and the data gradient (main term + halo shell, with addends, split
-    over two tensors) must agree BIT FOR BIT; the fused GroupNorm statistics (summed in a different order) to 1e-5.
-    Run twice to catch copies that outlive a launch or arrive late (counted vmcnt waits)."""
+    levels: the same bf16 products accumulated in fp32 in a different order (8-channel units, taps in pairs, bias first),
+    so forward output and data gradient (main term + halo shell, with addends, split over two tensors) agree to fp32
+    summation noise after one bf16 rounding (rel-L2 < 5e-4, a few per cent of the elements one ulp apart), the fused
+    GroupNorm statistics to 1e-5; and the smallest case against the fp64 oracle.  Run twice to catch copies that outlive
+    a launch or arrive late (counted vmcnt waits)."""
     from turbdiff_amd import _lib as L, ops
 
     B, C1, C2, Co, (X, Y, Z) = case
@@ -858,33 +859,81 @@ def test_conv3_ring_kernel_vs_brick_kernel(case, monkeypatch):
     monkeypatch.setenv("TDX_CONV3_RING", "0")
     brick = run()
     monkeypatch.setenv("TDX_CONV3_RING", "2")
+    names = ["y", "stats", "y (no bias, no stats)", "gx1", "gx2", "gx1 (no addend)", "gx2 (no addend)"]
     for rep in range(2):
         ring = run()
-        for n, a, b in zip(["y", "stats", "y (no bias, no stats)", "gx1", "gx2", "gx1 (no addend)", "gx2 (no addend)"], ring, brick):
+        for n, a, b in zip(names, ring, brick):
             if a is None:
                 continue
             assert torch.isfinite(a.float()).all(), n
             if n == "stats":
                 assert rel_l2(a, b) < 1e-5, (n, case, rep)
-            elif n.startswith("gx"):
-                # interior voxels carry the conv kernel's term only: exact.  Boundary voxels also receive the halo-shell
-                # kernel's read-add-write / bf16 atomic adds, whose rounding depends on arrival order (both paths)
-                assert torch.equal(a[:, 1:-1, 1:-1, 1:-1], b[:, 1:-1, 1:-1, 1:-1]), (n, case, rep)
-                assert rel_l2(a.float(), b.float()) < 4e-3, (n, case, rep)
-            elif n == "y":
-                # the ring kernel starts its accumulators from the bias, the brick kernel adds it last: same fp32 sum in a
-                # different order -> an occasional last-bit difference after rounding to bf16
-                assert rel_l2(a.float(), b.float()) < 1e-3 and (a != b).float().mean() < 0.02, (n, case, rep)
             else:
-                assert torch.equal(a, b), (n, case, rep, rel_l2(a.float(), b.float()))
+                assert rel_l2(a.float(), b.float()) < 5e-4 and (a != b).float().mean() < 0.05, (n, case, rep)
+        if rep == 0:
+            first = ring
+        else:  # run-to-run: the conv kernel itself is deterministic (interior voxels carry no halo-shell atomics)
+            assert torch.equal(ring[0], first[0]) and torch.equal(ring[2], first[2])
+            assert torch.equal(ring[3][:, 1:-1, 1:-1, 1:-1], first[3][:, 1:-1, 1:-1, 1:-1])
+    if X * Y * Z <= 4096:  # the fp64 oracle: replicate-padded conv and its adjoint
+        xr = torch.cat([x1] + ([x2] if C2 else []), dim=-1).double().cpu().permute(0, 4, 1, 2, 3).requires_grad_()
+        yr = O.conv3_replicate(xr, w.to(dt).double().cpu(), bias.double().cpu())
+        yr.backward(gy.double().cpu().permute(0, 4, 1, 2, 3))
+        assert rel_l2(ring[0].float().cpu().permute(0, 4, 1, 2, 3), yr) < 4e-3
+        gx = torch.cat([ring[5]] + ([ring[6]] if C2 else []), dim=-1).float().cpu()
+        assert rel_l2(gx.permute(0, 4, 1, 2, 3), xr.grad) < 6e-3
     # the switch does select the kernel: with one workgroup per CU the ring launch leaves the brick path's timing,
     # not its results; check the dispatcher's own report instead
     assert bool(L.query("tdx_conv3_uses_ring", C1, C2, Co, B, X, Y, Z))
 
 
 @pytest.mark.gpu
+def test_scratch_arena_is_per_stream():
+    """The library holds one arena pointer, bound per launch to the launching stream's arena (_lib.ensure_scratch): convs
+    that use it (K-split slabs of the small-grid kernel) run concurrently on two streams, many times over, with different
+    operands and must each reproduce their single-stream result; the two streams own different arenas; a GraphSampler's
+    graph is captured on a stream of its own (tests/test_hip_model.py::test_graph_sampler_equals_eager_loop replays it
+    next to eager steps)."""
+    from turbdiff_amd import _lib as L, ops
+
+    d = dev()
+    B, C, X, Y, Z = 6, 512, 12, 4, 3
+    g = torch.Generator(device=d).manual_seed(21)
+    xs = [torch.randn(B, X, Y, Z, C, device=d, generator=g).bfloat16() for _ in range(2)]
+    ws = [torch.randn(C, C, 3, 3, 3, device=d, generator=g) * 0.02 for _ in range(2)]
+    packed = [ops._packed_conv3(w, torch.bfloat16)[0] for w in ws]
+
+    def conv(i, y):
+        L.call("tdx_conv3_fwd", L.ptr(xs[i]), C, None, 0, L.ptr(packed[i]), None, L.ptr(y), B, X, Y, Z, C, L.BF16, L.CONV_AUTO,
+               L.stream())
+
+    refs = []
+    for i in range(2):
+        y = torch.empty(B, X, Y, Z, C, device=d, dtype=torch.bfloat16)
+        conv(i, y)
+        refs.append(y)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[torch.empty_like(refs[0]) for _ in range(20)] for _ in range(2)]
+    arenas = []
+    for k in range(20):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                conv(i, outs[i][k])
+                if k == 0:
+                    arenas.append(L.scratch_arena(d).data_ptr())
+    torch.cuda.synchronize()
+    assert arenas[0] != arenas[1] and L.scratch_arena(d).data_ptr() not in arenas
+    for i in range(2):
+        for k in range(20):
+            assert torch.equal(outs[i][k], refs[i]), (i, k)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,T,chans", [(6, 32, (64, 64, 128, 256, 512, 512, 32)), (1, 96, (8,)), (19, 64, (40, 24, 512)),
-                                       (3, 32, tuple([16] * 37))])
+                                       (3, 32, tuple([16] * 37)),
+                                       (200, 32, (64, 32)),    # 85 KiB of LDS in the backward: above the default 48 KiB cap
+                                       (600, 32, (64, 32))])   # beyond the kernels' 160 KiB: per-block torch projection
 def test_film_projections_match_linear(B, T, chans):
     """tdx_film_fwd / tdx_film_bwd (all ResnetBlocks' nn.Linear(c_dim, 2 C) + chunk in one launch, reference
     ddpm.py:184,191-192) against F.linear in fp64: outputs, and the gradients of c, every weight and every bias; more
@@ -991,6 +1040,54 @@ def test_conv1_weight_gradient_in_parameter_layout(dt, C1, C2, Cout):
     old = torch.empty(C1, Cout, device=d)
     L.call("tdx_conv1_bwd_weight", L.ptr(x1), C1, L.ptr(gy), Cout, L.ptr(old), Cout, None, rows, L.dtype_code(dt), L.stream())
     assert rel_l2(gw[:, :C1].t().cpu(), old.cpu()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # B, C1, C2, Cout, grid: 64-wide output tiles; whole and ragged bricks (zero rows from the arena's zero block), two
+    # inputs, a half-filled last ci tile (C1 = 16), several co tiles, few and many bricks per workgroup, level-0 size
+    (2, 64, 0, 64, (32, 32, 16)), (1, 32, 32, 64, (48, 32, 24)), (2, 16, 0, 64, (32, 16, 16)), (1, 64, 0, 128, (20, 18, 13)),
+    (3, 32, 0, 64, (9, 17, 10)), (1, 64, 0, 64, (96, 32, 24)), (2, 64, 0, 64, (192, 64, 48)), (6, 128, 0, 256, (48, 16, 12)),
+])
+def test_conv3_weight_gradient_dma_kernel_vs_brick_kernel(case, monkeypatch):
+    """The LDS-DMA double-buffered weight-gradient kernel (tdx_conv3_wgrad_ring.hip) against the brick kernel it replaces
+    for 64-wide output tiles (TDX_WGRAD_RING = 1 / 0): same per-workgroup partial sums, merged by fp32 atomics or slabs in
+    a different order -> 2e-6; the bias gradient comes from an all-ones MFMA slot instead of the staging registers; the
+    workspace is left zero; and the fp64 sums on the small cases.  Twice: the second call catches stale LDS / late copies."""
+    from turbdiff_amd import _lib as L
+
+    B, C1, C2, Co, (X, Y, Z) = case
+    d = dev()
+    Ci = C1 + C2
+    g = torch.Generator(device=d).manual_seed(13)
+    rn = lambda *s: torch.randn(*s, device=d, generator=g)
+    x1, x2 = rn(B, X, Y, Z, C1).bfloat16(), (rn(B, X, Y, Z, C2).bfloat16() if C2 else None)
+    gy = rn(B, X, Y, Z, Co).bfloat16()
+    st = L.stream()
+    L.ensure_scratch(d)
+    ws = torch.zeros(L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, L.CONV_AUTO), dtype=torch.uint8, device=d)
+
+    def run(ring):
+        monkeypatch.setenv("TDX_WGRAD_RING", str(ring))
+        monkeypatch.setenv("TDX_WGRAD_SMALL_ROWS", "0")
+        dw, db = torch.empty(Co, Ci, 3, 3, 3, device=d), torch.empty(Co, device=d)
+        L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(dw), L.ptr(db), B, X, Y, Z, Co, L.BF16,
+               L.CONV_AUTO | L.WS_CLEAN, L.ptr(ws), st)
+        torch.cuda.synchronize()
+        assert int(ws[: (27 * Ci * Co + Co) * 4].count_nonzero()) == 0
+        return dw, db
+
+    brick = run(0)
+    for rep in range(2):
+        ring = run(1)
+        assert torch.isfinite(ring[0]).all() and torch.isfinite(ring[1]).all()
+        assert rel_l2(ring[0], brick[0]) < 2e-6 and rel_l2(ring[1], brick[1]) < 2e-6, (case, rep)
+    if B * X * Y * Z <= 20000:
+        xr = torch.cat([x1] + ([x2] if C2 else []), dim=-1).double().cpu().permute(0, 4, 1, 2, 3)
+        w = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        bz = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+        O.conv3_replicate(xr, w, bz).backward(gy.double().cpu().permute(0, 4, 1, 2, 3))
+        assert rel_l2(ring[0].cpu(), w.grad) < 1e-5 and rel_l2(ring[1].cpu(), bz.grad) < 1e-5
 
 
 @pytest.mark.gpu

@@ -56,43 +56,41 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
     const double fl = 54.0 * Cin * Cout * B * X * Y * Z;
-    const int nsl = Cin / 16;
     printf("# ring kernel Cin %d Cout %d grid %dx%dx%d B %d zero_pad %d: %.3f ms/launch, %.0f TFLOP/s (with stamps)\n", Cin, Cout, X, Y, Z, B,
            (int)zp, ms, fl / ms / 1e9);
     std::vector<unsigned long long> h(nrec);
     hipMemcpy(h.data(), rg_stamp_buffer, nrec * 8, hipMemcpyDeviceToHost);
-    // per brick: 3 nsl units x 3 stamps (top, landed, barrier passed) then 3 epilogue stamps
-    const int per_brick = 9 * nsl + 3;
-    double wait = 0, bar = 0, body = 0, epi_bar = 0, epi = 0, gap = 0, brick = 0;
+    // per brick: nun units x 3 stamps (top, own copies landed, barrier passed), then "last MFMA issued", "stores issued"
+    const int nun = Cin / 8, per_brick = 3 * nun + 2;
+    const int nbk = 2 * per_brick <= RG_NSTAMP ? 2 : 1;
+    double wait = 0, bar = 0, body = 0, epi = 0, gap = 0, brick = 0;
     std::vector<long long> bodies, waits, bars;
     size_t n = 0, nu = 0;
     for (size_t wv = 0; wv < (size_t)256 * RG_WAVES; ++wv) {
         const unsigned long long* rec = &h[wv * (RG_NSTAMP + 1)];
-        if ((int)rec[0] < 2 * per_brick) continue;
+        if ((int)rec[0] < nbk * per_brick) continue;
         const unsigned long long* s = rec + 1;
-        for (int bk = 0; bk < 2; ++bk) {
+        for (int bk = 0; bk < nbk; ++bk) {
             const unsigned long long* q = s + bk * per_brick;
-            for (int u = 0; u < 3 * nsl; ++u) {
+            for (int u = 0; u < nun; ++u) {
                 const unsigned long long top = q[3 * u], landed = q[3 * u + 1], passed = q[3 * u + 2];
-                const unsigned long long next = u + 1 < 3 * nsl ? q[3 * u + 3] : q[9 * nsl];
+                const unsigned long long next = u + 1 < nun ? q[3 * u + 3] : q[3 * nun];
                 wait += (double)(landed - top); bar += (double)(passed - landed); body += (double)(next - passed);
                 waits.push_back((long long)(landed - top)); bars.push_back((long long)(passed - landed)); bodies.push_back((long long)(next - passed));
                 ++nu;
             }
-            epi_bar += (double)(q[9 * nsl + 1] - q[9 * nsl]);
-            epi += (double)(q[9 * nsl + 2] - q[9 * nsl + 1]);
-            if (bk == 0) { gap += (double)(q[per_brick] - q[9 * nsl + 2]); brick += (double)(q[per_brick] - q[0]); }
+            epi += (double)(q[3 * nun + 1] - q[3 * nun]);
+            if (bk == 0 && nbk == 2) { gap += (double)(q[per_brick] - q[3 * nun + 1]); brick += (double)(q[per_brick] - q[0]); }
         }
         ++n;
     }
     if (!n) { printf("no stamps\n"); return 1; }
     auto pct = [](std::vector<long long>& v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
-    printf("# %zu waves; per unit (shader cycles; ideal MFMA time of a unit = %d per wave, x2 for the two waves of a SIMD):\n", n, 9 * (Cout % 64 == 0 ? 4 : 2) * 32);
+    printf("# %zu waves; per unit = 8 channels x 28 taps (shader cycles; MFMA time of a unit = %d per wave, x2 for the two waves of a SIMD):\n", n, 14 * 4 * 32);
     printf("#   wait for own copies   mean %.0f  p50 %lld p90 %lld p99 %lld\n", wait / nu, pct(waits, .5), pct(waits, .9), pct(waits, .99));
     printf("#   barrier               mean %.0f  p50 %lld p90 %lld p99 %lld\n", bar / nu, pct(bars, .5), pct(bars, .9), pct(bars, .99));
     printf("#   body (MFMA + DMA)     mean %.0f  p50 %lld p90 %lld p99 %lld\n", body / nu, pct(bodies, .5), pct(bodies, .9), pct(bodies, .99));
-    printf("# per brick: epilogue barrier %.0f, epilogue (tiles, stores, stats) %.0f, to next unit top %.0f; brick period %.0f cycles\n",
-           epi_bar / (2 * n), epi / (2 * n), gap / n, brick / n);
+    printf("# per brick: epilogue (tiles, stores, stats) %.0f, to next unit top %.0f; brick period %.0f cycles\n", epi / (nbk * n), gap / n, brick / n);
     // one wave's raw timeline
     const unsigned long long* rec = &h[0];
     printf("wave 0 of workgroup 0:");

@@ -46,7 +46,7 @@ lines += ["", "## HBM traffic and SQ counters of the matrix-core conv kernels (a
 traffic = {}
 durs = {r["Name"]: float(r["AverageNs"]) for r in rows}
 for k in sorted(set(list(fetch) + list(write))):
-    if not any(t in k for t in ("conv3_mfma_kernel", "wgrad_mfma", "conv3_mfma_split", "conv3_mfma_f32", "conv1_f32_mfma", "conv3_shell")):
+    if not any(t in k for t in ("conv3_ring_kernel", "conv3_small_kernel", "conv3_mfma_kernel", "wgrad_mfma", "conv3_mfma_split", "conv3_mfma_f32", "conv1_f32_mfma", "conv3_shell")):
         continue
     f_kb = mean(fetch[k].get("FETCH_SIZE", [0])); w_kb = mean(write[k].get("WRITE_SIZE", [0]))
     rd, wr = 2 * f_kb * 1024, w_kb * 1024
