@@ -47,6 +47,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define RG_WSLOTS 3                     // weight ring (lookahead 2 units)
 #define RG_WAVES 8
 #define RG_STEPS 14                     // K steps per unit: tap pairs (2p, 2p + 1); tap 27 is the zero dummy
+#ifndef RG_DEFAULT_LOADERS
+#define RG_DEFAULT_LOADERS 1            // loader waves by default? (TDX_RING_LOADERS overrides per call)
+#endif
 
 struct RingArgs {
     const bf16* x1; const bf16* x2; int C1, C2;
@@ -100,8 +103,13 @@ __device__ __forceinline__ int rg_tile_addr(int v, int c) {  // wave-private [32
     return v * 64 + ((c ^ ((v >> 1) & 3)) << 4);
 }
 
-template <int NT>
+// LW = 0: the 8 computing waves issue the copies themselves (one per K step).  LW = 4: four extra LOADER waves (one more
+// wave per SIMD) issue every copy, wait for their arrival and meet the computing waves at the unit barrier; the
+// computing waves then carry no vector-memory instruction in their MFMA stream (an LDS-DMA instruction costs the issuing
+// wave ~150 cycles there: profiles/r10_ring_stamps.txt, ablations).
+template <int NT, int LW = 0>
 struct RingShape {
+    static constexpr int IW = LW ? LW : 8;                  // waves that issue copies
     static constexpr int BN = NT * 32;
     static constexpr int MT = 4 / NT;                       // M tiles per wave
     static constexpr int XP = MT / 2;                       // x planes per wave
@@ -109,10 +117,10 @@ struct RingShape {
     static constexpr int ENT = (BX + 2) * RG_HY * RG_SZ;    // LDS entries of a brick image (16 B = 8 channels of a voxel)
     static constexpr int APIECES = (ENT + 63) / 64;         // 1-KiB DMA pieces: 19 / 34
     static constexpr int ABUF = APIECES * 1024;
-    static constexpr int BPW = (APIECES + RG_WAVES - 1) / RG_WAVES;  // brick pieces per wave and unit: 3 / 5
+    static constexpr int BPW = (APIECES + IW - 1) / IW;     // brick pieces per issuing wave and unit: 3 / 5 (LW = 4: 5 / 9)
     static constexpr int WPIECES = 28 * BN * 16 / 1024;     // 28 / 14
     static constexpr int WSLOT = WPIECES * 1024;
-    static constexpr int WPW = (WPIECES + RG_WAVES - 1) / RG_WAVES;  // weight pieces per wave and unit: 4 / 2
+    static constexpr int WPW = (WPIECES + IW - 1) / IW;     // weight pieces per issuing wave and unit: 4 / 2 (LW = 4: 7 / 4)
     static constexpr int TILE = 32 * BN * 2;                // wave-private output tile: 4 / 2 KiB
     static constexpr int CH = BN / 8;                       // 16-B chunks per output row
     static constexpr int VPI = 64 / CH;                     // voxels per store instruction
@@ -121,11 +129,11 @@ struct RingShape {
                                   64 /* zero entry */ + BN * 4 /* bias */ + (size_t)RG_WAVES * BN * 2 * 4 /* statistics */;
 };
 
-template <int NT, bool ZP>
-__global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
-    typedef RingShape<NT> S;
+template <int NT, bool ZP, int LW>
+__global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(RingArgs A) {
+    typedef RingShape<NT, LW> S;
     constexpr int BN = S::BN, MT = S::MT, XP = S::XP, BPW = S::BPW, WPW = S::WPW, CH = S::CH, VPI = S::VPI, NST = S::NST;
-    static_assert(BPW + WPW < RG_STEPS, "one DMA instruction per K step");
+    static_assert(LW > 0 || BPW + WPW < RG_STEPS, "one DMA instruction per K step");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* sA = smem;                                   // [2][ABUF]
     unsigned char* sW = sA + 2 * S::ABUF;                       // [RG_WSLOTS][WSLOT]: [28 taps][BN] x 16 B
@@ -140,6 +148,8 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
+    const bool loader = LW > 0 && wave >= RG_WAVES;
+    const int iw = LW ? wave - RG_WAVES : wave;                 // index among the issuing waves
 #ifdef RG_STAMPS
     // NT = 2: the statistics scratch is exactly 8 waves x 64 stamps; NT = 1: behind it (ring_go adds the bytes)
     unsigned long long* sStamp = reinterpret_cast<unsigned long long*>(NT == 2 ? sRed : sRed + RG_WAVES * BN * 2);
@@ -166,7 +176,7 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
     int hxyz[BPW];
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
-        const int pi = min(wave * BPW + i, S::APIECES - 1);
+        const int pi = min(max(iw, 0) * BPW + i, S::APIECES - 1);
         const int e = min(pi * 64 + lane, S::ENT - 1);
         const int hx = e / (RG_HY * RG_SZ), rem = e - hx * (RG_HY * RG_SZ);
         const int hy = rem / RG_SZ, hz = min(rem - hy * RG_SZ, 9);
@@ -177,7 +187,7 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
     unsigned wlane[WPW];
 #pragma unroll
     for (int j = 0; j < WPW; ++j) {
-        const int pj = min(wave * WPW + j, S::WPIECES - 1);
+        const int pj = min(max(iw, 0) * WPW + j, S::WPIECES - 1);
         const int e = pj * 64 + lane;
         wlane[j] = (unsigned)((min(e / BN, 26) * A.Cout + (e % BN)) * 32);
     }
@@ -227,7 +237,7 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
         const bf16* xs; int Cs, kk;
         if (k0 < A.C1) { xs = A.x1; Cs = A.C1; kk = k0; } else { xs = A.x2; Cs = A.C2; kk = k0 - A.C1; }
         const bf16* base = xs + ((int64_t)vb_b * V) * Cs + kk;  // uniform
-        const int pi = wave * BPW + i;
+        const int pi = iw * BPW + i;
         const unsigned dst = pi < S::APIECES ? ldsA + buf * S::ABUF + pi * 1024 : ldsD;
         if (ZP) {
             const bf16* src = vox[i] >= 0 ? base + (int64_t)vox[i] * Cs : reinterpret_cast<const bf16*>(A.zeros);
@@ -239,7 +249,7 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
     // piece j of the weights of 8-channel slice c8 -> ring slot
     auto issue_weight_piece = [&](int c8, int wslot, int j) {
         const bf16* base = A.wp + ((int64_t)((c8 >> 1) * 27) * A.Cout + n0) * 16 + (c8 & 1) * 8;  // uniform
-        const int pj = wave * WPW + j;
+        const int pj = iw * WPW + j;
         const unsigned dst = pj < S::WPIECES ? ldsW + wslot * S::WSLOT + pj * 1024 : ldsD;
         rg_dma_off(base, wlane[j], dst);
     };
@@ -278,19 +288,48 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
         for (int e = 0; e < 4; ++e) p1[e] = p2[e] = f32x2{0.f, 0.f};
     };
 
-    // ---- prologue: brick 0 / slice 0 and the weights of units 0 and 1
-    plan_brick(0);
-#pragma unroll
-    for (int i = 0; i < BPW; ++i) issue_brick_piece(0, 0, i);
-#pragma unroll
-    for (int j = 0; j < WPW; ++j) issue_weight_piece(0, 0, j);
-#pragma unroll
-    for (int j = 0; j < WPW; ++j) issue_weight_piece(1 % nun, 1, j);
+    // ---- prologue (issuing waves): brick 0 / slice 0 and the weights of units 0 and 1
     // cursors of what is issued next: slice qs of the planned brick qb; weights of unit uw (slice ws)
-    int qs = 1, qb = 0;
-    if (qs == nun) { qs = 0; qb = 1; plan_brick(1); }
-    int ws = 2 % nun, uw = 2;
+    int qs = 1, qb = 0, ws = 2 % nun, uw = 2;
     int u = 0;  // unit being computed
+    if (LW == 0 || loader) {
+        plan_brick(0);
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) issue_brick_piece(0, 0, i);
+#pragma unroll
+        for (int j = 0; j < WPW; ++j) issue_weight_piece(0, 0, j);
+#pragma unroll
+        for (int j = 0; j < WPW; ++j) issue_weight_piece(1 % nun, 1, j);
+        if (qs == nun) { qs = 0; qb = 1; plan_brick(1); }
+    }
+    if (LW > 0 && loader) {
+        // ---- loader waves: per unit, wait for the unit's operands (the only younger copies are the next unit's weights),
+        // meet the computing waves, then issue the next unit's brick and the weights of the unit after it.  They join
+        // every barrier the computing waves execute (the two of a statistics flush included).
+        for (int ord = 0; ord < nmine; ++ord) {
+            for (int c8 = 0; c8 < nun; ++c8, ++u) {
+                RG_VMCNT(WPW);
+                rg_barrier();
+#pragma unroll
+                for (int i = 0; i < BPW; ++i) issue_brick_piece(qs, (u + 1) & 1, i);
+#pragma unroll
+                for (int j = 0; j < WPW; ++j) issue_weight_piece(ws, uw % RG_WSLOTS, j);
+                ++uw;
+                if (++ws == nun) ws = 0;
+                if (++qs == nun) { qs = 0; ++qb; plan_brick(qb); }
+            }
+#ifndef RG_STAMPS
+            if (!ZP && A.gn_acc != nullptr) {
+                int b, nb = -1, t0, t1, t2;
+                brick_coords(ord, b, t0, t1, t2);
+                if (ord + 1 < nmine) brick_coords(ord + 1, nb, t0, t1, t2);
+                if (nb != b) { rg_barrier(); rg_barrier(); }
+            }
+#endif
+        }
+        RG_VMCNT(0);  // the wrapped copies of the last units must not outlive the workgroup's LDS
+        return;
+    }
     bool stores_behind = false;  // the previous brick's epilogue stores were issued after this unit's operands
 
     f32x16 acc[NT][MT];
@@ -315,7 +354,7 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
             // copies are the weights of the next unit; the stores of a brick's epilogue sit behind its successor's
             // first unit's operands
             RG_T();  // unit top
-            if (stores_behind) RG_VMCNT(WPW + NST); else RG_VMCNT(WPW);
+            if (LW == 0) { if (stores_behind) RG_VMCNT(WPW + NST); else RG_VMCNT(WPW); }
             stores_behind = false;
             RG_T();  // this wave's copies have landed
             rg_barrier();
@@ -367,10 +406,10 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
                 // them stalls the wave in the address queue while the matrix pipe drains): the next unit's brick behind
                 // steps 0 .. BPW - 1, the weights of the unit after it behind the following WPW
 #if !defined(RG_ABL) || !(RG_ABL & 1)  // (diagnostic ablation builds drop the copies: timing only)
-                if (p < BPW) issue_brick_piece(qs, (u + 1) & 1, p);
-                if (p >= BPW && p < BPW + WPW) issue_weight_piece(ws, uw % RG_WSLOTS, p - BPW);
+                if (LW == 0 && p < BPW) issue_brick_piece(qs, (u + 1) & 1, p);
+                if (LW == 0 && p >= BPW && p < BPW + WPW) issue_weight_piece(ws, uw % RG_WSLOTS, p - BPW);
 #endif
-                if (p == BPW + WPW) {
+                if (LW == 0 && p == BPW + WPW) {
                     ++uw;
                     if (++ws == nun) ws = 0;
                     if (++qs == nun) { qs = 0; ++qb; plan_brick(qb); }
@@ -444,7 +483,7 @@ __global__ void __launch_bounds__(512, 2) conv3_ring_kernel(RingArgs A) {
         }
 #endif
     }
-    RG_VMCNT(0);  // the wrapped copies of the last units must not outlive the workgroup's LDS
+    if (LW == 0) RG_VMCNT(0);  // the wrapped copies of the last units must not outlive the workgroup's LDS
 #ifdef RG_STAMPS
     if (lane == 0 && A.stamps != nullptr) {
         unsigned long long* rec = A.stamps + ((size_t)blockIdx.x * RG_WAVES + wave) * (RG_NSTAMP + 1);
@@ -478,20 +517,20 @@ bool conv3_ring_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z) 
 static unsigned long long* rg_stamp_buffer = nullptr;
 #endif
 
-template <int NT, bool ZP>
+template <int NT, bool ZP, int LW>
 static int ring_go(const RingArgs& a, hipStream_t st) {
-    size_t lds = RingShape<NT>::LDS;
+    size_t lds = RingShape<NT, LW>::LDS;
 #ifdef RG_STAMPS
     if (NT == 1) lds += (size_t)RG_WAVES * RG_NSTAMP * 8;
 #endif
-    auto kern = conv3_ring_kernel<NT, ZP>;
+    auto kern = conv3_ring_kernel<NT, ZP, LW>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512 + 64 * LW), lds, st, a);
     return tdx_launch_status();
 }
 
@@ -515,8 +554,14 @@ int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void
 #ifdef RG_STAMPS
     a.stamps = rg_stamp_buffer;
 #endif
-    if (NT == 2) return zero_pad ? ring_go<2, true>(a, st) : ring_go<2, false>(a, st);
-    return zero_pad ? ring_go<1, true>(a, st) : ring_go<1, false>(a, st);
+    const char* env = getenv("TDX_RING_LOADERS");  // A/B switch: 0 = the computing waves issue the copies themselves
+    const bool lw = env ? atoi(env) != 0 : RG_DEFAULT_LOADERS;
+    if (NT == 2) {
+        if (lw) return zero_pad ? ring_go<2, true, 4>(a, st) : ring_go<2, false, 4>(a, st);
+        return zero_pad ? ring_go<2, true, 0>(a, st) : ring_go<2, false, 0>(a, st);
+    }
+    if (lw) return zero_pad ? ring_go<1, true, 4>(a, st) : ring_go<1, false, 4>(a, st);
+    return zero_pad ? ring_go<1, true, 0>(a, st) : ring_go<1, false, 0>(a, st);
 }
 
 extern "C" int tdx_conv3_uses_ring(int C1, int C2, int Cout, int B, int X, int Y, int Z) {

@@ -366,19 +366,18 @@ int tdx_radam_step(const TdxOptTensor* table, const int* chunk_tensor, const int
  * the chunk into (scale, shift) (reference models/ddpm.py:184,191-192), and in the backward its three gradients.
  * c: (B, T) f32.  Layer i: weight (2 C_i, T), bias (2 C_i) or NULL, out (2, B, C_i) f32 -- out[0] = scale,
  * out[1] = shift, the dense (B, C) operands of tdx_gn_apply / tdx_gn_bwd.  `layers` is a HOST array of n <=
- * TDX_FILM_MAX_LAYERS entries (its pointers are device pointers); B * T <= 12288. */
+ * TDX_FILM_MAX_LAYERS entries (its pointers are device pointers); batch limits: tdx_film_supported. */
 #define TDX_FILM_MAX_LAYERS 32
 typedef struct {
     const float* weight;
     const float* bias;
     float* out;
-    int channels; /* 1 if tdx_film_fwd and tdx_film_bwd take a batch of B conditioning vectors of T features (they keep the batch's
+    int channels; /* C_i */
+} TdxFilmLayer;
+/* 1 if tdx_film_fwd and tdx_film_bwd take a batch of B conditioning vectors of T features (they keep the batch's
  * vectors in LDS: B*T*4 bytes forward, (B*T + 64*(B+1) + 64*(T+1))*4 backward, at most 160 KiB); otherwise a host
  * projects per block with its own GEMM (turbdiff_amd.ops.film_projections does), as ddpm.py:191-192 does. */
 int tdx_film_supported(int B, int T);
-
-/* C_i */
-} TdxFilmLayer;
 int tdx_film_fwd(const float* c, int B, int T, const TdxFilmLayer* layers, int n, void* stream);
 /* grad_out (2, B, C_i) -> grad_weight (2 C_i, T), grad_bias (2 C_i) or NULL; dc (B, T) = the sum over all layers of
  * grad_out_i^T-stacked @ weight_i (overwritten).  Deterministic (fixed summation order).  workspace:

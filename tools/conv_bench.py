@@ -70,6 +70,8 @@ def miopen_table(a):
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=6); ap.add_argument("--only", default="")
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--no-wgrad", action="store_true", help="skip the weight-gradient column")
+    ap.add_argument("--layers", default="", help="comma-separated layer names (exact), e.g. down.0.b1,up.3.b2")
     ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights (switching-activity experiment)")
     ap.add_argument("--miopen", action="store_true", help="time the same layers through F.conv3d (MIOpen) instead")
     ap.add_argument("--miopen-find", action="store_true", help="with --miopen: torch.backends.cudnn.benchmark = True")
@@ -85,6 +87,7 @@ def main():
     print(f"{'layer':12s} {'Cin':>5s} {'Cout':>5s} {'grid':>12s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
     for name, C1, C2, Co, (X, Y, Z) in LAYERS:
         if a.only and a.only not in name: continue
+        if a.layers and name not in a.layers.split(","): continue
         Ci = C1 + C2
         zf = 0.0 if a.zeros else 1.0
         x1 = (torch.randn(B, X, Y, Z, C1, device=dev) * zf).to(tdt)
@@ -103,7 +106,7 @@ def main():
         ws2 = torch.empty(L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, 0), dtype=torch.uint8, device=dev)
         wg = lambda: L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(gw), L.ptr(gb), B, X, Y, Z, Co, dc, im, L.ptr(ws2), st)
         fl = 54.0 * Ci * Co * B * X * Y * Z
-        tf, td, tw = (timeit(f, 10), 1e9, 1e9) if a.fwd_only else (timeit(f), timeit(d), timeit(wg))
+        tf, td, tw = (timeit(f, 10), 1e9, 1e9) if a.fwd_only else (timeit(f), timeit(d), 1e9 if a.no_wgrad else timeit(wg))
         mult = 4 if name == "center" else (2 if name in ("down.0.b1",) else 1)  # center x4; down.0.b1 == down.0.b2
         if name == "up.3.b2": mult = 3  # + decode.0.b1, decode.0.b2
         for k, t in (("fwd", tf), ("dgrad", td), ("wgrad", tw)): tot[k] += t * mult
