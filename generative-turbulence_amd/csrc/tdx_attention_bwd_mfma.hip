@@ -1,4 +1,4 @@
-// bf16 MFMA flash attention, backward (long token sequences; BASELINE config 5 sizes).  gfx950.
+// bf16 / fp16 MFMA flash attention, backward (long token sequences; BASELINE config 5 sizes).  gfx950.
 //
 // Same data layout and the same "swapped" MFMA orientation as the forward kernel
 // (tdx_attention_mfma.hip): a lane owns ONE row of the side its workgroup keeps resident, so every
@@ -34,36 +34,56 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 #define FB_RB (4 * FB_RW)  // resident rows per workgroup
 #define FB_LOG2E 1.4426950408889634f
 
+
+// operand element: bf16 (the model's bf16 mode) or fp16 (BASELINE configs[4]); see tdx_attention_mfma.hip
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+struct AttnBf16 {
+    typedef bf16 T;
+    typedef bf16x8 V8;
+    static __device__ __forceinline__ unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+struct AttnF16 {
+    typedef f16 T;
+    typedef f16x8 V8;
+    static __device__ __forceinline__ unsigned pack2(float a, float b) { return pack_f16x2(a, b); }
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
 // 64-B rows: chunk c of row r at c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 fragments)
 __device__ __forceinline__ int fb_sw64(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
 
-__device__ __forceinline__ bf16x8 fb_tr_frag(const unsigned char* lo, const unsigned char* hi) {
+template <typename V8>
+__device__ __forceinline__ V8 fb_tr_frag(const unsigned char* lo, const unsigned char* hi) {
     s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo));
     s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(hi));
     s16x8 r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, r);
+    return __builtin_bit_cast(V8, r);
 }
 
 // accumulator registers 8 s .. 8 s + 7 of a 32 x 32 tile -> bf16 B operand of k step s
-__device__ __forceinline__ bf16x8 fb_as_b(const f32x16& t, int s) {
-    return __builtin_bit_cast(bf16x8, make_uint4(pack_bf16x2(t[8 * s], t[8 * s + 1]), pack_bf16x2(t[8 * s + 2], t[8 * s + 3]),
-                                                  pack_bf16x2(t[8 * s + 4], t[8 * s + 5]), pack_bf16x2(t[8 * s + 6], t[8 * s + 7])));
+template <typename E>
+__device__ __forceinline__ typename E::V8 fb_as_b(const f32x16& t, int s) {
+    return __builtin_bit_cast(typename E::V8, make_uint4(E::pack2(t[8 * s], t[8 * s + 1]), E::pack2(t[8 * s + 2], t[8 * s + 3]),
+                                                         E::pack2(t[8 * s + 4], t[8 * s + 5]), E::pack2(t[8 * s + 6], t[8 * s + 7])));
 }
 
 // resident-side fragment as a B operand (col = row r of the side, k = d), optionally scaled
-__device__ __forceinline__ bf16x8 fb_row_frag(const bf16* row, float scale) {
-    Vec8<bf16> v;
+template <typename E>
+__device__ __forceinline__ typename E::V8 fb_row_frag(const typename E::T* row, float scale) {
+    Vec8<typename E::T> v;
     v.load(row);
     unsigned w[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = pack_bf16x2(v.v[2 * e] * scale, v.v[2 * e + 1] * scale);
-    return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+    for (int e = 0; e < 4; ++e) w[e] = E::pack2(v.v[2 * e] * scale, v.v[2 * e + 1] * scale);
+    return __builtin_bit_cast(typename E::V8, make_uint4(w[0], w[1], w[2], w[3]));
 }
 
 // ------------------------------------------------------------------ dQ ---------------------------
+template <typename E>
 __global__ void __launch_bounds__(256, 2)
-attn_bwd_dq_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, const float* __restrict__ lse,
-                        const float* __restrict__ delta, bf16* __restrict__ dqkv, int N, int H) {
+attn_bwd_dq_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E::T* __restrict__ dout, const float* __restrict__ lse,
+                        const float* __restrict__ delta, typename E::T* __restrict__ dqkv, int N, int H) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * FB_T * 64];
     unsigned char* sK = smem;                  // K tile, swizzled chunks (S^T = K Q^T: A operand rows = keys)
     unsigned char* sKp = smem + FB_T * 64;     // K tile, plain rows (K^T fragments by transposed reads)
@@ -73,11 +93,11 @@ attn_bwd_dq_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d
     const int r = lane & 31, hh = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int ld = 3 * H * FB_D;
-    const bf16* base = qkv + (int64_t)b * N * ld;
+    const typename E::T* base = qkv + (int64_t)b * N * ld;
     const int q0 = blockIdx.x * FB_RB + wave * FB_RW;
     const float sm_scale = rsqrtf((float)FB_D);
 
-    bf16x8 qf[2][2], gf[2][2];  // Q (pre-scaled) and dO as B operands: col = query r, k = d
+    typename E::V8 qf[2][2], gf[2][2];  // Q (pre-scaled) and dO as B operands: col = query r, k = d
     float lse2[2], dl[2];
     f32x16 dq[2];               // dQ^T[d][q]
 #pragma unroll
@@ -85,8 +105,8 @@ attn_bwd_dq_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d
         const int q = min(q0 + qt * 32 + r, N - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            qf[qt][ks] = fb_row_frag(base + (int64_t)q * ld + h * FB_D + ks * 16 + hh * 8, FB_LOG2E * sm_scale);
-            gf[qt][ks] = fb_row_frag(dout + ((int64_t)b * N + q) * (H * FB_D) + h * FB_D + ks * 16 + hh * 8, 1.0f);
+            qf[qt][ks] = fb_row_frag<E>(base + (int64_t)q * ld + h * FB_D + ks * 16 + hh * 8, FB_LOG2E * sm_scale);
+            gf[qt][ks] = fb_row_frag<E>(dout + ((int64_t)b * N + q) * (H * FB_D) + h * FB_D + ks * 16 + hh * 8, 1.0f);
         }
         lse2[qt] = lse[((int64_t)b * H + h) * N + q] * FB_LOG2E;
         dl[qt] = delta[((int64_t)b * H + h) * N + q];
@@ -98,7 +118,7 @@ attn_bwd_dq_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d
     uint4 kreg, vreg;
     auto load_tile = [&](int k0) {
         const int key = min(k0 + st_row, N - 1);
-        const bf16* kp = base + (int64_t)key * ld + H * FB_D + h * FB_D + st_c * 8;
+        const typename E::T* kp = base + (int64_t)key * ld + H * FB_D + h * FB_D + st_c * 8;
         kreg = *reinterpret_cast<const uint4*>(kp);
         vreg = *reinterpret_cast<const uint4*>(kp + H * FB_D);
     };
@@ -116,26 +136,26 @@ attn_bwd_dq_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d
 
         auto key_block = [&](int kb, auto tail_c) {
             constexpr bool TAIL = decltype(tail_c)::value;
-            bf16x8 kf[2], vf[2], ktf[2];
+            typename E::V8 kf[2], vf[2], ktf[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                kf[ks] = *reinterpret_cast<const bf16x8*>(sK + fb_sw64(kb * 32 + r, 2 * ks + hh));
-                vf[ks] = *reinterpret_cast<const bf16x8*>(sV + fb_sw64(kb * 32 + r, 2 * ks + hh));
+                kf[ks] = *reinterpret_cast<const typename E::V8*>(sK + fb_sw64(kb * 32 + r, 2 * ks + hh));
+                vf[ks] = *reinterpret_cast<const typename E::V8*>(sV + fb_sw64(kb * 32 + r, 2 * ks + hh));
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {  // K^T: rows = d, k = key 16 s + 8 (j >> 2) + 4 hh + (j & 3)
                 const unsigned char* kp = sKp + (kb * 32 + 16 * s + 4 * (g >> 1) + tq) * 64 + t_col;
-                ktf[s] = fb_tr_frag(kp, kp + 8 * 64);
+                ktf[s] = fb_tr_frag<typename E::V8>(kp, kp + 8 * 64);
             }
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 f32x16 st, dp;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[qt][0], st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[qt][1], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], gf[qt][0], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], gf[qt][1], dp, 0, 0, 0);
+                st = E::mfma(kf[0], qf[qt][0], st);
+                st = E::mfma(kf[1], qf[qt][1], st);
+                dp = E::mfma(vf[0], gf[qt][0], dp);
+                dp = E::mfma(vf[1], gf[qt][1], dp);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     float p = __builtin_amdgcn_exp2f(st[i] - lse2[qt]);
@@ -143,7 +163,7 @@ attn_bwd_dq_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d
                     st[i] = p * (dp[i] - dl[qt]);  // dS^T
                 }
 #pragma unroll
-                for (int s = 0; s < 2; ++s) dq[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[s], fb_as_b(st, s), dq[qt], 0, 0, 0);
+                for (int s = 0; s < 2; ++s) dq[qt] = E::mfma(ktf[s], fb_as_b<E>(st, s), dq[qt]);
             }
         };
         if (k0 + FB_T <= N) {
@@ -159,11 +179,11 @@ attn_bwd_dq_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + qt * 32 + r;
         if (q < N) {
-            bf16* op = dqkv + ((int64_t)b * N + q) * ld + h * FB_D;
+            typename E::T* op = dqkv + ((int64_t)b * N + q) * ld + h * FB_D;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint2 v = make_uint2(pack_bf16x2(dq[qt][4 * j] * sm_scale, dq[qt][4 * j + 1] * sm_scale),
-                                           pack_bf16x2(dq[qt][4 * j + 2] * sm_scale, dq[qt][4 * j + 3] * sm_scale));
+                const uint2 v = make_uint2(E::pack2(dq[qt][4 * j] * sm_scale, dq[qt][4 * j + 1] * sm_scale),
+                                           E::pack2(dq[qt][4 * j + 2] * sm_scale, dq[qt][4 * j + 3] * sm_scale));
                 *reinterpret_cast<uint2*>(op + 8 * j + 4 * hh) = v;
             }
         }
@@ -171,9 +191,10 @@ attn_bwd_dq_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d
 }
 
 // ------------------------------------------------------------------ dK, dV -----------------------
+template <typename E>
 __global__ void __launch_bounds__(256, 2)
-attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout, const float* __restrict__ lse,
-                         const float* __restrict__ delta, bf16* __restrict__ dqkv, int N, int H) {
+attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E::T* __restrict__ dout, const float* __restrict__ lse,
+                         const float* __restrict__ delta, typename E::T* __restrict__ dqkv, int N, int H) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * FB_T * 64 + 2 * FB_T * 4];
     unsigned char* sQ = smem;                   // Q tile, swizzled (S = Q K^T: A operand rows = queries)
     unsigned char* sQp = smem + FB_T * 64;      // Q tile, plain rows (Q^T fragments)
@@ -186,19 +207,19 @@ attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
     const int r = lane & 31, hh = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int ld = 3 * H * FB_D;
-    const bf16* base = qkv + (int64_t)b * N * ld;
+    const typename E::T* base = qkv + (int64_t)b * N * ld;
     const int j0 = blockIdx.x * FB_RB + wave * FB_RW;
     const float sm_scale = rsqrtf((float)FB_D);
 
-    bf16x8 kf[2][2], vf[2][2];  // K (pre-scaled) and V as B operands: col = key r, k = d
+    typename E::V8 kf[2][2], vf[2][2];  // K (pre-scaled) and V as B operands: col = key r, k = d
     f32x16 dk[2], dv[2];        // dK^T[d][key], dV^T[d][key]
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         const int key = min(j0 + kt * 32 + r, N - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            kf[kt][ks] = fb_row_frag(base + (int64_t)key * ld + H * FB_D + h * FB_D + ks * 16 + hh * 8, FB_LOG2E * sm_scale);
-            vf[kt][ks] = fb_row_frag(base + (int64_t)key * ld + 2 * H * FB_D + h * FB_D + ks * 16 + hh * 8, 1.0f);
+            kf[kt][ks] = fb_row_frag<E>(base + (int64_t)key * ld + H * FB_D + h * FB_D + ks * 16 + hh * 8, FB_LOG2E * sm_scale);
+            vf[kt][ks] = fb_row_frag<E>(base + (int64_t)key * ld + 2 * H * FB_D + h * FB_D + ks * 16 + hh * 8, 1.0f);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) dk[kt][i] = dv[kt][i] = 0.f;
@@ -233,17 +254,17 @@ attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
 
 #pragma unroll
         for (int qb = 0; qb < FB_T / 32; ++qb) {
-            bf16x8 qa[2], ga[2], qtf[2], gtf[2];
+            typename E::V8 qa[2], ga[2], qtf[2], gtf[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {  // A operands: row = query r, k = d
-                qa[ks] = *reinterpret_cast<const bf16x8*>(sQ + fb_sw64(qb * 32 + r, 2 * ks + hh));
-                ga[ks] = *reinterpret_cast<const bf16x8*>(sG + fb_sw64(qb * 32 + r, 2 * ks + hh));
+                qa[ks] = *reinterpret_cast<const typename E::V8*>(sQ + fb_sw64(qb * 32 + r, 2 * ks + hh));
+                ga[ks] = *reinterpret_cast<const typename E::V8*>(sG + fb_sw64(qb * 32 + r, 2 * ks + hh));
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {  // Q^T, dO^T: rows = d, k = query 16 s + 8 (j >> 2) + 4 hh + (j & 3)
                 const int off = (qb * 32 + 16 * s + 4 * (g >> 1) + tq) * 64 + t_col;
-                qtf[s] = fb_tr_frag(sQp + off, sQp + off + 8 * 64);
-                gtf[s] = fb_tr_frag(sGp + off, sGp + off + 8 * 64);
+                qtf[s] = fb_tr_frag<typename E::V8>(sQp + off, sQp + off + 8 * 64);
+                gtf[s] = fb_tr_frag<typename E::V8>(sGp + off, sGp + off + 8 * 64);
             }
             // per-register row scalars: register i <-> query row (i & 3) + 8 (i >> 2) + 4 hh of the block
             float lrow[16], drow[16];
@@ -259,10 +280,10 @@ attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
                 f32x16 st, dp;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[0], kf[kt][0], st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[1], kf[kt][1], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], vf[kt][0], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[1], vf[kt][1], dp, 0, 0, 0);
+                st = E::mfma(qa[0], kf[kt][0], st);
+                st = E::mfma(qa[1], kf[kt][1], st);
+                dp = E::mfma(ga[0], vf[kt][0], dp);
+                dp = E::mfma(ga[1], vf[kt][1], dp);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     st[i] = __builtin_amdgcn_exp2f(st[i] - lrow[i]);  // P
@@ -270,8 +291,8 @@ attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    dv[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gtf[s], fb_as_b(st, s), dv[kt], 0, 0, 0);
-                    dk[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[s], fb_as_b(dp, s), dk[kt], 0, 0, 0);
+                    dv[kt] = E::mfma(gtf[s], fb_as_b<E>(st, s), dv[kt]);
+                    dk[kt] = E::mfma(qtf[s], fb_as_b<E>(dp, s), dk[kt]);
                 }
             }
         }
@@ -281,26 +302,33 @@ attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ 
     for (int kt = 0; kt < 2; ++kt) {
         const int key = j0 + kt * 32 + r;
         if (key < N) {
-            bf16* okp = dqkv + ((int64_t)b * N + key) * ld + H * FB_D + h * FB_D;
-            bf16* ovp = okp + H * FB_D;
+            typename E::T* okp = dqkv + ((int64_t)b * N + key) * ld + H * FB_D + h * FB_D;
+            typename E::T* ovp = okp + H * FB_D;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 *reinterpret_cast<uint2*>(okp + 8 * j + 4 * hh) =
-                    make_uint2(pack_bf16x2(dk[kt][4 * j] * sm_scale, dk[kt][4 * j + 1] * sm_scale),
-                               pack_bf16x2(dk[kt][4 * j + 2] * sm_scale, dk[kt][4 * j + 3] * sm_scale));
+                    make_uint2(E::pack2(dk[kt][4 * j] * sm_scale, dk[kt][4 * j + 1] * sm_scale),
+                               E::pack2(dk[kt][4 * j + 2] * sm_scale, dk[kt][4 * j + 3] * sm_scale));
                 *reinterpret_cast<uint2*>(ovp + 8 * j + 4 * hh) =
-                    make_uint2(pack_bf16x2(dv[kt][4 * j], dv[kt][4 * j + 1]), pack_bf16x2(dv[kt][4 * j + 2], dv[kt][4 * j + 3]));
+                    make_uint2(E::pack2(dv[kt][4 * j], dv[kt][4 * j + 1]), E::pack2(dv[kt][4 * j + 2], dv[kt][4 * j + 3]));
             }
         }
     }
 }
 
 int attn_bwd_mfma_launch(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N,
-                         int H, hipStream_t st) {
+                         int H, int dtype, hipStream_t st) {
     dim3 grid(ceil_div(N, FB_RB), B * H);
-    hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse, delta,
-                       (bf16*)dqkv, N, H);
-    hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse, delta,
-                       (bf16*)dqkv, N, H);
+    if (dtype == TDX_F16) {
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<AttnF16>, grid, dim3(256), 0, st, (const f16*)qkv, (const f16*)dout, lse, delta,
+                           (f16*)dqkv, N, H);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<AttnF16>, grid, dim3(256), 0, st, (const f16*)qkv, (const f16*)dout, lse, delta,
+                           (f16*)dqkv, N, H);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<AttnBf16>, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse, delta,
+                           (bf16*)dqkv, N, H);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<AttnBf16>, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse, delta,
+                           (bf16*)dqkv, N, H);
+    }
     return tdx_launch_status();
 }

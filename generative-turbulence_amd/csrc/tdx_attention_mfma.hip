@@ -1,4 +1,4 @@
-// bf16 MFMA flash attention (forward) for long token sequences (BASELINE config 5:
+// bf16 / fp16 MFMA flash attention (forward) for long token sequences (BASELINE config 5:
 // N = 96*32*24 = 73 728 voxels, 4 heads x 32).  gfx950.
 //
 // qkv is the NDHWC to_qkv output [B][N][3*H*D] (q | k | v thirds, head-major), D = 32.
@@ -39,19 +39,43 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 // K tile rows of 64 B: chunk c of row r at c ^ ((r >> 2) & 3)  (conflict-free ds_read_b128, see conv1)
 __device__ __forceinline__ int fa_sw64(int r, int c) { return r * 64 + ((c ^ ((r >> 2) & 3)) << 4); }
 
-__device__ __forceinline__ bf16x8 fa_tr_frag(const unsigned char* lo, const unsigned char* hi) {
+
+// operand element of the matrix-core attention kernels: bf16 (the model's bf16 mode) or fp16 (BASELINE configs[4]:
+// "fp16 MFMA QK^T / AV" -- 11 significand bits in P, K and V instead of 8)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+struct AttnBf16 {
+    typedef bf16 T;
+    typedef bf16x8 V8;
+    static __device__ __forceinline__ unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
+    static __device__ __forceinline__ unsigned packp(float a, float b) { return pack_bf16x2(a, b); }
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+struct AttnF16 {
+    typedef f16 T;
+    typedef f16x8 V8;
+    static __device__ __forceinline__ unsigned pack2(float a, float b) { return pack_f16x2(a, b); }
+    // probabilities (in [0, 1], consumed at once by the next MFMA): one v_cvt_pkrtz_f16_f32 -- the kernel is bound by
+    // its vector-ALU work, round-to-nearest costs three instructions per pair
+    static __device__ __forceinline__ unsigned packp(float a, float b) {
+        const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);
+        return *reinterpret_cast<const unsigned*>(&h);
+    }
+    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+
+template <typename V8>
+__device__ __forceinline__ V8 fa_tr_frag(const unsigned char* lo, const unsigned char* hi) {
     s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lo));
     s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(hi));
     s16x8 r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, r);
+    return __builtin_bit_cast(V8, r);
 }
-
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) { return pack_bf16x2(a, b); }  // one v_cvt_pk_bf16_f32
 
 // (256, 2): two workgroups per CU = two waves per SIMD, i.e. up to 256 architectural VGPRs per lane --
 // without the bound the allocator parks the accumulators in AGPRs and pays ~60 v_accvgpr moves per tile
+template <typename E>
 __global__ void __launch_bounds__(256, 2)
-attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse, int N, int H) {
+attn_fwd_mfma_kernel(const typename E::T* __restrict__ qkv, typename E::T* __restrict__ out, float* __restrict__ lse, int N, int H) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FA_KT * 64];
     unsigned char* sK = smem;                // [64 keys][32 d] bf16, swizzled 16-B chunks
     unsigned char* sV = smem + FA_KT * 64;   // [64 keys][32 d] bf16, plain rows (transposed reads)
@@ -60,23 +84,23 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float
     const int r = lane & 31, hh = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int ld = 3 * H * FA_D;
-    const bf16* base = qkv + (int64_t)b * N * ld;
+    const typename E::T* base = qkv + (int64_t)b * N * ld;
     const int q0 = blockIdx.x * FA_QB + wave * FA_QW;
 
     // ---- Q fragments (B operand: col = query r, k = d), pre-scaled by log2(e)/sqrt(D)
     const float qscale = 1.4426950408889634f * rsqrtf((float)FA_D);
-    bf16x8 qf[2][2];  // [q tile][k step]
+    typename E::V8 qf[2][2];  // [q tile][k step]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = min(q0 + qt * 32 + r, N - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            Vec8<bf16> v;
+            Vec8<typename E::T> v;
             v.load(base + (int64_t)q * ld + h * FA_D + ks * 16 + hh * 8);
             unsigned w[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = pack_bf16(v.v[2 * e] * qscale, v.v[2 * e + 1] * qscale);
-            qf[qt][ks] = __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+            for (int e = 0; e < 4; ++e) w[e] = E::pack2(v.v[2 * e] * qscale, v.v[2 * e + 1] * qscale);
+            qf[qt][ks] = __builtin_bit_cast(typename E::V8, make_uint4(w[0], w[1], w[2], w[3]));
         }
     }
 
@@ -94,7 +118,7 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float
     uint4 kreg, vreg;
     auto load_tile = [&](int k0) {
         const int key = min(k0 + st_key, N - 1);
-        const bf16* kp = base + (int64_t)key * ld + H * FA_D + h * FA_D + st_c * 8;
+        const typename E::T* kp = base + (int64_t)key * ld + H * FA_D + h * FA_D + st_c * 8;
         kreg = *reinterpret_cast<const uint4*>(kp);
         vreg = *reinterpret_cast<const uint4*>(kp + H * FA_D);
     };
@@ -113,24 +137,24 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float
         auto key_block = [&](int kb, auto tail_c) {
             constexpr bool TAIL = decltype(tail_c)::value;
             // K fragments (A operand: row = key r, k = d)
-            bf16x8 kf[2];
+            typename E::V8 kf[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                kf[ks] = *reinterpret_cast<const bf16x8*>(sK + fa_sw64(kb * 32 + r, 2 * ks + hh));
+                kf[ks] = *reinterpret_cast<const typename E::V8*>(sK + fa_sw64(kb * 32 + r, 2 * ks + hh));
             // V^T fragments for the two key sub-steps s: element j <-> key 16 s + 8 (j >> 2) + 4 hh + (j & 3)
-            bf16x8 vf[2];
+            typename E::V8 vf[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const unsigned char* vp = sV + (kb * 32 + 16 * s + 4 * (g >> 1) + tq) * 64 + v_col;
-                vf[s] = fa_tr_frag(vp, vp + 8 * 64);
+                vf[s] = fa_tr_frag<typename E::V8>(vp, vp + 8 * 64);
             }
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
                 f32x16 st;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) st[i] = 0.f;
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[qt][0], st, 0, 0, 0);
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[qt][1], st, 0, 0, 0);
+                st = E::mfma(kf[0], qf[qt][0], st);
+                st = E::mfma(kf[1], qf[qt][1], st);
                 if (TAIL) {  // keys beyond N: register i <-> key (i & 3) + 8 (i >> 2) + 4 hh
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
@@ -173,10 +197,10 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float
                 // P^T as the B operand of O^T += V^T P^T: registers 8 s .. 8 s + 7 -> k step s
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const bf16x8 pf = __builtin_bit_cast(
-                        bf16x8, make_uint4(pack_bf16(st[8 * s], st[8 * s + 1]), pack_bf16(st[8 * s + 2], st[8 * s + 3]),
-                                           pack_bf16(st[8 * s + 4], st[8 * s + 5]), pack_bf16(st[8 * s + 6], st[8 * s + 7])));
-                    o[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s], pf, o[qt], 0, 0, 0);
+                    const typename E::V8 pf = __builtin_bit_cast(
+                        typename E::V8, make_uint4(E::packp(st[8 * s], st[8 * s + 1]), E::packp(st[8 * s + 2], st[8 * s + 3]),
+                                           E::packp(st[8 * s + 4], st[8 * s + 5]), E::packp(st[8 * s + 6], st[8 * s + 7])));
+                    o[qt] = E::mfma(vf[s], pf, o[qt]);
                 }
             }
         };
@@ -196,11 +220,11 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float
         const int q = q0 + qt * 32 + r;
         if (q < N) {
             const float inv = 1.0f / l[qt];
-            bf16* op = out + ((int64_t)b * N + q) * (H * FA_D) + h * FA_D;
+            typename E::T* op = out + ((int64_t)b * N + q) * (H * FA_D) + h * FA_D;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint2 v = make_uint2(pack_bf16(o[qt][4 * j] * inv, o[qt][4 * j + 1] * inv),
-                                           pack_bf16(o[qt][4 * j + 2] * inv, o[qt][4 * j + 3] * inv));
+                const uint2 v = make_uint2(E::pack2(o[qt][4 * j] * inv, o[qt][4 * j + 1] * inv),
+                                           E::pack2(o[qt][4 * j + 2] * inv, o[qt][4 * j + 3] * inv));
                 *reinterpret_cast<uint2*>(op + 8 * j + 4 * hh) = v;
             }
             if (hh == 0) lse[((int64_t)b * H + h) * N + q] = (m[qt] + log2f(l[qt])) * 0.6931471805599453f;
@@ -210,8 +234,11 @@ attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float
 
 bool attn_mfma_supported(int N, int D) { return D == FA_D && N >= 128; }  // incl. the U-Net bottleneck (N = 144 at 192x64x48)
 
-int attn_fwd_mfma_launch(const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t st) {
+int attn_fwd_mfma_launch(const void* qkv, void* out, float* lse, int B, int N, int H, int dtype, hipStream_t st) {
     dim3 grid(ceil_div(N, FA_QB), B * H);
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, N, H);
+    if (dtype == TDX_F16)
+        hipLaunchKernelGGL(attn_fwd_mfma_kernel<AttnF16>, grid, dim3(256), 0, st, (const f16*)qkv, (f16*)out, lse, N, H);
+    else
+        hipLaunchKernelGGL(attn_fwd_mfma_kernel<AttnBf16>, grid, dim3(256), 0, st, (const bf16*)qkv, (bf16*)out, lse, N, H);
     return tdx_launch_status();
 }

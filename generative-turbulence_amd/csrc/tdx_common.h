@@ -6,6 +6,7 @@
 #include "../../include/tdx.h"
 
 typedef __hip_bfloat16 bf16;
+typedef _Float16 f16;  // fp16 tensors: accepted by the attention entry points only (TDX_F16)
 
 #define TDX_CHECK_ARG(cond) \
     do {                    \
@@ -24,6 +25,8 @@ __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16* p) { return __bfloat162float(*p); }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16* p, float v) { *p = __float2bfloat16(v); }
+__device__ __forceinline__ float ldf(const f16* p) { return (float)*p; }
+__device__ __forceinline__ void stf(f16* p, float v) { *p = (f16)v; }
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
@@ -37,6 +40,15 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     const f32x2_t v = {lo, hi};
     const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    return *reinterpret_cast<const unsigned*>(&h);
+}
+
+// two floats -> packed fp16 pair, round to nearest even (v_cvt_f16_f32 x2 + v_pack_b32_f16)
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+    const f32x2_t v = {lo, hi};
+    const f16x2_t h = __builtin_convertvector(v, f16x2_t);
     return *reinterpret_cast<const unsigned*>(&h);
 }
 
@@ -75,6 +87,24 @@ struct Vec8<bf16> {
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+template <>
+struct Vec8<f16> {
+    float v[8];
+    __device__ __forceinline__ void load(const f16* p) {
+        typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+        const h8 u = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)u[i];
+    }
+    __device__ __forceinline__ void store(f16* p) const {
+        typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+        h8 u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[i] = (_Float16)v[i];
+        *reinterpret_cast<h8*>(p) = u;
     }
 };
 

@@ -17,6 +17,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("TDX_LIB", _HERE / "libtdx_hip.so"))  # TDX_LIB: kernel-development builds
 
 F32, BF16 = 0, 1
+F16 = 3  # TDX_F16: the attention entry points only
 CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_SPLIT = 0, 1, 2, 3
 F32_SPLIT = 2  # TDX_F32_SPLIT: pack code of fp32 weights for CONV_SPLIT
 WS_CLEAN = 0x100  # TDX_WS_CLEAN (include/tdx.h)
@@ -173,6 +174,8 @@ def dtype_code(dt: torch.dtype) -> int:
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if dt == torch.float16:
+        return F16  # accepted by tdx_attn_fwd / tdx_attn_bwd only; every other entry point answers TDX_EDTYPE
     raise TypeError(f"tdx kernels support float32 and bfloat16 activations, got {dt}")
 
 

@@ -50,6 +50,8 @@ extern "C" {
                               split kernel does not cover run as TDX_CONV_AUTO                */
 /* dtype code accepted by tdx_conv3_pack_weight only: fp32 weights packed for TDX_CONV_SPLIT */
 #define TDX_F32_SPLIT 2
+/* fp16 tensors: accepted by tdx_attn_fwd / tdx_attn_bwd only (BASELINE configs[4]: fp16 MFMA QK^T / AV) */
+#define TDX_F16 3
 /* OR-able into `impl` of tdx_conv3_fwd_gn and tdx_conv3_bwd_weight: the caller guarantees that the
  * workspace is all-zero on entry; the call skips its memsets and, as always, leaves the workspace
  * all-zero on exit (the kernels that read the accumulators clear them).  Lets a host keep one

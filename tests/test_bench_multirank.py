@@ -37,3 +37,21 @@ def test_bench_two_ranks_one_gpu():
     # BASELINE configs[3]: trajectories sharded over the ranks, aggregate samples/s
     sm = d["extra"]["sampling"]
     assert sm["trajectories"] == 2 and sm["trajectories_per_gpu"] == 1 and sm["ddpm_samples_per_s_T1000"] > 0
+
+
+def test_bench_bare_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (the command the driver uses for N = 1, with N = 2): bench.py
+    starts torch.distributed.run itself as a child process before it touches the GPU, relays rank 0's JSON line and the
+    exit code; the overlap report carries the HIP-event figures (backward span, exposed all-reduce wait)."""
+    env = dict(os.environ, TDX_BENCH_BACKEND="gloo", TDX_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
+           "--no-cpu-baseline", "--sample-steps", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    ov = d["extra"]["overlap"]
+    assert ov["ms_backward"] > 0 and ov["ms_exposed"] >= 0 and "HIP events" in ov["method"]

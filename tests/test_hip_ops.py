@@ -520,6 +520,52 @@ def test_attention_config5_rows_vs_oracle():
     assert (got - ref).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("N", [144, 333, 1000, 4096])
+def test_attention_fp16_operands(N, monkeypatch):
+    """BASELINE configs[4] names fp16 MFMA QK^T / AV: the matrix-core attention kernels with fp16 tensors and fp16
+    operands (tdx_attn_fwd / tdx_attn_bwd, dtype TDX_F16: 11 significand bits in K, V and P instead of bf16's 8).
+    Forward and all three gradients against the fp64 oracle on the same fp16-rounded inputs at 2e-3 / 5e-3 -- four
+    times tighter than the bf16 kernels' tolerances; the row-wise kernels (short sequences, TDX_ATTN_IMPL=vector) too."""
+    from turbdiff_amd import ops
+
+    B, H, D = 2, 4, 32
+    qkv = rnd(B, N, 3 * H * D, seed=1).half()
+    refq = qkv.double().requires_grad_()
+    q2, k2, v2 = (p.reshape(B, N, H, D).transpose(1, 2) for p in refq.chunk(3, dim=-1))
+    go = rnd(B, N, H * D, seed=2).half()
+    ref = O.sdpa(q2, k2, v2).transpose(1, 2).reshape(B, N, H * D)
+    ref.backward(go.double())
+    for impl in ("mfma", "vector"):
+        if impl == "vector":
+            monkeypatch.setenv("TDX_ATTN_IMPL", "vector")
+        qd = qkv.to(dev()).requires_grad_()
+        out = ops.attention(qd, H)
+        assert out.dtype == torch.float16
+        out.backward(go.to(dev()))
+        assert rel_l2(out.float().cpu(), ref.detach()) < 2e-3, impl
+        for name, a, b in zip("qkv", qd.grad.float().cpu().chunk(3, dim=-1), refq.grad.chunk(3, dim=-1)):
+            assert rel_l2(a, b) < 5e-3, (impl, name)
+    monkeypatch.delenv("TDX_ATTN_IMPL")
+
+
+def test_attention_config5_rows_vs_oracle_fp16():
+    """The config-5 size itself (N = 73 728, 4 heads x 32) with fp16 operands: 256 oracle rows at 2e-3."""
+    from oracle import turbdiff_oracle as O
+    from turbdiff_amd import ops
+
+    B, H, D, N = 1, 4, 32, 96 * 32 * 24
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(11)
+    qkv = torch.randn(B, N, 3 * H * D, device=d, generator=g).half()
+    out = ops.attention(qkv, H).float().cpu()
+    rows = torch.randperm(N, generator=torch.Generator().manual_seed(12))[:256]
+    q, k, v = qkv.float().cpu().reshape(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    ref = O.sdpa(q[:, :, rows], k, v)
+    got = out.reshape(B, N, H, D)[:, rows].permute(0, 2, 1, 3)
+    assert rel_l2(got, ref) < 2e-3
+    assert (got - ref).abs().max().item() < 5e-3
+
+
 @pytest.mark.parametrize("grid", [(18, 10, 10), (10, 18, 9), (9, 10, 18), (14, 18, 18), (6, 9, 10)])
 def test_conv3_thin_slab_bricks(grid, monkeypatch):
     """grids with a 1-2 voxel remainder per axis (the reference's real 194x50x50 family and every
