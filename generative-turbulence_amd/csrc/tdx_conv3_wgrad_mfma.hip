@@ -67,6 +67,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base_lo, const un
     return __builtin_bit_cast(bf16x8, r);
 }
 
+// Diagnostic builds only (tools/micro/wgrad_stamp.hip defines W3_STAMPS): s_memtime stamps of brick iterations 4 .. 11
+// of every wave per phase, kept in spare LDS and dumped to w3_stamps_dev at the end; the product build carries none of it.
+#ifdef W3_STAMPS
+#define W3_NSTAMP 64
+__device__ unsigned long long* w3_stamps_dev;
+#define W3_T()                                                                              \
+    do {                                                                                    \
+        if (it_ >= 4 && it_ < 12) {                                                         \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                     \
+            if (lane == 0 && nst_ < W3_NSTAMP) sStamp_[wave * W3_NSTAMP + nst_] = t_;       \
+            ++nst_;                                                                         \
+        }                                                                                   \
+    } while (0)
+#else
+#define W3_T() do { } while (0)
+#endif
+
 template <int NT>
 __global__ void __launch_bounds__(256, NT == 2 ? 1 : 2)
 conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
@@ -180,13 +197,25 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
         }
     };
 
+#ifdef W3_STAMPS
+    unsigned long long* sStamp_ = reinterpret_cast<unsigned long long*>(smem + W3_XBYTES + NT * W3_GPLANE);
+    int nst_ = 0, it_ = 0;
+#endif
     int brick = split;
     if (brick < nbricks) load_brick(brick);
     for (; brick < nbricks; brick += nsplit) {
+        W3_T();  // iteration top
         __syncthreads();  // previous brick's fragment reads are done
+        W3_T();  // barrier 1 passed (includes the wait for the staged loads)
         store_brick();
+#ifdef W3_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        W3_T();  // LDS stores done
         __syncthreads();
+        W3_T();  // barrier 2 passed
         if (brick + nsplit < nbricks) load_brick(brick + nsplit);  // in flight during the MFMA phase
+        W3_T();  // next brick's loads issued
 
         // K-step s: voxels (x = s >> 2, y = 2 (s & 3) + kh, z = q (+4)).  One wave per SIMD, so the
         // LDS latency has to be hidden inside the wave: while step s issues its 7 x NT MFMAs from
@@ -253,7 +282,18 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                 }
             }
         }
+        W3_T();  // MFMAs of the brick issued
+#ifdef W3_STAMPS
+        ++it_;
+#endif
     }
+#ifdef W3_STAMPS
+    if (lane == 0 && w3_stamps_dev != nullptr) {
+        unsigned long long* rec = w3_stamps_dev + ((size_t)blockIdx.x * 4 + wave) * (W3_NSTAMP + 1);
+        rec[0] = nst_;
+        for (int i = 0; i < W3_NSTAMP; ++i) rec[1 + i] = sStamp_[wave * W3_NSTAMP + i];
+    }
+#endif
 
     // ---- merge: D[row = ci][col = co]; lane holds col (lane & 31), rows (i&3) + 8 (i>>2) + 4 (lane>>5)
     const int r = lane & 31, hh = lane >> 5;
@@ -327,7 +367,10 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
     int nsplit = ((NT == 2 ? 256 : 512) + ntiles - 1) / ntiles;
     if (nsplit > nbricks) nsplit = nbricks;
     if (nsplit < 1) nsplit = 1;
-    const size_t lds = W3_XBYTES + (size_t)NT * W3_GPLANE;
+    size_t lds = W3_XBYTES + (size_t)NT * W3_GPLANE;
+#ifdef W3_STAMPS
+    lds += 4 * W3_NSTAMP * 8;
+#endif
     dim3 grid((unsigned)(ntiles * nsplit));
     // slab mode: every (tile, split) pair stores its whole partial tile, so the slabs need no zeroing
     static const int slab_cap = getenv("TDX_WGRAD_SLABS") ? atoi(getenv("TDX_WGRAD_SLABS")) : 1 << 30;  // A/B switch
