@@ -338,6 +338,11 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
     {   // deep U-Net levels: packed-K kernel (tdx_conv3_wgrad_small.hip); TDX_ESHAPE = not such a case
         int rs = conv3_wgrad_small_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st, slabs, max_slabs, nslab_out);
         if (rs != TDX_ESHAPE) return rs;
+#ifndef W3_STAMPS
+        // fine levels, 64-wide tiles: the producer / consumer form (8 computing + 4 loader waves)
+        rs = conv3_wgrad_ring_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st, slabs, max_slabs, nslab_out);
+        if (rs != TDX_ESHAPE) return rs;
+#endif
     }
     const int Cin = C1 + C2;
     const int NT = (Cout % 64 == 0) ? 2 : 1;

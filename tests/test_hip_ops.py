@@ -1094,6 +1094,55 @@ def test_conv1_weight_gradient_in_parameter_layout(dt, C1, C2, Cout):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [
+    # B, C1, C2, Cout, grid: 64-wide output tiles; whole and ragged bricks (zero rows from the arena's zero block), two
+    # inputs, a half-filled last ci tile (C1 = 16), several co tiles, few and many bricks per workgroup, level-0 size
+    (2, 64, 0, 64, (32, 32, 16)), (1, 32, 32, 64, (48, 32, 24)), (2, 16, 0, 64, (32, 16, 16)), (1, 64, 0, 128, (20, 18, 13)),
+    (3, 32, 0, 64, (9, 17, 10)), (1, 64, 0, 64, (96, 32, 24)), (2, 64, 0, 64, (192, 64, 48)), (6, 128, 0, 256, (48, 16, 12)),
+])
+def test_conv3_weight_gradient_producer_consumer_kernel_vs_brick_kernel(case, monkeypatch):
+    """The producer / consumer weight-gradient kernel (tdx_conv3_wgrad_ring.hip: 8 computing + 4 loader waves) against the
+    brick kernel it replaces for 64-wide output tiles (TDX_WGRAD_RING = 1 / 0): the same per-workgroup partial sums,
+    merged by fp32 atomics or slabs in a different order -> 2e-6; the bias gradient comes from an all-ones MFMA slot
+    instead of the staging registers; the workspace is left zero; and the fp64 sums on the small cases.  Twice: the
+    second call catches stale LDS / late copies."""
+    from turbdiff_amd import _lib as L
+
+    B, C1, C2, Co, (X, Y, Z) = case
+    d = dev()
+    Ci = C1 + C2
+    g = torch.Generator(device=d).manual_seed(13)
+    rn = lambda *s: torch.randn(*s, device=d, generator=g)
+    x1, x2 = rn(B, X, Y, Z, C1).bfloat16(), (rn(B, X, Y, Z, C2).bfloat16() if C2 else None)
+    gy = rn(B, X, Y, Z, Co).bfloat16()
+    st = L.stream()
+    L.ensure_scratch(d)
+    ws = torch.zeros(L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, L.CONV_AUTO), dtype=torch.uint8, device=d)
+
+    def run(ring):
+        monkeypatch.setenv("TDX_WGRAD_RING", str(ring))
+        monkeypatch.setenv("TDX_WGRAD_SMALL_ROWS", "0")
+        dw, db = torch.empty(Co, Ci, 3, 3, 3, device=d), torch.empty(Co, device=d)
+        L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(dw), L.ptr(db), B, X, Y, Z, Co, L.BF16,
+               L.CONV_AUTO | L.WS_CLEAN, L.ptr(ws), st)
+        torch.cuda.synchronize()
+        assert int(ws[: (27 * Ci * Co + Co) * 4].count_nonzero()) == 0
+        return dw, db
+
+    brick = run(0)
+    for rep in range(2):
+        ring = run(1)
+        assert torch.isfinite(ring[0]).all() and torch.isfinite(ring[1]).all()
+        assert rel_l2(ring[0], brick[0]) < 2e-6 and rel_l2(ring[1], brick[1]) < 2e-6, (case, rep)
+    if B * X * Y * Z <= 20000:
+        xr = torch.cat([x1] + ([x2] if C2 else []), dim=-1).double().cpu().permute(0, 4, 1, 2, 3)
+        w = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        bz = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+        O.conv3_replicate(xr, w, bz).backward(gy.double().cpu().permute(0, 4, 1, 2, 3))
+        assert rel_l2(ring[0].cpu(), w.grad) < 1e-5 and rel_l2(ring[1].cpu(), bz.grad) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
     # B, C1, C2, Cout, grid -- the deep levels of the shipped model and ragged / tiny relatives
     (6, 512, 0, 512, (12, 4, 3)), (6, 256, 0, 512, (24, 8, 6)), (6, 512, 512, 256, (24, 8, 6)), (6, 256, 0, 256, (24, 8, 6)),
     (2, 128, 0, 32, (5, 3, 1)), (3, 256, 0, 96, (7, 9, 4)), (8, 512, 0, 512, (12, 4, 3)), (1, 160, 0, 64, (13, 7, 6)),
