@@ -18,295 +18,25 @@
 // tdx_conv3_pack_weight_split ([2][K/16][27][N][16] bf16).  157 KB of LDS for NT = 2: one workgroup per CU,
 // one wave per SIMD, so the fragments of tap t+1 are read into a second register set while tap t issues
 // its 6 NT MFMAs, and the next slice's global loads are in flight during the whole MFMA phase.
-#include "tdx_common.h"
-#include "tdx_conv3.h"
-#include "tdx_conv3_brick.h"
-#include <stdlib.h>
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-#define SP_KC 16
+#include "tdx_conv3_mfma_split_kernel.h"
 
 bool conv3_mfma_split_supported(int C1, int C2, int Cout) {
     return C1 > 0 && (C1 % SP_KC) == 0 && (C2 % SP_KC) == 0 && (Cout % 32) == 0;
 }
 
-template <int BN>
-__device__ __forceinline__ int outs_addr(int v, int c) {
-    return v * (BN * 4) + ((c ^ (v & (BN / 4 - 1))) << 4);
-}
-
-// 8 fp32 -> 8 bf16 hi and 8 bf16 lo
-__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-        const float r0 = v[2 * i] - __uint_as_float(h[i] << 16), r1 = v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u);
-        l[i] = pack_bf16x2(r0, r1);
-    }
-    hi = make_uint4(h[0], h[1], h[2], h[3]);
-    lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-
-template <int NT, bool ZERO_PAD, int SHAPE, bool PERM>
-__global__ void __launch_bounds__(256, 1)
-conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
-                        const bf16* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, BrickRegions R,
-                        int Cout, int64_t lo_offset, double* __restrict__ gn_acc, float* __restrict__ d1, int D1,
-                        float* __restrict__ d2, const float* __restrict__ a1, const float* __restrict__ a2) {
-    using BR = Brick<SHAPE>;
-    constexpr int MT = BR::MT;
-    constexpr int BN = NT * 32;
-    constexpr int HY = BR::HY, HZ = BR::HZ, SZ = BR::SZ;
-    constexpr int NHALO = BR::NHALO;
-    constexpr int APLANE = BR::ENTRIES * 16 + 64;   // one half-plane of one part
-    constexpr int A_BYTES = 4 * APLANE;             // [part][half]
-    constexpr int B_PLANE = 27 * BN * 16 + 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* sA = smem;
-    unsigned char* sB = smem + A_BYTES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-
-    int b, o[3];
-    const BrickView g = brick_decode<SHAPE>(R, xcd_contiguous((int)blockIdx.x, (int)gridDim.x), b, o);
-    const int n0 = blockIdx.y * BN;
-    const int Cin = C1 + C2;
-
-    // ---- staging plan of the halo brick: pieces (voxel, half) of 8 fp32 channels
-    constexpr int A_PIECES = NHALO * 2;
-    constexpr int A_PER_THREAD = (A_PIECES + 255) / 256;
-    int a_src[A_PER_THREAD], a_dst[A_PER_THREAD];
-#pragma unroll
-    for (int i = 0; i < A_PER_THREAD; ++i) {
-        const int p = tid + i * 256;
-        a_dst[i] = -1;
-        a_src[i] = -1;
-        if (p < A_PIECES) {
-            const int hv = p >> 1, half = p & 1;
-            const int hx = hv / (HY * HZ), rem = hv - hx * (HY * HZ);
-            const int hy = rem / HZ, hz = rem - hy * HZ;
-            a_dst[i] = half * APLANE + ((hx * HY + hy) * SZ + hz) * 16;
-            const int src = brick_halo_source<ZERO_PAD, PERM>(g, o, hx, hy, hz);
-            if (src >= 0) a_src[i] = src * 2 + half;
-        }
-    }
-    const int64_t batch_vox = (int64_t)b * g.Ei[0] * g.Ei[1] * g.Ei[2];
-
-    // ---- weight staging: pieces (part, row = tap * BN + n, half) of 16 B; packed [part][K/16][27][Cout][16]
-    constexpr int B_ROWS = 27 * BN;
-    constexpr int B_PIECES = B_ROWS * 4;
-    constexpr int B_PER_THREAD = (B_PIECES + 255) / 256;
-
-    float4 areg[A_PER_THREAD][2];
-    uint4 breg[B_PER_THREAD];
-    auto load_slice = [&](int c) {
-        const int k0 = c * SP_KC;
-        const float* xs;
-        int Cs, kk;
-        if (k0 < C1) { xs = x1; Cs = C1; kk = k0; } else { xs = x2; Cs = C2; kk = k0 - C1; }
-        xs += batch_vox * Cs + kk;
-#pragma unroll
-        for (int i = 0; i < A_PER_THREAD; ++i) {
-            areg[i][0] = areg[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_src[i] >= 0) {
-                const float4* src = reinterpret_cast<const float4*>(xs + (int64_t)(a_src[i] >> 1) * Cs + (a_src[i] & 1) * 8);
-                areg[i][0] = src[0];
-                areg[i][1] = src[1];
-            }
-        }
-        const bf16* wc = wp + (int64_t)c * 27 * Cout * SP_KC;
-#pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) {
-            const int p = tid + i * 256;
-            breg[i] = make_uint4(0, 0, 0, 0);
-            if (p < B_PIECES) {
-                const int half = p & 1, row = (p >> 1) % B_ROWS, part = (p >> 1) / B_ROWS;
-                const int tap = row / BN, n = row - tap * BN;
-                breg[i] = *reinterpret_cast<const uint4*>(wc + part * lo_offset + ((int64_t)tap * Cout + n0 + n) * SP_KC + half * 8);
-            }
-        }
-    };
-    auto store_slice = [&]() {
-#pragma unroll
-        for (int i = 0; i < A_PER_THREAD; ++i)
-            if (a_dst[i] >= 0) {
-                uint4 hi, lo;
-                split8(areg[i][0], areg[i][1], hi, lo);
-                *reinterpret_cast<uint4*>(sA + a_dst[i]) = hi;
-                *reinterpret_cast<uint4*>(sA + 2 * APLANE + a_dst[i]) = lo;
-            }
-#pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) {
-            const int p = tid + i * 256;
-            if (p < B_PIECES) {
-                const int half = p & 1, row = (p >> 1) % B_ROWS, part = (p >> 1) / B_ROWS;
-                *reinterpret_cast<uint4*>(sB + (part * 2 + half) * B_PLANE + row * 16) = breg[i];
-            }
-        }
-    };
-
-    // this lane's voxel of M tile mt (Brick<THIN>::lane_voxel)
-    int a_h[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int lx, ly, lz;
-        BR::lane_voxel(wave, mt, r, lx, ly, lz);
-        a_h[mt] = hh * APLANE + (((lx + 1) * HY + (ly + 1)) * SZ + (lz + 1)) * 16;
-    }
-    int tap_row[27];  // weight-image row of every local tap (uniform; immediates when the axes are not permuted)
-#pragma unroll
-    for (int t = 0; t < 27; ++t) tap_row[t] = (PERM ? brick_tap(g, t / 9 - 1, (t / 3) % 3 - 1, t % 3 - 1) : t) * (BN * 16);
-    const int b_off = hh * B_PLANE + r * 16;
-
-    f32x16 acc[NT][MT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
-
-    struct Frags { bf16x8 xh[MT], xl[MT], wh[NT], wl[NT]; };
-    auto read_frags = [&](int tap, Frags& f) {
-        const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
-        const int toff = ((ex * HY + ey) * SZ + ez) * 16;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            f.xh[mt] = *reinterpret_cast<const bf16x8*>(sA + a_h[mt] + toff);
-            f.xl[mt] = *reinterpret_cast<const bf16x8*>(sA + 2 * APLANE + a_h[mt] + toff);
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            f.wh[nt] = *reinterpret_cast<const bf16x8*>(sB + b_off + tap_row[tap] + nt * 512);
-            f.wl[nt] = *reinterpret_cast<const bf16x8*>(sB + 2 * B_PLANE + b_off + tap_row[tap] + nt * 512);
-        }
-    };
-    // term-major order: with one wave per SIMD nothing hides the ~12-cycle stall of an MFMA that accumulates
-    // onto the result of the MFMA right before it (tools/micro/mfma_peak: 1785 vs 2437 TFLOP/s), so consecutive
-    // MFMAs go to different accumulators (2 NT apart)
-    auto mfmas = [&](const Frags& f) {
-#pragma unroll
-        for (int term = 0; term < 3; ++term)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 2 ? f.wl[nt] : f.wh[nt],
-                                                                         term == 1 ? f.xl[mt] : f.xh[mt], acc[nt][mt], 0, 0, 0);
-    };
-
-    const int nchunks = Cin / SP_KC;
-    load_slice(0);
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();
-        store_slice();
-        __syncthreads();
-        if (c + 1 < nchunks) load_slice(c + 1);
-        Frags f0, f1;
-        read_frags(0, f0);
-#pragma unroll
-        for (int tap = 0; tap < 27; tap += 2) {
-            if (tap + 1 < 27) read_frags(tap + 1, f1);
-            mfmas(f0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 2 * NT, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NT, 0);
-            if (tap + 1 < 27) {
-                if (tap + 2 < 27) read_frags(tap + 2, f0);
-                mfmas(f1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 2 * NT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NT, 0);
-            }
-        }
-    }
-
-    // ---- epilogue: as the fp32 kernel (lane (r, hh): voxel (wave, 4 mt + (r & 3), r >> 2), channels nt*32 + 8 j + 4 hh + 0..3)
-    __syncthreads();
-    unsigned char* sO = smem;  // [NVOX voxels][BN] fp32
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ch = nt * 32 + 8 * j + 4 * hh;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bias) bv = *reinterpret_cast<const float4*>(bias + n0 + ch);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                int lx, ly, lz;
-                BR::lane_voxel(wave, mt, r, lx, ly, lz);
-                const int v = BR::tile_index(lx, ly, lz);
-                *reinterpret_cast<float4*>(sO + outs_addr<BN>(v, ch >> 2)) =
-                    make_float4(acc[nt][mt][4 * j] + bv.x, acc[nt][mt][4 * j + 1] + bv.y, acc[nt][mt][4 * j + 2] + bv.z,
-                                acc[nt][mt][4 * j + 3] + bv.w);
-            }
-        }
-    __syncthreads();
-    constexpr int CHUNKS = BN / 4;
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};  // GroupNorm moments of this thread's 4 channels
-#pragma unroll
-    for (int i = 0; i < CHUNKS * (BR::NVOX / 256); ++i) {
-        const int p = tid + i * 256;
-        const int v = p / CHUNKS, cidx = p % CHUNKS;
-        int lx, ly, lz, c[3];
-        BR::tile_voxel(v, lx, ly, lz);
-        if (brick_out_coords<PERM>(g, o, lx, ly, lz, c)) {
-            const int c0 = c[0], c1 = c[1], c2 = c[2];
-            const int64_t ov = (((int64_t)b * g.Eo[0] + c0) * g.Eo[1] + c1) * g.Eo[2] + c2;
-            float4 val = *reinterpret_cast<const float4*>(sO + outs_addr<BN>(v, cidx));
-            bool direct = false;
-            if (ZERO_PAD && d1 != nullptr) {
-                // data gradient: padded position = original voxel + 1.  Positions inside the original grid go
-                // straight to dx (split over the two inputs of a concatenated conv, plus the optional addend);
-                // only the halo shell is written to the padded workspace for the face fix-up
-                const int u0 = c0 + g.off, u1 = c1 + g.off, u2 = c2 + g.off;
-                if (u0 >= 0 && u0 < g.Ei[0] && u1 >= 0 && u1 < g.Ei[1] && u2 >= 0 && u2 < g.Ei[2]) {
-                    const int64_t u = (((int64_t)b * g.Ei[0] + u0) * g.Ei[1] + u1) * g.Ei[2] + u2;
-                    const int n = n0 + cidx * 4;
-                    const bool lo = n < D1;
-                    float* dst = lo ? d1 + u * D1 + n : d2 + u * (Cout - D1) + (n - D1);
-                    const float* asrc = lo ? (a1 ? a1 + u * D1 + n : nullptr) : (a2 ? a2 + u * (Cout - D1) + (n - D1) : nullptr);
-                    if (asrc) {
-                        const float4 av = *reinterpret_cast<const float4*>(asrc);
-                        val.x += av.x; val.y += av.y; val.z += av.z; val.w += av.w;
-                    }
-                    *reinterpret_cast<float4*>(dst) = val;
-                    direct = true;
-                }
-            }
-            if (!direct) *reinterpret_cast<float4*>(y + ov * Cout + n0 + cidx * 4) = val;
-            if (gn_acc != nullptr) {
-                s1[0] += val.x; s2[0] += val.x * val.x; s1[1] += val.y; s2[1] += val.y * val.y;
-                s1[2] += val.z; s2[2] += val.z * val.z; s1[3] += val.w; s2[3] += val.w * val.w;
-            }
-        }
-    }
-    if (gn_acc != nullptr) {
-        // per-channel moments of the tile (tdx_conv3_fwd_gn): threads with equal tid % CHUNKS hold the same 4
-        // channels; LDS reduce behind the output tile, then one f64 atomic per channel and moment into one of
-        // TDX_GN_REPLICAS tables (as the bf16 kernel)
-        constexpr int NP = 256 / CHUNKS;
-        float* red = reinterpret_cast<float*>(smem + BR::NVOX * BN * 4);  // [NP][BN][2]
-        const int cidx = tid % CHUNKS, part = tid / CHUNKS;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            red[(part * BN + cidx * 4 + e) * 2] = s1[e];
-            red[(part * BN + cidx * 4 + e) * 2 + 1] = s2[e];
-        }
-        __syncthreads();
-        if (tid < BN * 2) {
-            float t = 0.f;
-#pragma unroll 8
-            for (int pp = 0; pp < NP; ++pp) t += red[pp * BN * 2 + tid];
-            const int rep = blockIdx.x & (TDX_GN_REPLICAS - 1);
-            atomicAdd(&gn_acc[(((size_t)rep * g.B + b) * Cout + n0) * 2 + tid], (double)t);
-        }
-    }
-}
+int conv3_mfma_split_go_2zmp(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_2zmn(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_2rmp(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_2rmn(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_1zbp(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_1zbn(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_1rbp(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_1rbn(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_1zmp(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_1zmn(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_1rmp(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_1rmn(SPLIT_GO_ARGS);
+int conv3_mfma_split_go_1ztp(SPLIT_GO_ARGS);
 
 int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                             const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
@@ -320,40 +50,28 @@ int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, cons
     BrickRegions main, thin;
     brick_plan(g, zero_pad, !no_thin, main, thin, big ? BRICK_BIG : BRICK_MAIN);
     const int64_t lo_offset = (int64_t)27 * (C1 + C2) * Cout;  // elements between the hi and the lo weight image
-#define SP_GO(NTV, ZP, TH, PM, REG)                                                                                     \
-    do {                                                                                                                \
-        constexpr int BNV = NTV * 32;                                                                                   \
-        const size_t lds = (size_t)4 * (Brick<TH>::ENTRIES * 16 + 64) + (size_t)4 * (27 * BNV * 16 + 64);               \
-        auto kern = conv3_mfma_split_kernel<NTV, ZP, TH, PM>;                                                           \
-        static bool attr_set = false;                                                                                   \
-        if (!attr_set) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            if (e != hipSuccess) return (int)e;                                                                         \
-            attr_set = true;                                                                                            \
-        }                                                                                                               \
-        dim3 grid((unsigned)(REG).start[(REG).n], Cout / BNV);                                                          \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const float*)x1, C1, (const float*)x2, C2, (const bf16*)wp, \
-                           bias, (float*)y, REG, Cout, lo_offset, gn_acc, (float*)d1, D1, (float*)d2, (const float*)a1,  \
-                           (const float*)a2);                                                                           \
-    } while (0)
     const bool perm = main.v[0].perm[0] != 0;  // forward on ragged grids: the short brick edge on another axis
-    if (NT == 2) {
-        if (zero_pad && perm) SP_GO(2, true, BRICK_MAIN, true, main);
-        else if (zero_pad) SP_GO(2, true, BRICK_MAIN, false, main);
-        else if (perm) SP_GO(2, false, BRICK_MAIN, true, main);
-        else SP_GO(2, false, BRICK_MAIN, false, main);
-    } else if (big) {
-        if (zero_pad && perm) SP_GO(1, true, BRICK_BIG, true, main);
-        else if (zero_pad) SP_GO(1, true, BRICK_BIG, false, main);
-        else if (perm) SP_GO(1, false, BRICK_BIG, true, main);
-        else SP_GO(1, false, BRICK_BIG, false, main);
-    } else {
-        if (zero_pad && perm) SP_GO(1, true, BRICK_MAIN, true, main);
-        else if (zero_pad) SP_GO(1, true, BRICK_MAIN, false, main);
-        else if (perm) SP_GO(1, false, BRICK_MAIN, true, main);
-        else SP_GO(1, false, BRICK_MAIN, false, main);
-    }
-    if (thin.n > 0) SP_GO(1, true, BRICK_THIN, true, thin);  // remainder slabs of the padded grid: 2 x 16 x 8 bricks, 32-wide tiles
-#undef SP_GO
-    return tdx_launch_status();
+    auto go_main = [&]() -> int {
+        if (NT == 2) {
+            if (zero_pad && perm) { return conv3_mfma_split_go_2zmp(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st); }
+            if (zero_pad) { return conv3_mfma_split_go_2zmn(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st); }
+            if (perm) { return conv3_mfma_split_go_2rmp(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st); }
+            return conv3_mfma_split_go_2rmn(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st);
+        }
+        if (big) {
+            if (zero_pad && perm) { return conv3_mfma_split_go_1zbp(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st); }
+            if (zero_pad) { return conv3_mfma_split_go_1zbn(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st); }
+            if (perm) { return conv3_mfma_split_go_1rbp(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st); }
+            return conv3_mfma_split_go_1rbn(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st);
+        }
+        if (zero_pad && perm) { return conv3_mfma_split_go_1zmp(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st); }
+        if (zero_pad) { return conv3_mfma_split_go_1zmn(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st); }
+        if (perm) { return conv3_mfma_split_go_1rmp(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st); }
+        return conv3_mfma_split_go_1rmn(x1, C1, x2, C2, wp, bias, y, main, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st);
+    };
+    int rc = go_main();
+    if (rc != TDX_OK) return rc;
+    // remainder slabs of the padded grid: 2 x 16 x 8 bricks, 32-wide tiles
+    if (thin.n > 0) { return conv3_mfma_split_go_1ztp(x1, C1, x2, C2, wp, bias, y, thin, Cout, lo_offset, gn_acc, d1, D1, d2, a1, a2, st); }
+    return TDX_OK;
 }

@@ -1,0 +1,3 @@
+// One instantiation of the split-precision MFMA conv kernel (tdx_conv3_mfma_split_kernel.h): NT = 1, replicate padding, brick bigs, natural axes.
+#include "tdx_conv3_mfma_split_kernel.h"
+SPLIT_INSTANCE(1, false, BRICK_BIG, false, conv3_mfma_split_go_1rbn)

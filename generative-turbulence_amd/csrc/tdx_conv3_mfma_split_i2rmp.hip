@@ -1,0 +1,3 @@
+// One instantiation of the split-precision MFMA conv kernel (tdx_conv3_mfma_split_kernel.h): NT = 2, replicate padding, brick mains, permuted axes.
+#include "tdx_conv3_mfma_split_kernel.h"
+SPLIT_INSTANCE(2, false, BRICK_MAIN, true, conv3_mfma_split_go_2rmp)

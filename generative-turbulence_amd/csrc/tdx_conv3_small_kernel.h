@@ -172,8 +172,13 @@ conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict_
         // fragments of tap t + 1 are read while the MFMAs of tap t issue (two register sets, pinned with
         // sched_group_barrier): one wave per SIMD has nothing else to hide an LDS round trip behind
         struct Frags { bf16x8 w, wl, x[MTW]; float4 xa[SPLIT ? MTW : 1], xb[SPLIT ? MTW : 1]; };
-        auto read_tap = [&](int tap, Frags& f) {
-            const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
+        // The 27 taps run as CHUNKS groups of TPC: one fully unrolled group for the bf16 kernels; three x planes of 9 taps
+        // (rolled outer loop) for the split-precision ones, whose 27 x MTW x 3 MFMAs in one basic block cost the
+        // instruction scheduler 2-6 minutes of compile time per instantiation (97 % of the build of this file).
+        constexpr int CHUNKS = SPLIT ? 3 : 1, TPC = 27 / CHUNKS;
+        auto read_tap = [&](int ch, int k, Frags& f) {
+            const int ex = CHUNKS == 3 ? ch - 1 : k / 9 - 1, kk = k % 9, ey = kk / 3 - 1, ez = kk % 3 - 1;
+            const int tap = CHUNKS == 3 ? ch * 9 + k : k;
             const int toff = ((ex * g.Iy + ey) * g.Iz + ez) * 16;
             f.w = *reinterpret_cast<const bf16x8*>(W + tap * (SM_BN * 16));
             if (SPLIT) f.wl = *reinterpret_cast<const bf16x8*>(W + 2 * (W_HALF + 512) + tap * (SM_BN * 16));
@@ -203,28 +208,31 @@ conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict_
         };
         constexpr int NRD = SPLIT ? 2 * MTW + 2 : MTW + 1;  // ds_read_b128 per tap
         constexpr int NMF = SPLIT ? 3 * MTW : MTW;          // MFMAs per tap
-        Frags f0, f1;
-        read_tap(0, f0);
-        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+#pragma unroll 1
+        for (int ch = 0; ch < CHUNKS; ++ch) {
+            Frags f0, f1;
+            read_tap(ch, 0, f0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
 #pragma unroll
-        for (int tap = 0; tap < 27; tap += 2) {
-            if (tap + 1 < 27) read_tap(tap + 1, f1);
-            mfma_tap(f0);
-            if (tap + 1 < 27) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
-                if (tap + 2 < 27) read_tap(tap + 2, f0);
-                mfma_tap(f1);
-                if (tap + 2 < 27) {
+            for (int k = 0; k < TPC; k += 2) {
+                if (k + 1 < TPC) read_tap(ch, k + 1, f1);
+                mfma_tap(f0);
+                if (k + 1 < TPC) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+                    if (k + 2 < TPC) read_tap(ch, k + 2, f0);
+                    mfma_tap(f1);
+                    if (k + 2 < TPC) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 1, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+                    }
                 } else {
                     __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
                 }
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
             }
         }
         if (SPLIT) {  // single-buffered: the next slice is copied only after every wave is done with this one
