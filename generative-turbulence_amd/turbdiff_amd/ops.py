@@ -762,6 +762,37 @@ def film_projections(c: torch.Tensor, linears) -> list:
 # --------------------------------------------------------------------------- fused ResnetBlock
 
 
+_SIDE = {}  # device index -> side stream of the weight gradients (TDX_WGRAD_STREAM=1)
+
+
+class _WgradSide:
+    """TDX_WGRAD_STREAM=1 (experiment): the 3x3x3 weight gradients of a block run on a side stream next to the rest of
+    its backward -- they feed nothing before the optimiser, are bound by the matrix cores, and what runs beside them
+    (GroupNorm backward, 1x1 convs) is bound by memory.  The block joins the streams before it returns, and holds the
+    tensors the side stream reads until then (the caching allocator knows nothing of the side stream's reads)."""
+
+    def __init__(self, device):
+        self.on = os.environ.get("TDX_WGRAD_STREAM", "0") == "1"
+        if self.on:
+            idx = device.index
+            if idx not in _SIDE:
+                _SIDE[idx] = torch.cuda.Stream(device=device)
+            self.side, self.main, self.keep = _SIDE[idx], torch.cuda.current_stream(device), []
+
+    def run(self, fn, *tensors):
+        if not self.on:
+            return fn()
+        self.keep.extend(t for t in tensors if t is not None)
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+            self.keep.clear()
+
+
 class _ResnetBlock(torch.autograd.Function):
     """ResnetBlock (reference ddpm.py:180-197) as ONE autograd node:
 
@@ -873,8 +904,9 @@ class _ResnetBlock(torch.autograd.Function):
         # one workspace per (Cin, Cout): the accumulator / slab layout inside depends on both
         wws2 = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cout, Cout, impl), dev, ("w3", Cout, Cout))
         wws1 = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cc, Cout, impl), dev, ("w3", Cc, Cout))
-        L.call("tdx_conv3_bwd_weight", L.ptr(a1), Cout, None, 0, L.ptr(dh2), L.ptr(dw2), L.ptr(db2), B, X, Y, Z, Cout, code,
-               impl | WS_CLEAN, L.ptr(wws2), st, work=flops(Cout))
+        side = _WgradSide(dev)
+        side.run(lambda: L.call("tdx_conv3_bwd_weight", L.ptr(a1), Cout, None, 0, L.ptr(dh2), L.ptr(dw2), L.ptr(db2), B, X, Y, Z,
+                                Cout, code, impl | WS_CLEAN, L.ptr(wws2), L.stream(), work=flops(Cout)), a1, dh2, dw2, db2)
         da1 = torch.empty_like(a1)
         dws = _ws(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, max(Cin, Cout, Cc), code, impl), dev)
         L.call("tdx_conv3_bwd_data", L.ptr(dh2), L.ptr(wb2), L.ptr(da1), Cout, None, 0, 0, B, X, Y, Z, Cout, code, impl,
@@ -891,16 +923,18 @@ class _ResnetBlock(torch.autograd.Function):
             # block1's conv has its own input: weight gradient w.r.t. that input; the block input x1 only
             # feeds the identity skip, so its gradient is gy; the data gradient of the conv is needed only
             # if xc itself requires one (e.g. a learned cell-type embedding behind the raw conditioning)
-            L.call("tdx_conv3_bwd_weight", L.ptr(xc), Cc, None, 0, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
-                   impl | WS_CLEAN, L.ptr(wws1), st, work=flops(ctx.xc_real or Cc))
+            side.run(lambda: L.call("tdx_conv3_bwd_weight", L.ptr(xc), Cc, None, 0, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z,
+                                    Cout, code, impl | WS_CLEAN, L.ptr(wws1), L.stream(), work=flops(ctx.xc_real or Cc)),
+                     xc, dh1, dw1, db1)
             dxc = None
             if ctx.needs_input_grad[16]:
                 dxc = torch.empty_like(xc)
                 L.call("tdx_conv3_bwd_data", L.ptr(dh1), L.ptr(wb1), L.ptr(dxc), Cc, None, 0, 0, B, X, Y, Z, Cout, code, impl,
                        L.ptr(dws), st, work=flops(ctx.xc_real or Cc))
+            side.join()
             return (gy, None, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, dxc, None)
-        L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z, Cout, code,
-               impl | WS_CLEAN, L.ptr(wws1), st, work=flops(Cin))
+        side.run(lambda: L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z,
+                                Cout, code, impl | WS_CLEAN, L.ptr(wws1), L.stream(), work=flops(Cin)), x1, x2, dh1, dw1, db1)
         # ---- input gradient = conv1 data gradient + residual-path gradient
         gx1 = torch.empty_like(x1)
         gx2 = None if x2 is None else torch.empty_like(x2)
@@ -920,6 +954,7 @@ class _ResnetBlock(torch.autograd.Function):
                        B * V, C2, code, st)
             dwr, dbr = _conv1_weight_grad(x1, C1, x2, C2, gy, Cout, hbr, B * V, code, st)
             dwr = dwr.view(wrs)
+        side.join()
         return (gx1, gx2, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None, None)
 
 
