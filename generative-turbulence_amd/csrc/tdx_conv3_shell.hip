@@ -35,6 +35,22 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define SH_F32 1
 #define SH_SPLIT 2
 
+// Diagnostic builds only (tools/micro/shell_stamp.hip defines SH_STAMPS): s_memtime stamps of every wave's phases, written
+// straight to sh_stamps_dev; the product build carries none of it.
+#ifdef SH_STAMPS
+#define SH_NSTAMP 16
+__device__ unsigned long long* sh_stamps_dev;
+#define SH_T()                                                                                                   \
+    do {                                                                                                         \
+        if ((threadIdx.x & 63) == 0 && sh_stamps_dev != nullptr && nst_ < SH_NSTAMP)                             \
+            sh_stamps_dev[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)) * SH_NSTAMP + nst_] = \
+                __builtin_amdgcn_s_memtime();                                                                    \
+        ++nst_;                                                                                                  \
+    } while (0)
+#else
+#define SH_T() do {} while (0)
+#endif
+
 #define SH_P 16                 // patch edge
 #define SH_H (SH_P + 2)         // halo'd patch edge
 #define SH_SZ 24                // row stride of the LDS patch: == 8 mod 16, so the 16 lanes of a ds_read_b128 group
@@ -87,6 +103,10 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
+#ifdef SH_STAMPS
+    int nst_ = 0;
+#endif
+    SH_T();  // 0: start
 
     // block -> region, sample, face, patch.  The view is selected by value (uniform selects).
     int bid = blockIdx.x;
@@ -206,11 +226,13 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
 
     struct Frags { uint4 x[PARTS][2], w[PARTS][NT]; };
     const int nchunks = K / (KC * S);
+    SH_T();  // 1: plans done
     load_slice(0);
     for (int c = 0; c < nchunks; ++c) {
         __syncthreads();
         store_slice();
         __syncthreads();
+        if (c < 2) SH_T();  // 2, 4: slice c in LDS
         if (c + 1 < nchunks) load_slice(c + 1);
         // Fragment ring, prefetch distance RING - 1: the LDS reads of tap-step ts + 2 are issued before the MFMAs of step ts
         // (2-12 MFMAs per step do not cover an LDS round trip; with one or two waves per SIMD nothing else does).
@@ -266,7 +288,9 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
             if (ts + D < NS) __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);  // DS reads of step ts + D first,
             __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);                    // then the MFMAs of step ts
         }
+        if (c < 2) SH_T();  // 3, 5: MFMAs of slice c issued
     }
+    SH_T();  // K loop done
 
     // ---- fold.  Lane (r, hh) holds, for M tile mt, its position and channels nt*32 + 8 j + 4 hh + (0..3) in
     // accumulator registers 4 j .. 4 j + 3: transposed through an fp32 LDS tile [256 positions][BN] so that a thread
@@ -288,6 +312,7 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
             }
         }
     __syncthreads();
+    SH_T();  // transposed tile in LDS
     constexpr int CH = MODE == SH_BF16 ? 8 : 4;  // channels per 16-B piece of dx
     constexpr int CHUNKS = BN / CH;
 #pragma unroll 4
@@ -338,6 +363,10 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
             }
         }
     }
+#ifdef SH_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SH_T();  // fold done
 }
 
 template <int MODE, int NT, int S>
