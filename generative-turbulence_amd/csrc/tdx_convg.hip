@@ -2,11 +2,11 @@
 //   dilated 3x3x3, replicate padding          DilatedCNNBlock, dilresnet.py:22-38   (dilation 1, 2, 4, 8)
 //   strided k x k x k, zero padding           tfnet.py:185-199  conv()    (stride 2)
 //   transposed 4x4x4, stride 2, padding 1     tfnet.py:201-208  deconv()
-// on NDHWC tensors (fp32 or bf16 storage, fp32 accumulation).  These layers are off the benchmark path: the
-// kernels are vector-ALU kernels with the arithmetic laid out for coalesced 16-B accesses (a thread owns one
-// output voxel and 8 output channels; the weights of a tap are read as [ci][co] rows shared by the whole wave),
-// not MFMA kernels -- the baselines' channel counts (48; 64..512 with stride 2) and one-off use do not justify a
-// second family of matrix-core kernels.
+// on NDHWC tensors (fp32 or bf16 storage, fp32 accumulation).  These layers are off the benchmark path.  The kernels
+// in this file are vector-ALU kernels with the arithmetic laid out for coalesced 16-B accesses (a thread owns one
+// output voxel and 8 output channels; the weights of a tap are read as [ci][co] rows shared by the whole wave): they
+// serve fp32 tensors.  bf16 tensors take the matrix-core kernels of tdx_convg_mfma.hip through the same entry points
+// (TDX_CONVG_MFMA=0 keeps them here: the A/B switch of tools/baseline_conv_bench.py).
 //
 // Three kernels cover forward and both gradients of all three layer types:
 //   gather     out[o]  = sum_t W[t] in[src(o, t)],      src = o * stride - pad + t * dilation  (zero or clamped)
@@ -18,6 +18,16 @@
 //   wgrad      dW[t][ci][co] = sum_{b, o} in[src(o, t)][ci] * dy[o][co]
 // Weights are passed as [taps][Cin][Cout] fp32 (the host transposes the reference layouts once per call).
 #include "tdx_common.h"
+#include <stdlib.h>
+
+int convg_mfma_apply(const void* in, const float* w, const float* bias, void* out, int B, const int* Ei, const int* Eo, int Cin,
+                     int Cout, int k, int stride, int dil, int pad, int replicate, int transposed, hipStream_t st);
+int convg_mfma_bwd_weight(const void* in, const void* dy, float* dw, float* dbias, int B, const int* Ei, const int* Eo, int Cin,
+                          int Cout, int k, int stride, int dil, int pad, int replicate, hipStream_t st);
+static bool convg_use_mfma(int dtype) {  // read per call: the switch is a test / benchmark knob
+    const char* e = getenv("TDX_CONVG_MFMA");
+    return dtype == TDX_BF16 && !(e && atoi(e) == 0);
+}
 
 struct ConvG {
     int B;
@@ -222,6 +232,9 @@ extern "C" int tdx_convg_apply(const void* in, const float* w, const float* bias
     int rc = convg_check(B, g.Ei, g.Eo, k, stride, dilation, pad, Cin, Cout);
     if (rc != TDX_OK) return rc;
     if (transposed && replicate) return TDX_EINVAL;
+    if (convg_use_mfma(dtype))
+        return convg_mfma_apply(in, w, bias, out, B, g.Ei, g.Eo, Cin, Cout, k, stride, dilation, pad, replicate, transposed,
+                                as_stream(stream));
     const int64_t total = (int64_t)B * Xo * Yo * Zo * (Cout / 8);
     if (transposed)
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((convg_kernel<T, true>), dim3(ceil_div(total, 256)), dim3(256), 0,
@@ -252,6 +265,9 @@ extern "C" int tdx_convg_bwd_weight(const void* in, const void* dy, float* dw, f
     ConvG g = {B, {Xi, Yi, Zi}, {Xo, Yo, Zo}, k, stride, dilation, pad, replicate, Cin, Cout};
     int rc = convg_check(B, g.Ei, g.Eo, k, stride, dilation, pad, Cin, Cout);
     if (rc != TDX_OK) return rc;
+    if (convg_use_mfma(dtype))
+        return convg_mfma_bwd_weight(in, dy, dw, dbias, B, g.Ei, g.Eo, Cin, Cout, k, stride, dilation, pad, replicate,
+                                     as_stream(stream));
     if (Cout > 512) return TDX_ESHAPE;  // co groups of 8 must fit one workgroup
     const int64_t nvox = (int64_t)B * Xo * Yo * Zo;
     dim3 grid(ceil_div(nvox, CGW_VOX), k * k * k, Cin / 8);
