@@ -762,17 +762,20 @@ def film_projections(c: torch.Tensor, linears) -> list:
 # --------------------------------------------------------------------------- fused ResnetBlock
 
 
-_SIDE = {}  # device index -> side stream of the weight gradients (TDX_WGRAD_STREAM=1)
+_SIDE = {}  # device index -> side stream of the weight gradients
 
 
 class _WgradSide:
-    """TDX_WGRAD_STREAM=1 (experiment): the 3x3x3 weight gradients of a block run on a side stream next to the rest of
-    its backward -- they feed nothing before the optimiser, are bound by the matrix cores, and what runs beside them
-    (GroupNorm backward, 1x1 convs) is bound by memory.  The block joins the streams before it returns, and holds the
-    tensors the side stream reads until then (the caching allocator knows nothing of the side stream's reads)."""
+    """The 3x3x3 weight gradients of a block run on a side stream next to the rest of its backward: they feed nothing
+    before the optimiser and are bound by the matrix cores, what runs beside them (GroupNorm backward, 1x1 convs, the
+    halo-shell launches) is bound by memory or latency: 22.94 -> 22.59 ms per step (four alternating pairs on one
+    box).  The block joins the streams before it returns (gradient hooks and the optimiser see finished tensors) and holds
+    the tensors the side stream reads until then (the caching allocator knows nothing of those reads).  One join at the
+    end of the whole backward pass instead (engine callback) was measured too: no faster (22.77 vs 22.71 ms).
+    TDX_WGRAD_STREAM=0: everything on the launching stream."""
 
     def __init__(self, device):
-        self.on = os.environ.get("TDX_WGRAD_STREAM", "0") == "1"
+        self.on = os.environ.get("TDX_WGRAD_STREAM", "1") != "0"
         if self.on:
             idx = device.index
             if idx not in _SIDE:
