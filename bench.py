@@ -422,6 +422,10 @@ def main():
         if rb:
             out["roofline"] = rb
         out["kernels"] = kernel_table(kern, K)
+        if os.environ.get("TDX_WGRAD_STREAM", "1") != "0":
+            # the weight gradients run on a side stream beside the data-gradient chain (ops._WgradSide): the two event
+            # durations cover overlapped time; TDX_WGRAD_STREAM=0 gives them one after the other
+            out["kernels"]["note"] = "tdx_conv3_bwd_weight and tdx_conv3_bwd_data run concurrently: durations overlap"
     extra = {}
     if accuracy is not None:
         extra["accuracy"] = accuracy

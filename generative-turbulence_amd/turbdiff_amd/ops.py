@@ -771,7 +771,9 @@ class _WgradSide:
     halo-shell launches) is bound by memory or latency: 22.94 -> 22.59 ms per step (four alternating pairs on one
     box).  The block joins the streams before it returns (gradient hooks and the optimiser see finished tensors) and holds
     the tensors the side stream reads until then (the caching allocator knows nothing of those reads).  One join at the
-    end of the whole backward pass instead (engine callback) was measured too: no faster (22.77 vs 22.71 ms).
+    end of the whole backward pass instead (engine callback) was measured too: no faster (22.77 vs 22.71 ms); so was putting
+    the 1x1 skip conv (beside the forward conv chain) and its weight gradient on the side stream as well: -0.07 ms, and
+    the forward convs' own durations grow by 9 % under the overlap.
     TDX_WGRAD_STREAM=0: everything on the launching stream."""
 
     def __init__(self, device):
