@@ -177,7 +177,7 @@ def torch_rocm_baseline(B, dev, amp, steps=2):
 
 # forward instantiations of the matrix-core conv kernels in a rocprofv3 kernel name (ZERO_PAD / ZP template argument false)
 FWD_KERNEL_PATTERNS = {
-    "bf16": r"conv3_ring_kernel<\d, false>|conv3_mfma_kernel<\d, (true|false), false,",  # <NT, ZP> | <NT, XT, ZERO_PAD, PERM, EXT>
+    "bf16": r"conv3_ring_kernel<\d, false, \d>|conv3_mfma_kernel<\d, (true|false), false,",  # <NT, ZP, LW> | <NT, XT, ZERO_PAD, PERM, EXT>
     "f32": r"conv3_mfma_f32_kernel<\d, false,", "f32s": r"conv3_mfma_split_kernel<\d, false,"}
 
 
