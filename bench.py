@@ -87,10 +87,7 @@ def set_mode(diff, mode):
     """bf16: bf16 storage + bf16 MFMA; f32: fp32 storage, IEEE fp32 MFMA convs; f32s: fp32 storage,
     split-precision convs (bf16 hi + lo, three MFMAs per product)."""
     diff.model.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
-    if mode == "f32s":
-        os.environ["TDX_CONV_IMPL"] = "split"
-    else:
-        os.environ.pop("TDX_CONV_IMPL", None)
+    diff.model.conv_impl = "split" if mode == "f32s" else "auto"  # per model: no process-wide switch, no environment edits
 
 
 def cpu_baseline(budget_s=120.0):

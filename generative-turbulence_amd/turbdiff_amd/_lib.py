@@ -184,16 +184,45 @@ _conv_impl_override: str | None = None
 
 
 def set_conv_impl(name: str | None) -> None:
-    """Process-wide choice of the 3x3x3 conv implementation ("auto", "direct", "mfma", "split"; None: back to the
-    TDX_CONV_IMPL environment variable, default "auto").  "split" = split-precision MFMA convs on fp32 tensors."""
+    """Process-wide default of the 3x3x3 conv implementation ("auto", "direct", "mfma", "split"; None: "auto") for code
+    that runs outside any model's conv_impl_scope and without TDX_CONV_IMPL.  "split" = split-precision MFMA convs on
+    fp32 tensors."""
     global _conv_impl_override
     if name is not None and name not in _CONV_IMPLS:
         raise ValueError(f"unknown conv implementation {name!r}")
     _conv_impl_override = name
 
 
+_conv_impl_scopes: list = []  # innermost model whose forward is running (DenoisingModel.conv_impl)
+
+
+class conv_impl_scope:
+    """`with conv_impl_scope(name):` -- the conv implementation of ONE model while its forward runs (name None: no-op).
+    The autograd nodes created inside remember it for their backward, so two models with different arithmetic (an
+    f32s trainer next to an f32 one) no longer share a process-wide switch."""
+
+    def __init__(self, name: str | None):
+        if name is not None and name not in _CONV_IMPLS:
+            raise ValueError(f"unknown conv implementation {name!r}")
+        self.name = name
+
+    def __enter__(self):
+        if self.name is not None:
+            _conv_impl_scopes.append(self.name)
+
+    def __exit__(self, *exc):
+        if self.name is not None:
+            _conv_impl_scopes.pop()
+
+
 def conv_impl() -> int:
-    return _CONV_IMPLS[_conv_impl_override or os.environ.get("TDX_CONV_IMPL", "auto")]
+    """TDX_CONV_IMPL (the explicit test / benchmark knob) > the running model's own choice > set_conv_impl > "auto"."""
+    env = os.environ.get("TDX_CONV_IMPL")
+    if env:
+        return _CONV_IMPLS[env]
+    if _conv_impl_scopes:
+        return _CONV_IMPLS[_conv_impl_scopes[-1]]
+    return _CONV_IMPLS[_conv_impl_override or "auto"]
 
 
 def pack_code(dt: torch.dtype) -> int:

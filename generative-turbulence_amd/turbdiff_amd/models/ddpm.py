@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .. import ops, schedules
+from .. import _lib, ops, schedules
 from ..sequential import KwargsSequential
 from .conditioning import global_conditioning, local_conditioning
 from .utils import broadcast_right
@@ -284,6 +284,7 @@ class DenoisingModel(nn.Module):
         self.u_net_levels = u_net_levels
         self.with_geometry_embedding = with_geometry_embedding
         self.compute_dtype = torch.float32
+        self.conv_impl = None  # "auto" / "split" / "direct" / "mfma": this model's 3x3x3 conv arithmetic (_lib.conv_impl_scope)
 
         groups_of = {"instance": lambda ch: ch, "layer": lambda ch: 1, "group": lambda ch: 8}
         if norm_type not in groups_of:
@@ -384,6 +385,10 @@ class DenoisingModel(nn.Module):
         """encode_c_local(c_local) as a (1, X, Y, Z, dim) NDHWC tensor (None without local
         conditioning).  Independent of x and t: sampling computes it once per trajectory batch
         (the reference recomputes it every step, TODO at ddpm.py:480)."""
+        with _lib.conv_impl_scope(self.conv_impl):
+            return self._encode_local(C)
+
+    def _encode_local(self, C):
         c_local = local_conditioning(C)
         if c_local is None:
             return None
@@ -447,6 +452,11 @@ class DenoisingModel(nn.Module):
         return raw, w_eff, b_eff, self.in_features + self.c_local_features
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
+        # conv_impl: this model's own choice of the 3x3x3 conv arithmetic (None: the process-wide default)
+        with _lib.conv_impl_scope(self.conv_impl):
+            return self._forward(x, t, C, encoded_local)
+
+    def _forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
         B = x.shape[0]
         c = self.conditioning_vector(t, C, B)
         c_local = local_conditioning(C) if self.c_local_features > 0 else None

@@ -321,16 +321,17 @@ class _Conv3(torch.autograd.Function):
         ctx.save_for_backward(x1, x2, wb)
         ctx.has_bias = bias is not None
         ctx.wshape = tuple(weight.shape)
+        impl = ctx.impl = L.conv_impl()  # the backward runs outside the model's conv_impl_scope: it reuses this
         if gn_groups:
             stats = torch.empty((B, gn_groups, 2), dtype=torch.float32, device=x1.device)
             ws = _clean_ws(L.query("tdx_gn_workspace_bytes", B, Cout), x1.device)
             L.call("tdx_conv3_fwd_gn", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats),
-                   gn_groups, float(gn_eps), L.ptr(ws), B, X, Y, Z, Cout, L.dtype_code(dt), L.conv_impl() | WS_CLEAN,
+                   gn_groups, float(gn_eps), L.ptr(ws), B, X, Y, Z, Cout, L.dtype_code(dt), impl | WS_CLEAN,
                    L.stream(), work=flops, meta=lambda: L.conv3_fwd_meta(C1, C2, Cout, B, X, Y, Z, dt))
             ctx.mark_non_differentiable(stats)
             return y, stats
         L.call("tdx_conv3_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), B, X, Y, Z, Cout,
-               L.dtype_code(dt), L.conv_impl(), L.stream(), work=flops,
+               L.dtype_code(dt), impl, L.stream(), work=flops,
                meta=lambda: L.conv3_fwd_meta(C1, C2, Cout, B, X, Y, Z, dt))
         return y
 
@@ -343,7 +344,7 @@ class _Conv3(torch.autograd.Function):
         Cout, Cin = ctx.wshape[0], ctx.wshape[1]
         gy = gy.contiguous()
         dt, dev = gy.dtype, gy.device
-        code, impl, st = L.dtype_code(dt), L.conv_impl(), L.stream()
+        code, impl, st = L.dtype_code(dt), ctx.impl, L.stream()
         gx1 = gx2 = gw = gb = None
         if ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1]):
             gx1 = torch.empty_like(x1)
@@ -880,7 +881,7 @@ class _ResnetBlock(torch.autograd.Function):
         ctx.save_for_backward(x1, x2, h1, st1, a1, h2, st2, film, g1, be1, g2, be2, wb1, wb2, wr2, xc)
         ctx.cfg = (groups, tuple(w1.shape), tuple(w2.shape), None if wr is None else tuple(wr.shape),
                    b1 is not None, b2 is not None, br is not None)
-        ctx.xc_real = xc_real
+        ctx.xc_real, ctx.impl = xc_real, impl
         return y
 
     @staticmethod
@@ -896,7 +897,7 @@ class _ResnetBlock(torch.autograd.Function):
         V = X * Y * Z
         gy = gy.contiguous()
         dev, dt = gy.device, gy.dtype
-        code, impl, st = L.dtype_code(dt), L.conv_impl(), L.stream()
+        code, impl, st = L.dtype_code(dt), ctx.impl, L.stream()
         f32 = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         gws = _ws(L.query("tdx_gn_workspace_bytes", B, Cout), dev)
         flops = lambda ci: 54.0 * ci * Cout * B * V

@@ -77,12 +77,11 @@ COMPUTE_MODES = ("f32", "f32s", "bf16")
 
 def apply_compute_mode(net: DenoisingModel, mode: str) -> None:
     """f32: fp32 tensors, IEEE fp32 MFMA convs; f32s: fp32 tensors, split-precision convs; bf16: bf16 tensors."""
-    from . import _lib
-
     if mode not in COMPUTE_MODES:
         raise ValueError(f"compute mode {mode!r} not in {COMPUTE_MODES}")
     net.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
-    _lib.set_conv_impl("split" if mode == "f32s" else None)
+    # per model, not per process: a second trainer in another mode leaves this one's arithmetic alone
+    net.conv_impl = "split" if mode == "f32s" else "auto"
 
 
 def _get(cfg, key, default=None):

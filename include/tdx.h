@@ -153,7 +153,13 @@ int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void* wf, const
  * wf[tap][:, :] dy[b,v,:]  (adjoint of the replicate-padded conv, halo folded back onto
  * the boundary).  The result has C1 + C2 channels and is split into dx1 / dx2 (dx2 may be
  * NULL when C2 == 0).  If `accumulate` != 0 the result is added to dx1/dx2 instead of
- * overwriting.  workspace: tdx_conv3_bwd_data_workspace_bytes(). */
+ * overwriting.  workspace: tdx_conv3_bwd_data_workspace_bytes().
+ * Reproducibility: on the brick / ring kernels the boundary voxels' halo-shell terms are ADDED onto the stored main term
+ * (tdx_conv3_shell.hip): a voxel on exactly one face gets one read-add-write, edge and corner voxels get up to 7 hardware
+ * atomics (global_atomic_pk_add_bf16 / global_atomic_add_f32) in whatever order the workgroups finish, each with its own
+ * rounding in the tensor's dtype -- those voxels (1-3 % of the boundary shell) are not bit-reproducible from run to run,
+ * in bf16 within 2^-8 relative per add.  Everything else in the library sums in a fixed order.  The small-grid kernels of the
+ * deep levels and impl = TDX_CONV_DIRECT are deterministic throughout. */
 size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z, int Cin, int dtype, int impl);
 int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2, int accumulate,
                        int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* workspace, void* stream);

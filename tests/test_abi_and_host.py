@@ -198,6 +198,37 @@ def test_trainer_from_config_matches_reference_task(case):
             assert abs(sched.lr_lambdas[0](int(step)) - f) <= 1e-15 * max(1.0, abs(f)), step
 
 
+def test_conv_arithmetic_is_chosen_per_model_not_per_process(monkeypatch):
+    """Building a trainer must not change the conv arithmetic of other models in the process: the choice lives on the
+    DenoisingModel (conv_impl), is in force while ITS forward runs (_lib.conv_impl_scope) and remembered by the autograd
+    nodes for their backward; TDX_CONV_IMPL stays the explicit override of tests and benchmarks."""
+    from turbdiff_amd import _lib as L
+    from turbdiff_amd.training import DiffusionTrainer
+
+    monkeypatch.delenv("TDX_CONV_IMPL", raising=False)
+    small = {**DiffusionTrainer.SHIPPED_CONFIG, "dim": 8, "timesteps": 10}
+    a = DiffusionTrainer(**small, u_net_levels=2, max_train_steps=5, compute_mode="f32s")
+    b = DiffusionTrainer(**small, u_net_levels=2, max_train_steps=5, compute_mode="f32")
+    c = DiffusionTrainer(**small, u_net_levels=2, max_train_steps=5, compute_mode="bf16")
+    assert (a.model.model.conv_impl, b.model.model.conv_impl, c.model.model.conv_impl) == ("split", "auto", "auto")
+    assert L.conv_impl() == L.CONV_AUTO  # nothing process-wide was touched
+    with L.conv_impl_scope(a.model.model.conv_impl):
+        assert L.conv_impl() == L.CONV_SPLIT and L.pack_code(torch.float32) == L.F32_SPLIT
+        with L.conv_impl_scope(b.model.model.conv_impl):  # a model called inside another model's forward
+            assert L.conv_impl() == L.CONV_AUTO
+        assert L.conv_impl() == L.CONV_SPLIT
+        monkeypatch.setenv("TDX_CONV_IMPL", "direct")
+        assert L.conv_impl() == L.CONV_DIRECT
+        monkeypatch.delenv("TDX_CONV_IMPL")
+    assert L.conv_impl() == L.CONV_AUTO
+    with L.conv_impl_scope(None):  # a model without a choice of its own: the process default
+        L.set_conv_impl("split")
+        assert L.conv_impl() == L.CONV_SPLIT
+        L.set_conv_impl(None)
+    with pytest.raises(ValueError):
+        L.conv_impl_scope("winograd")
+
+
 def test_trainer_constructor_defaults_are_the_reference_constructors():
     """DiffusionTrainer() with NO keywords against the reference's DiffusionTraining built with only its two required
     paths (diffusion.py:42-70 defaults: sigmoid schedule, T = 100, l1, Adam at 1e-3 without decay, instance norm,

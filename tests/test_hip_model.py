@@ -434,6 +434,40 @@ def test_fused_resnet_block_golden(golden, dtype):
             assert_grad_close(f"{tag}/{k}", v.grad.cpu(), g[f"{tag}/grad/{k}"], gtol)
 
 
+def test_two_trainers_in_different_modes_keep_their_own_conv_arithmetic(golden, monkeypatch):
+    """an f32 trainer built after an f32s one used to reset the f32s model to IEEE-fp32 convs (process-global
+    switch).  The f32s model's output must not change when another trainer is built, must differ from the f32 model's on
+    the same weights (different arithmetic), and its backward -- which runs outside the forward's scope -- must work on the
+    split-packed operands."""
+    from turbdiff_amd.training import DiffusionTrainer
+
+    monkeypatch.delenv("TDX_CONV_IMPL", raising=False)
+    g = golden("model_cfg1")
+    d = dev()
+    small = {**DiffusionTrainer.SHIPPED_CONFIG, "dim": 8, "timesteps": 10}
+    build = lambda mode: DiffusionTrainer(**small, u_net_levels=2, max_train_steps=5, compute_mode=mode).to(d)
+    a = build("f32s")
+    a.model.model.load_state_dict(g.sub("sd/"))
+    x, t = g["x"].to(d), g["t"].to(d)
+    cl = cond(torch.randn(a.model.model.c_local_features, *g["x"].shape[-3:], generator=torch.Generator().manual_seed(5)).to(d))
+    with torch.no_grad():
+        ya = a.model.model(x, t, cl)
+    b = build("f32")
+    b.model.model.load_state_dict(g.sub("sd/"))
+    with torch.no_grad():
+        yb = b.model.model(x, t, cl)
+        ya2 = a.model.model(x, t, cl)
+    assert torch.equal(ya, ya2), "building a second trainer changed the first one's arithmetic"
+    assert not torch.equal(ya, yb) and rel_l2(ya.cpu(), yb.cpu()) < 1e-4
+    out = a.model.model(x, t, cl)
+    out.square().mean().backward()  # data / weight gradients on the split-packed operands, outside the forward's scope
+    gb = b.model.model(x, t, cl)
+    gb.square().mean().backward()
+    for (n, pa), (_, pb) in zip(a.model.model.named_parameters(), b.model.model.named_parameters()):
+        if pa.grad is not None and pb.grad is not None and pb.grad.norm() > 0:
+            assert rel_l2(pa.grad.cpu(), pb.grad.cpu()) < 2e-3, n
+
+
 def test_trainer_training_step_and_sample(golden):
     """DiffusionTrainer: normalisation + learned cell-type embedding + GaussianDiffusion, checked
     against the oracle fed with the same normalised input / embedded conditioning."""
