@@ -270,8 +270,8 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)   # 0.5 s of timed steps; 5 steps after 2 warm-up measured 3 % slower
+    ap.add_argument("--warmup", type=int, default=5)   # (clocks and allocator not settled) than 20 after 5 on the same box
     ap.add_argument("--batch", type=int, default=6, help="per-GPU batch (reference: 6, config/model/diffusion.yaml:3)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32s"],
                     help="mode of the headline line.  bf16: bf16 storage + bf16 MFMA (BASELINE configs[1]); f32: fp32 storage, "

@@ -8,6 +8,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
+# Per-kernel attribution needs kernels that run one after the other: the weight gradients go back onto the launching stream
+# for the profiled runs (in the product they run on a side stream beside the data-gradient chain -- ops._WgradSide -- and a
+# kernel trace then charges each of two concurrent kernels the whole overlapped span).  The forward launches that
+# bench.py's roofline is quoted on have nothing beside them either way.
+export TDX_WGRAD_STREAM=${TDX_WGRAD_STREAM:-0}
 BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra ${TDX_BENCH_ARGS:-}"
 # (1) per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1

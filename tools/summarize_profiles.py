@@ -37,7 +37,10 @@ def counter_avgs(pattern):
 fetch, write, sq = counter_avgs("fetch/*/*counter_collection.csv"), counter_avgs("write/*/*counter_collection.csv"), counter_avgs("sq/*/*counter_collection.csv")
 mean = lambda v: sum(v) / max(len(v), 1)
 lines = [f"# rocprofv3 summary `{tag}` — `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra` (B = 6, {mode}, 192x64x48)", "",
-         f"Total kernel time {tot/1e6/steps:.2f} ms per step ({steps} steps incl. warm-up in the trace).", "",
+         f"Total kernel time {tot/1e6/steps:.2f} ms per step ({steps} steps incl. warm-up in the trace).  Collected with "
+         "`TDX_WGRAD_STREAM=0` (tools/collect_profiles.sh): every kernel runs alone, so durations and counters are its own; the "
+         "product overlaps the weight gradients with the data-gradient chain on a side stream (DESIGN 3.4) and its step is "
+         "shorter than this sum.", "",
          "| kernel | calls/step | ms/step | avg µs | % |", "|---|---|---|---|---|"]
 for r in rows[:28]:
     lines.append(f"| `{r['Name'][:80]}` | {int(r['Calls'])/steps:.1f} | {float(r['TotalDurationNs'])/1e6/steps:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
