@@ -310,10 +310,18 @@ def main():
     dev = torch.device("cuda", local)
     B, K, Wm = args.batch, args.steps, args.warmup
 
+    wall, t_leg = {}, [time.perf_counter()]  # wall seconds per leg of this call -> extra.wall_s
+
+    def leg_done(name):
+        now = time.perf_counter()
+        wall[name] = round(now - t_leg[0], 1)
+        t_leg[0] = now
+
     # ---- CPU leg first (rank 0, N = 1): baseline + the oracle's eps-hat for the accuracy probe
     cpu, probe = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, probe = cpu_baseline()
+        leg_done("cpu_baseline")
 
     from turbdiff_amd.models.conditioning import Conditioning
     from turbdiff_amd.optim import ClipRAdam
@@ -393,7 +401,9 @@ def main():
         kern = merged_kernel_times(timer)
         return elapsed, (kern, timer), loss.item(), train_step
 
+    leg_done("build_model_and_accuracy_probe")
     elapsed, (kern, timer), last_loss, train_step = run_mode(args.dtype, K, Wm)
+    leg_done("headline_steps")
     value = world * B * V * K / elapsed
     out = {
         "metric": "U-Net fwd+bwd voxels/sec (DDPM training step, 192x64x48x4)",
@@ -475,6 +485,7 @@ def main():
             pm[m] = d
         extra["parity_modes"] = pm
         set_mode(diff, args.dtype)
+        leg_done("parity_modes")
 
     if not args.no_extra:
         set_mode(diff, args.dtype)
@@ -515,6 +526,7 @@ def main():
                                  "ddpm_samples_per_s_T500": Bs * world / (per_step * 500),
                                  "note": "whole-job aggregate; per-step time x T" + ("" if full else " (extrapolated from the timed steps)")}
             del sampler, sdiff
+        leg_done("forward_and_sampling")
     if extra:
         out["extra"] = extra
 
@@ -529,6 +541,9 @@ def main():
             except Exception as e:  # noqa: BLE001 -- a baseline that cannot run is reported, not fatal
                 ref["bf16_autocast" if amp else "fp32"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out.setdefault("extra", {})["torch_rocm_reference"] = ref
+        leg_done("torch_rocm_reference")
+    if rank == 0 and wall:
+        out.setdefault("extra", {})["wall_s"] = wall
 
     if cpu is not None:
         out["cpu_baseline"] = cpu

@@ -13,7 +13,6 @@
 //             atomics, deterministic) -> finalize -> apply pass
 #define TDX_NT_LOADS 1  // activations are streamed once per pass: nontemporal 16-B loads (+0.4 % step)
 #include "tdx_common.h"
-#include <stdlib.h>
 
 #define GN_THREADS 256
 #define GN_VOX_PER_BLOCK 1024
@@ -399,7 +398,7 @@ gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const flo
                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ scale,
                     const float* __restrict__ shift, const float* __restrict__ gsum, T* __restrict__ dx, int64_t V,
                     int C, int G, const double* __restrict__ acc, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                    float* __restrict__ dscale, float* __restrict__ dshift, int rev) {
+                    float* __restrict__ dscale, float* __restrict__ dshift) {
     if (blockIdx.x == 0 && blockIdx.y == 0) gn_bwd_params(acc, gamma, beta, scale, dgamma, dbeta, dscale, dshift, gridDim.y, C);
     const int b = blockIdx.y;
     const int L = C >> 3;
@@ -423,10 +422,6 @@ gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const flo
     }
     const int64_t base = ((int64_t)b * V) * C + lc * 8;
     const int64_t stride = (int64_t)gridDim.x * rows;
-    // rev: walk the sample from its last voxel down.  The reduce pass has just streamed x and dy front to back; what the
-    // 256 MiB Infinity Cache still holds of them is their END, and a second front-to-back sweep would push that out before
-    // reaching it.
-    auto at = [&](int64_t vv) { return rev ? V - 1 - vv : vv; };
     auto one = [&](const Vec8<T>& a, const Vec8<T>& g, int64_t vv) {
         Vec8<T> o;
 #pragma unroll
@@ -436,15 +431,15 @@ gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const flo
             const float xh = __builtin_fmaf(a.v[j], rstd[j], mr[j]);
             o.v[j] = __builtin_fmaf(k1[j], dn, -__builtin_fmaf(xh, k3[j], k2[j]));
         }
-        o.store(dx + base + at(vv) * C);
+        o.store(dx + base + vv * C);
     };
     int64_t v = (int64_t)blockIdx.x * rows + r;
     for (; v + (GN_UNROLL - 1) * stride < V; v += stride * GN_UNROLL) {
         Raw8<T> a[GN_UNROLL], g[GN_UNROLL];
 #pragma unroll
         for (int u = 0; u < GN_UNROLL; ++u) {
-            a[u].load(x + base + at(v + u * stride) * C);
-            g[u].load(dy + base + at(v + u * stride) * C);
+            a[u].load(x + base + (v + u * stride) * C);
+            g[u].load(dy + base + (v + u * stride) * C);
         }
         __builtin_amdgcn_sched_barrier(0);  // all loads of the trip are issued before any arithmetic
 #pragma unroll
@@ -452,8 +447,8 @@ gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const flo
     }
     for (; v < V; v += stride) {
         Vec8<T> a, g;
-        a.load(x + base + at(v) * C);
-        g.load(dy + base + at(v) * C);
+        a.load(x + base + v * C);
+        g.load(dy + base + v * C);
         one(a, g, v);
     }
 }
@@ -472,8 +467,6 @@ extern "C" int tdx_gn_bwd(const void* x, const void* dy, const float* stats, con
     float* partial = gsum + (size_t)B * C * 2;             // [B][nblk][C][2]
     dim3 grid(nblk, B);
     hipStream_t st = as_stream(stream);
-    const char* rev_env = getenv("TDX_GN_REVERSE");  // A/B switch, read per call
-    const int rev = rev_env ? atoi(rev_env) : 1;
     if (act)
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, true>), grid, dim3(GN_THREADS), 0, st,
                                                       (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift,
@@ -486,10 +479,10 @@ extern "C" int tdx_gn_bwd(const void* x, const void* dy, const float* stats, con
     if (act)
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, true>), grid, dim3(GN_THREADS), 0, st,
                                                       (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, gsum,
-                                                      (T*)dx, V, C, G, acc, dgamma, dbeta, dscale, dshift, rev));
+                                                      (T*)dx, V, C, G, acc, dgamma, dbeta, dscale, dshift));
     else
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, false>), grid, dim3(GN_THREADS), 0, st,
                                                       (const T*)x, (const T*)dy, stats, gamma, beta, scale, shift, gsum,
-                                                      (T*)dx, V, C, G, acc, dgamma, dbeta, dscale, dshift, rev));
+                                                      (T*)dx, V, C, G, acc, dgamma, dbeta, dscale, dshift));
     return tdx_launch_status();
 }

@@ -464,7 +464,8 @@ def test_two_trainers_in_different_modes_keep_their_own_conv_arithmetic(golden, 
     gb = b.model.model(x, t, cl)
     gb.square().mean().backward()
     for (n, pa), (_, pb) in zip(a.model.model.named_parameters(), b.model.model.named_parameters()):
-        if pa.grad is not None and pb.grad is not None and pb.grad.norm() > 0:
+        # (a conv bias in front of a normalisation has a mathematically zero gradient: rounding noise in both modes)
+        if pa.grad is not None and pb.grad is not None and pb.grad.abs().max() > 1e-6:
             assert rel_l2(pa.grad.cpu(), pb.grad.cpu()) < 2e-3, n
 
 

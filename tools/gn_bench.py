@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """GroupNorm backward (tdx_gn_bwd: reduce pass + group pass + apply pass) at the U-Net's level-0 / level-1 shapes, B = 6, bf16:
-microseconds per call and the bandwidth over its 5 activation passes, with the apply pass walking each sample back to front
-(TDX_GN_REVERSE=1, default: what the reduce pass left in the Infinity Cache is read first) and front to back (=0).
+microseconds per call and the bandwidth over its 5 activation passes.  (Round 3 measured an apply pass that walks each
+sample back to front, so that what the reduce pass left in the 256 MiB Infinity Cache is read first: 199 vs 192 us at
+192x64x48 x 32 channels, 437 vs 431 at 64 channels -- no gain, not kept.)
 GPU box: python tools/gn_bench.py"""
 import os, sys
 from pathlib import Path
@@ -23,8 +24,7 @@ for (grid, C) in (((192, 64, 48), 64), ((192, 64, 48), 32), ((96, 32, 24), 128),
     st = L.stream()
     L.call("tdx_gn_stats", L.ptr(x), L.ptr(stats), B, V, C, G, 1e-5, L.BF16, L.ptr(ws), st)
     out = []
-    for rev in ("0", "1", "0", "1"):
-        os.environ["TDX_GN_REVERSE"] = rev
+    for rep in range(2):
         go = lambda: L.call("tdx_gn_bwd", L.ptr(x), L.ptr(dy), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift),
                             L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(ds), L.ptr(dsh), B, V, C, G, 1, L.BF16, L.ptr(ws), st)
         for _ in range(5): go()
@@ -33,5 +33,5 @@ for (grid, C) in (((192, 64, 48), 64), ((192, 64, 48), 32), ((96, 32, 24), 128),
         for _ in range(20): go()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / 20 * 1e3
-        out.append(f"rev={rev}: {us:7.1f} us ({5 * x.numel() * 2 / us / 1e6:5.2f} TB/s)")
+        out.append(f"{us:7.1f} us ({5 * x.numel() * 2 / us / 1e6:5.2f} TB/s)")
     print(f"gn_bwd {grid[0]}x{grid[1]}x{grid[2]} C={C:3d} ({x.numel() * 2 / 1e6:.0f} MB per tensor): " + "  ".join(out), flush=True)
