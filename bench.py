@@ -270,6 +270,8 @@ def self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--torch-find", choices=("fast", "full"), default="fast",
+                    help="MIOpen find mode of the stock PyTorch-ROCm leg: fast (default, seconds) or full (exhaustive, ~10 min cold)")
     ap.add_argument("--steps", type=int, default=20)   # 0.5 s of timed steps; 5 steps after 2 warm-up measured 3 % slower
     ap.add_argument("--warmup", type=int, default=5)   # (clocks and allocator not settled) than 20 after 5 on the same box
     ap.add_argument("--batch", type=int, default=6, help="per-GPU batch (reference: 6, config/model/diffusion.yaml:3)")
@@ -533,7 +535,15 @@ def main():
     if world == 1 and not args.no_torch_baseline and not args.no_extra:
         del diff
         torch.cuda.empty_cache()
-        ref = {}
+        # MIOpen's default find mode compiles and times every candidate solver of every conv shape on a cold cache: 614 s
+        # of wall time for this leg on a fresh box (559 ms bf16 autocast / 4744 ms fp32 per step once it is done,
+        # profiles/r10_bench_default_fullfind.json).  The default run asks for MIOpen's FAST mode (20 s; 587 / 6474 ms) and says
+        # so; --torch-find full restores the exhaustive search.
+        if args.torch_find == "fast":
+            os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+        ref = {"miopen_find_mode": os.environ.get("MIOPEN_FIND_MODE", "default (exhaustive)"),
+               "note": "exhaustive find on a cold cache takes ~10 min and gave 559 ms (bf16 autocast) / 4744 ms (fp32) per "
+                       "step on this GPU (profiles/r10_bench_default_fullfind.json)"}
         for amp in (True, False):
             torch.cuda.reset_peak_memory_stats()
             try:
