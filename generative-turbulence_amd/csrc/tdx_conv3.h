@@ -91,8 +91,11 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
 
 // halo-shell term of the data gradient, added onto dx with atomics (tdx_conv3_shell.hip); mode 0 bf16, 1 fp32 MFMA,
 // 2 split-precision; wb = the packed data-gradient operand for (K -> N) in that mode's layout
+// sbuf: conv3_shell_buffer_bytes() of scratch, used when TDX_SHELL_DETERMINISTIC=1 (positions stored, then folded in a
+// fixed order by a second kernel, instead of atomics on edge / corner voxels); nullptr: always the atomics route
+size_t conv3_shell_buffer_bytes(int B, int X, int Y, int Z, int N);
 int conv3_shell_launch(const void* dy, const void* wb, void* d1, int D1, void* d2, int B, int X, int Y, int Z, int K, int N,
-                       int mode, hipStream_t st);
+                       int mode, hipStream_t st, void* sbuf = nullptr);
 
 int conv3_direct_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                         const Conv3Geom& g, int Cout, int dtype, bool zero_pad, hipStream_t st);

@@ -680,9 +680,12 @@ extern "C" int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void
 
 extern "C" size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z, int Cin, int dtype, int impl) {
     // the padded tensor of the vector-ALU path (shapes the MFMA kernels do not cover, TDX_CONV_DIRECT); which path a
-    // call takes also depends on Cout, so the size is the same for all; the MFMA paths do not touch it
+    // call takes also depends on Cout, so the size is the same for all; the MFMA paths use it only for the position buffer
+    // of the deterministic halo-shell route
     (void)impl;
-    return (size_t)B * (X + 2) * (Y + 2) * (Z + 2) * Cin * (dtype == TDX_BF16 ? 2 : 4) + 256;
+    const size_t padded = (size_t)B * (X + 2) * (Y + 2) * (Z + 2) * Cin * (dtype == TDX_BF16 ? 2 : 4);
+    const size_t shell = conv3_shell_buffer_bytes(B, X, Y, Z, Cin);  // TDX_SHELL_DETERMINISTIC=1: one fp32 row per shell position
+    return (padded > shell ? padded : shell) + 256;
 }
 
 // dx = adjoint of the replicate-padded conv.  MFMA paths: main term = zero-padded correlation on the original grid
@@ -708,7 +711,7 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
         if (rc == TDX_ESHAPE)
             rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2);
         if (rc != TDX_OK) return rc;
-        return conv3_shell_launch(dy, wb, dx1, C1, dx2, B, X, Y, Z, Cout, Cin, 0, st);
+        return conv3_shell_launch(dy, wb, dx1, C1, dx2, B, X, Y, Z, Cout, Cin, 0, st, workspace);
     } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT &&
                ((impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin)) || conv3_mfma_f32_supported(Cout, 0, Cin))) {
         const bool split = impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin);
@@ -721,7 +724,7 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
                    : conv3_mfma_f32_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2,
                                            add1, add2);
         if (rc != TDX_OK) return rc;
-        return conv3_shell_launch(dy, wb, dx1, C1, dx2, B, X, Y, Z, Cout, Cin, split ? 2 : 1, st);
+        return conv3_shell_launch(dy, wb, dx1, C1, dx2, B, X, Y, Z, Cout, Cin, split ? 2 : 1, st, workspace);
     }
     // adjoint on the padded grid: dpad[p'] = sum_e wb[e] dy_zero[p' - 1 + e]
     const Conv3Geom g = {B, X, Y, Z, X + 2, Y + 2, Z + 2, -1};

@@ -21,11 +21,16 @@
 // source plane (18 x 18 voxels) and the slice's weights of the 9 live taps go to LDS; wave w owns patch rows
 // 4w .. 4w+3 = two 32-position M tiles.  Results are ADDED onto dx[clamp(p)]: a voxel on exactly one face receives
 // exactly one shell position, so it is a plain 16-B read-add-write; edge and corner voxels (up to 7 positions from
-// different workgroups) use hardware atomics (global_atomic_add_f32 / global_atomic_pk_add_bf16).  Atomics for the
+// different workgroups) use hardware atomics (global_atomic_add_f32 / global_atomic_pk_add_bf16) -- in whatever order the
+// workgroups finish, each add rounded in the tensor's dtype: those voxels are not bit-reproducible from run to run.
+// TDX_SHELL_DETERMINISTIC=1 (read per call) takes the other route: every workgroup STORES its fp32 tile into a buffer with
+// one row per shell position (each position is computed exactly once), and conv3_shell_fold_kernel adds, for every boundary
+// voxel, the up to 7 positions that clamp onto it in a fixed order and rounds once.  Atomics for the
 // whole shell were measured first: 44 G atomics/s made the kernel 10x slower than its MFMA work.  Three arithmetic modes mirror the three conv kernels: bf16 MFMA, IEEE fp32 MFMA, and
 // split-precision (bf16 hi + lo, three MFMAs per product) on fp32 tensors.
 #include "tdx_common.h"
 #include "tdx_conv3.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -67,7 +72,8 @@ struct ShellView {
 
 struct ShellRegions {
     ShellView v[3];
-    int start[4];  // first block of region r; blocks of a region: [b][face][patch1][patch2]
+    int start[4];   // first block of region r; blocks of a region: [b][face][patch1][patch2]
+    int pstart[4];  // first row of region r in the position buffer; rows of a region: [b][face][position 1][position 2]
     int B;
 };
 
@@ -88,7 +94,7 @@ __device__ __forceinline__ void sh_split8(const float4& a, const float4& b, uint
 template <int MODE, int NT, int S>
 __global__ void __launch_bounds__(256, 2)
 conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, void* __restrict__ d1_, int D1,
-                   void* __restrict__ d2_, ShellRegions R, int K, int N, int64_t lo_offset) {
+                   void* __restrict__ d2_, ShellRegions R, int K, int N, int64_t lo_offset, float* __restrict__ sbuf) {
     constexpr int BN = NT * 32;
     constexpr int KC = MODE == SH_F32 ? 8 : 16;                // channels per K slice (one MFMA K step / four fp32 ones)
     constexpr int Q = 2 * S;                                   // S slices are staged per iteration, as Q half-slice planes
@@ -111,9 +117,9 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
     // block -> region, sample, face, patch.  The view is selected by value (uniform selects).
     int bid = blockIdx.x;
     ShellView g = R.v[0];
-    int first = 0;
-    if (bid >= R.start[1]) { g = R.v[1]; first = R.start[1]; }
-    if (bid >= R.start[2]) { g = R.v[2]; first = R.start[2]; }
+    int first = 0, prow0 = R.pstart[0];
+    if (bid >= R.start[1]) { g = R.v[1]; first = R.start[1]; prow0 = R.pstart[1]; }
+    if (bid >= R.start[2]) { g = R.v[2]; first = R.start[2]; prow0 = R.pstart[2]; }
     bid -= first;
     const int q2 = bid % g.nb[1]; bid /= g.nb[1];
     const int q1 = bid % g.nb[0]; bid /= g.nb[0];
@@ -321,6 +327,17 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
         const int v = p / CHUNKS, cidx = p % CHUNKS;
         const int l1 = v / SH_P, l2 = v % SH_P;
         if (q1 * SH_P + l1 >= g.ext[0] || q2 * SH_P + l2 >= g.ext[1]) continue;
+        if (sbuf != nullptr) {  // deterministic route: this position's fp32 row, folded by conv3_shell_fold_kernel
+            const int64_t row = prow0 + ((int64_t)(b * 2 + face) * g.ext[0] + q1 * SH_P + l1) * g.ext[1] + q2 * SH_P + l2;
+            float* dst = sbuf + row * N + n0 + cidx * CH;
+#pragma unroll
+            for (int q = 0; q < CH / 4; ++q) {
+                const int c4 = cidx * (CH / 4) + q;
+                *reinterpret_cast<float4*>(dst + 4 * q) =
+                    *reinterpret_cast<const float4*>(sO + v * (BN * 4) + ((c4 ^ (v & (BN / 4 - 1))) << 4));
+            }
+            continue;
+        }
         const int c1 = min(max(p1 + l1, 0), g.E[1] - 1), c2 = min(max(p2 + l2, 0), g.E[2] - 1);
         // on a second face (a grid one voxel thick has both faces of the clamped axis on the same plane)
         const bool shared = c1 == 0 || c1 == g.E[1] - 1 || c2 == 0 || c2 == g.E[2] - 1 || g.E[0] == 1;
@@ -369,9 +386,73 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
     SH_T();  // fold done
 }
 
+// Deterministic route, second pass: dx[u] += sum over the shell positions p != u with clamp(p) = u of their rows of the
+// position buffer, in a fixed order (z outermost), one rounding.  Threads walk the boundary voxels only: first the two z
+// planes, then the y planes between them, then the x planes inside both.
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv3_shell_fold_kernel(const float* __restrict__ sbuf, T* __restrict__ d1, int D1, T* __restrict__ d2, ShellRegions R, int X,
+                        int Y, int Z, int N) {
+    const int groups = N >> 3;
+    const int64_t nz = 2 * (int64_t)X * Y, ny = Z > 2 ? 2 * (int64_t)X * (Z - 2) : 0, nx = (Z > 2 && Y > 2) ? 2 * (int64_t)(Y - 2) * (Z - 2) : 0;
+    const int64_t per_sample = (Z == 1 ? nz / 2 : nz) + (Y == 1 ? ny / 2 : ny) + (X == 1 ? nx / 2 : nx);
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)R.B * per_sample * groups) return;
+    const int cg = (int)(idx % groups);
+    int64_t j = idx / groups;
+    const int b = (int)(j / per_sample);
+    j -= (int64_t)b * per_sample;
+    int u[3];  // (x, y, z)
+    const int64_t nzz = Z == 1 ? nz / 2 : nz, nyy = Y == 1 ? ny / 2 : ny;
+    if (j < nzz) {
+        const int f = (int)(j / ((int64_t)X * Y)); const int64_t rem = j % ((int64_t)X * Y);
+        u[2] = f ? Z - 1 : 0; u[0] = (int)(rem / Y); u[1] = (int)(rem % Y);
+    } else if (j < nzz + nyy) {
+        j -= nzz;
+        const int f = (int)(j / ((int64_t)X * (Z - 2))); const int64_t rem = j % ((int64_t)X * (Z - 2));
+        u[1] = f ? Y - 1 : 0; u[0] = (int)(rem / (Z - 2)); u[2] = 1 + (int)(rem % (Z - 2));
+    } else {
+        j -= nzz + nyy;
+        const int f = (int)(j / ((int64_t)(Y - 2) * (Z - 2))); const int64_t rem = j % ((int64_t)(Y - 2) * (Z - 2));
+        u[0] = f ? X - 1 : 0; u[1] = 1 + (int)(rem / (Z - 2)); u[2] = 1 + (int)(rem % (Z - 2));
+    }
+    const int E[3] = {X, Y, Z};
+    int lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = u[a] == 0 ? -1 : u[a];
+        hi[a] = u[a] == E[a] - 1 ? E[a] : u[a];
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int pz = lo[2]; pz <= hi[2]; ++pz)
+        for (int py = lo[1]; py <= hi[1]; ++py)
+            for (int px = lo[0]; px <= hi[0]; ++px) {
+                if (px == u[0] && py == u[1] && pz == u[2]) continue;  // the voxel itself: the main term
+                // owner region of the position: z faces own every (x, y); y faces the rest with z inside; x faces the rest
+                int r, face, a1, a2;
+                if (pz < 0 || pz >= Z) { r = 0; face = pz >= Z; a1 = px; a2 = py; }
+                else if (py < 0 || py >= Y) { r = 1; face = py >= Y; a1 = px; a2 = pz; }
+                else { r = 2; face = px >= X; a1 = py; a2 = pz; }
+                const ShellView& g = R.v[r];
+                const int64_t row = R.pstart[r] + ((int64_t)(b * 2 + face) * g.ext[0] + (a1 - g.org[0])) * g.ext[1] + (a2 - g.org[1]);
+                const float* p = sbuf + row * N + cg * 8;
+                const float4 va = *reinterpret_cast<const float4*>(p), vb = *reinterpret_cast<const float4*>(p + 4);
+                acc[0] += va.x; acc[1] += va.y; acc[2] += va.z; acc[3] += va.w;
+                acc[4] += vb.x; acc[5] += vb.y; acc[6] += vb.z; acc[7] += vb.w;
+            }
+    const int64_t vox = (((int64_t)b * X + u[0]) * Y + u[1]) * Z + u[2];
+    const int n = cg * 8;
+    T* dst = n < D1 ? d1 + vox * D1 + n : d2 + vox * (N - D1) + (n - D1);
+    Vec8<T> o;
+    o.load(dst);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.v[e] += acc[e];
+    o.store(dst);
+}
+
 template <int MODE, int NT, int S>
 static int shell_go(const void* dy, const void* wb, void* d1, int D1, void* d2, const ShellRegions& R, int K, int N,
-                    int64_t lo_offset, hipStream_t st) {
+                    int64_t lo_offset, float* sbuf, hipStream_t st) {
     constexpr int BN = NT * 32;
     constexpr int PARTS = MODE == SH_SPLIT ? 2 : 1;
     size_t lds = (size_t)PARTS * 2 * S * (SH_H * SH_SZ * 16 + 64) + (size_t)PARTS * 2 * S * (9 * BN * 16 + 64);
@@ -383,14 +464,20 @@ static int shell_go(const void* dy, const void* wb, void* d1, int D1, void* d2, 
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)R.start[3], N / BN), dim3(256), lds, st, dy, wb, d1, D1, d2, R, K, N, lo_offset);
+    hipLaunchKernelGGL(kern, dim3((unsigned)R.start[3], N / BN), dim3(256), lds, st, dy, wb, d1, D1, d2, R, K, N, lo_offset, sbuf);
     return tdx_launch_status();
 }
 
 // dx[clamp(p)] += g[p] over the halo shell.  dy: [B][X][Y][Z][K]; wb: the packed data-gradient operand of
 // tdx_conv3_pack_weight for (K -> N); dx split over d1 (N channels [0, D1)) and d2.  mode: SH_BF16 / SH_F32 / SH_SPLIT.
+size_t conv3_shell_buffer_bytes(int B, int X, int Y, int Z, int N) {  // the deterministic route's position buffer
+    const size_t pos = 2 * ((size_t)(X + 2) * (Y + 2) + (size_t)(X + 2) * Z + (size_t)Y * Z) * B;
+    return pos * N * sizeof(float);
+}
+
+// sbuf: nullptr, or conv3_shell_buffer_bytes() of scratch for the deterministic route (TDX_SHELL_DETERMINISTIC=1)
 int conv3_shell_launch(const void* dy, const void* wb, void* d1, int D1, void* d2, int B, int X, int Y, int Z, int K, int N,
-                       int mode, hipStream_t st) {
+                       int mode, hipStream_t st, void* sbuf_) {
     const int E[3] = {X, Y, Z}, str[3] = {Y * Z, Z, 1}, tapw[3] = {9, 3, 1};
     // region r: clamped global axis ax[r][0], in-plane axes ax[r][1], ax[r][2]; in-plane extents include the shell
     // of the axes whose faces come later in the list (so every shell position is owned by exactly one region)
@@ -398,7 +485,7 @@ int conv3_shell_launch(const void* dy, const void* wb, void* d1, int D1, void* d
     static const int wide[3][2] = {{1, 1}, {1, 0}, {0, 0}};
     ShellRegions R;
     R.B = B;
-    int total = 0;
+    int total = 0, prows = 0;
     for (int r = 0; r < 3; ++r) {
         ShellView& v = R.v[r];
         for (int k = 0; k < 3; ++k) { v.E[k] = E[ax[r][k]]; v.st[k] = str[ax[r][k]]; v.ws[k] = tapw[ax[r][k]]; }
@@ -409,8 +496,13 @@ int conv3_shell_launch(const void* dy, const void* wb, void* d1, int D1, void* d
         }
         R.start[r] = total;
         total += B * 2 * v.nb[0] * v.nb[1];
+        R.pstart[r] = prows;
+        prows += B * 2 * v.ext[0] * v.ext[1];
     }
     R.start[3] = total;
+    R.pstart[3] = prows;
+    const char* det_env = getenv("TDX_SHELL_DETERMINISTIC");
+    float* sbuf = (sbuf_ != nullptr && det_env && atoi(det_env) != 0 && (N % 8) == 0) ? (float*)sbuf_ : nullptr;
     const int64_t lo_offset = (int64_t)27 * K * N;
     // 64-wide channel tiles where the launch fills the chip without them; two K slices per iteration (half the
     // barriers, twice the loads in flight: the deep levels walk K = 512 with one or two workgroups per CU) where the
@@ -418,12 +510,22 @@ int conv3_shell_launch(const void* dy, const void* wb, void* d1, int D1, void* d
     const bool wide_n = (N % 64) == 0 && (int64_t)total * (N / 64) >= 1024;
     const int kc2 = (mode == SH_F32 ? 8 : 16) * 2;
     const bool two = (K % kc2) == 0 && !(mode == SH_SPLIT && wide_n);
-#define SH_GO(M, NTV, SV) shell_go<M, NTV, SV>(dy, wb, d1, D1, d2, R, K, N, M == SH_SPLIT ? lo_offset : 0, st)
+#define SH_GO(M, NTV, SV) shell_go<M, NTV, SV>(dy, wb, d1, D1, d2, R, K, N, M == SH_SPLIT ? lo_offset : 0, sbuf, st)
 #define SH_PICK(M) (wide_n ? (two ? SH_GO(M, 2, 2) : SH_GO(M, 2, 1)) : (two ? SH_GO(M, 1, 2) : SH_GO(M, 1, 1)))
-    if (mode == SH_BF16) return SH_PICK(SH_BF16);
-    if (mode == SH_F32) return SH_PICK(SH_F32);
-    if (wide_n) return SH_GO(SH_SPLIT, 2, 1);
-    return two ? SH_GO(SH_SPLIT, 1, 2) : SH_GO(SH_SPLIT, 1, 1);
+    int rc;
+    if (mode == SH_BF16) rc = SH_PICK(SH_BF16);
+    else if (mode == SH_F32) rc = SH_PICK(SH_F32);
+    else if (wide_n) rc = SH_GO(SH_SPLIT, 2, 1);
+    else rc = two ? SH_GO(SH_SPLIT, 1, 2) : SH_GO(SH_SPLIT, 1, 1);
 #undef SH_PICK
 #undef SH_GO
+    if (rc != TDX_OK || sbuf == nullptr) return rc;
+    const int64_t nz = 2 * (int64_t)X * Y, ny = Z > 2 ? 2 * (int64_t)X * (Z - 2) : 0, nx = (Z > 2 && Y > 2) ? 2 * (int64_t)(Y - 2) * (Z - 2) : 0;
+    const int64_t per_sample = (Z == 1 ? nz / 2 : nz) + (Y == 1 ? ny / 2 : ny) + (X == 1 ? nx / 2 : nx);
+    const int64_t threads = (int64_t)B * per_sample * (N / 8);
+    if (mode == SH_BF16)
+        hipLaunchKernelGGL(conv3_shell_fold_kernel<bf16>, dim3(ceil_div(threads, 256)), dim3(256), 0, st, sbuf, (bf16*)d1, D1, (bf16*)d2, R, X, Y, Z, N);
+    else
+        hipLaunchKernelGGL(conv3_shell_fold_kernel<float>, dim3(ceil_div(threads, 256)), dim3(256), 0, st, sbuf, (float*)d1, D1, (float*)d2, R, X, Y, Z, N);
+    return tdx_launch_status();
 }

@@ -158,7 +158,9 @@ int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void* wf, const
  * (tdx_conv3_shell.hip): a voxel on exactly one face gets one read-add-write, edge and corner voxels get up to 7 hardware
  * atomics (global_atomic_pk_add_bf16 / global_atomic_add_f32) in whatever order the workgroups finish, each with its own
  * rounding in the tensor's dtype -- those voxels (1-3 % of the boundary shell) are not bit-reproducible from run to run,
- * in bf16 within 2^-8 relative per add.  Everything else in the library sums in a fixed order.  The small-grid kernels of the
+ * in bf16 within 2^-8 relative per add.  TDX_SHELL_DETERMINISTIC=1 (environment, read per call) replaces the atomics by
+ * a position buffer in `workspace` and a fixed-order fold: bit-identical results, one more small launch per call.
+ * Everything else in the forward / data-gradient path sums in a fixed order (weight-gradient merges use fp32 atomics).  The small-grid kernels of the
  * deep levels and impl = TDX_CONV_DIRECT are deterministic throughout. */
 size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z, int Cin, int dtype, int impl);
 int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2, int accumulate,

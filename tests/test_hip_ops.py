@@ -853,6 +853,53 @@ def test_conv3_small_grid_kernel_vs_brick_kernels(case, mode, monkeypatch):
         assert rel_l2(gx.permute(0, 4, 1, 2, 3), xr.grad) < (1e-2 if mode == "bf16" else 5e-5)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f32", "f32s"])
+@pytest.mark.parametrize("case", [(2, 32, 0, 64, (24, 16, 8)), (1, 32, 32, 32, (9, 10, 7)), (2, 64, 0, 32, (1, 5, 4)),
+                                  (1, 32, 0, 32, (16, 2, 16))])
+def test_conv3_data_gradient_deterministic_shell_route(case, mode, monkeypatch):
+    """TDX_SHELL_DETERMINISTIC=1: the halo-shell term goes through one fp32 row per shell position and a fixed-order fold
+    (tdx_conv3_shell.hip) instead of atomics on edge and corner voxels.  The data gradient must be bit-identical from run to
+    run, agree with the default (atomics) route to rounding noise and with the fp64 oracle (adjoint of the replicate-padded
+    conv) -- incl. grids one and two voxels thick, where both faces of an axis fold onto the same plane -- and the
+    workspace query must cover the position buffer."""
+    import torch.nn.functional as F
+
+    from turbdiff_amd import _lib as L, ops
+
+    B, C1, C2, Co, (X, Y, Z) = case
+    d = dev()
+    Ci = C1 + C2
+    dt = torch.bfloat16 if mode == "bf16" else torch.float32
+    monkeypatch.setenv("TDX_CONV_IMPL", "split" if mode == "f32s" else "auto")
+    monkeypatch.setenv("TDX_CONV3_SMALL_ROWS", "1")  # keep the small-grid kernels (no shell launch) out of the way
+    gen = torch.Generator().manual_seed(7)
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=gen) / (27 * Ci) ** 0.5
+    gy = q(torch.randn(B, Co, X, Y, Z, generator=gen), dt)
+    x1 = torch.zeros(B, X, Y, Z, C1, device=d, dtype=dt, requires_grad=True)
+    x2 = torch.zeros(B, X, Y, Z, C2, device=d, dtype=dt, requires_grad=True) if C2 else None
+    wd = w.to(d)
+
+    def grad():
+        y = ops.conv3(x1, wd, None, x2=x2)
+        g = torch.autograd.grad(y, [x1] + ([x2] if C2 else []), nvc(gy).to(d).to(dt))
+        return torch.cat([t.float() for t in g], dim=-1).cpu()
+
+    base = grad()
+    monkeypatch.setenv("TDX_SHELL_DETERMINISTIC", "1")
+    a, b = grad(), grad()
+    assert torch.equal(a, b)
+    # oracle: adjoint of y = conv3(replicate_pad(x)) in fp64 (the conv is linear, so x = 0 is as good a point as any)
+    xr = torch.zeros(B, Ci, X, Y, Z, dtype=torch.float64, requires_grad=True)
+    wr = (q(w, dt) if mode == "bf16" else w).double()
+    F.conv3d(F.pad(xr, (1,) * 6, mode="replicate"), wr).backward(gy.double())
+    ref = nvc(xr.grad.float())
+    tol = 4e-3 if mode == "bf16" else (2e-5 if mode == "f32s" else 2e-6)
+    assert rel_l2(a, ref) < tol and rel_l2(base, ref) < tol
+    assert rel_l2(a, base) < (4e-3 if mode == "bf16" else 1e-6)
+    ws = L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, Ci, L.dtype_code(dt), L.conv_impl())
+    assert ws >= 2 * ((X + 2) * (Y + 2) + (X + 2) * Z + Y * Z) * B * Ci * 4
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [
     # B, C1, C2, Cout, grid: whole 8 x 8 x 8 bricks; one brick per workgroup ... nine per workgroup; one K slice (the composed

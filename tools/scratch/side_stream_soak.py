@@ -12,8 +12,9 @@ for sw in ("0", "0", "1", "1"):
     os.environ["TDX_WGRAD_STREAM"] = sw
     l, dt, mem = S.run("bf16", steps)
     runs.append((sw, l))
-    print(f"TDX_WGRAD_STREAM={sw}: {dt:.2f} ms/step, peak {mem:.1f} GB, loss at 0/100/200/300/{steps - 1}: "
-          + " ".join(f"{l[i]:.4f}" for i in (0, 100, 200, 300, steps - 1)), flush=True)
+    marks = [i for i in (0, 100, 200, 300) if i < steps - 1] + [steps - 1]
+    print(f"TDX_WGRAD_STREAM={sw}: {dt:.2f} ms/step, peak {mem:.1f} GB, loss at {'/'.join(map(str, marks))}: "
+          + " ".join(f"{l[i]:.4f}" for i in marks), flush=True)
 smooth = lambda l: [sum(l[i:i + 20]) / 20 for i in range(0, len(l) - 20)]
 dev = lambda u, v: max(abs(a - b) / abs(a) for a, b in zip(smooth(u), smooth(v)))
 print(f"largest relative deviation of the 20-step mean loss: launching stream run-to-run {dev(runs[0][1], runs[1][1]):.2e}; "
