@@ -1,7 +1,9 @@
 #!/bin/bash
 # Round-3 evidence (GPU box: bash tools/r10_profiles.sh): rocprofv3 stats + PMC passes of the bench command in the bf16 and
-# f32s modes (tools/collect_profiles.sh -> gpurun_out/prof_r10*), the config-5 attention profile with fp16 operands, the
-# per-layer conv table, and two bench.py lines (default flags; driver-style --steps 20 --warmup 5).
+# f32s modes (tools/collect_profiles.sh -> gpurun_out/prof_r10*; the weight gradients on the launching stream there, so that
+# every kernel's duration and counters are its own), the config-5 attention profile with fp16 operands, the per-layer conv
+# table, and two bench.py lines (default flags; --steps 20 --warmup 5 without the CPU / parity / PyTorch legs).
+# Summaries: python tools/summarize_profiles.py r10bf16 (and r10f32s) -> profiles/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/r10p; mkdir -p $O
 cd $R
 bash tools/collect_profiles.sh r10bf16 > $O/collect_bf16.log 2>&1
