@@ -266,3 +266,29 @@ def test_trainer_from_config_accepts_the_model_group_and_overrides():
     assert task.compute_mode == "f32" and task.gradient_clip_val == 0.5 and str(task.data_dir) == "d/data"
     with pytest.raises(ValueError):
         DiffusionTrainer.from_config(dict(model, name="tfnet"))
+
+
+def test_profiles_index_names_existing_files():
+    """profiles/README.md is the index the design document's round-3 citations go through: every r10 file it names exists,
+    and the traffic file bench.py's roofline block reads carries launches of the forward kernels it filters for."""
+    import json
+    import re
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    text = (root / "profiles" / "README.md").read_text()
+    names = set(re.findall(r"`(r10[\w]*\.(?:json|txt|md|csv))`", text))
+    assert len(names) >= 12
+    missing = sorted(n for n in names if not (root / "profiles" / n).exists())
+    assert not missing, missing
+    for stem in ("r10bf16", "r10f32s"):
+        for suffix in ("_summary.md", "_kernel_stats.csv", "_traffic.json"):
+            assert (root / "profiles" / (stem + suffix)).exists()
+    sys.path.insert(0, str(root))
+    import bench
+
+    bytes_per_launch, src, n = bench.measured_traffic("bf16")
+    assert src == "profiles/r10bf16_traffic.json" and n >= 60 and bytes_per_launch > 1e8
+    kernels = json.loads((root / src).read_text())["kernels"]
+    assert any("conv3_ring_kernel<2, false" in k for k in kernels)
