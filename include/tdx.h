@@ -417,7 +417,10 @@ int tdx_film_bwd(const float* c, int B, int T, const TdxFilmGrad* layers, int n,
  *     out[b, i, :] = bias + sum_t in[b, (i + pad - t*dilation)/stride, :] @ w[t]   where divisible and in range.
  * The data gradient of a REPLICATE-padded conv (stride 1) is the transposed form evaluated on the padded grid
  * (out grid = E + 2 pad, pad argument 0 ... see turbdiff_amd/ops.py) followed by tdx_convg_fold_clamp, which adds every
- * padded position onto the voxel it clamps to.  Cin % 8 == Cout % 8 == 0. */
+ * padded position onto the voxel it clamps to.  Cin % 8 == Cout % 8 == 0.
+ * Arithmetic: fp32 tensors run on the vector ALU with fp32 weights; bf16 tensors (TDX_BF16) run on the matrix cores
+ * (tdx_convg_mfma.hip) -- the fp32 weights are rounded to bf16 on their way into LDS, products accumulate in fp32, the
+ * result is stored as bf16; TDX_CONVG_MFMA=0 (environment, read per call) keeps bf16 tensors on the vector-ALU kernels. */
 int tdx_convg_apply(const void* in, const float* w, const float* bias, void* out, int B, int Xi, int Yi, int Zi, int Cin,
                     int Xo, int Yo, int Zo, int Cout, int k, int stride, int dilation, int pad, int replicate,
                     int transposed, int dtype, void* stream);
