@@ -423,7 +423,10 @@ def main():
         "config": {"workload": "BASELINE configs[1]: turbdiff U-Net dim32 x 4 levels GN(8), 192x64x48 (u,p), "
                                "DDPM train step (fwd+bwd+clip+RAdam)", "per_gpu_batch": B, "global_batch": B * world,
                    "grid": list(GRID), "timesteps": 500, "parallelism": f"dp{world}",
-                   "optimizer": "ClipRAdam (fused clip 0.1 + RAdam)" if fused_opt else "clip_grad_norm_ + torch.optim.RAdam"},
+                   "optimizer": "ClipRAdam (fused clip 0.1 + RAdam)" if fused_opt else "clip_grad_norm_ + torch.optim.RAdam",
+                   # what was switched away from the defaults through the environment (INTEGRATION.md lists the switches)
+                   "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("TDX_") and not k.startswith("TDX_BENCH_")},
+                   "weight_gradients_on_side_stream": os.environ.get("TDX_WGRAD_STREAM", "1") != "0"},
         "loss": last_loss,
     }
     if rank == 0:
