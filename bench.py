@@ -18,7 +18,10 @@ Inputs are resident in HBM before the timed region.  One JSON line is printed by
                parity_modes  the same step in the modes that meet north_star's 1e-4 gate (f32s: fp32 tensors +
                              split-precision convs; f32: IEEE fp32 MFMA convs), each with its own roofline block
                fwd-only and sampling legs (DDPM samples/s: >= 50 reverse steps timed; the full T = 1000 loop
-               when --steps >= 20); N > 1: overlap report of the gradient all-reduce and the sharded
+               when --steps >= 20; the public p_sample_loop: graph vs eager, and the reference's B = 1 protocol);
+               cfg1: BASELINE configs[0] (48x32x32, 2 levels, T = 10) on the GPU and on the CPU oracle;
+               real_grid: the dataset's 194x50x50 grid at the reference batch (bf16, f32s);
+               N > 1: overlap report of the gradient all-reduce and the sharded
                sampling leg of BASELINE configs[3] (8 trajectories per GPU)
 """
 
@@ -180,12 +183,19 @@ FWD_KERNEL_PATTERNS = {
 
 def measured_traffic(mode="bf16"):
     """HBM bytes per launch of the mode's forward brick / ring conv kernels from the committed rocprofv3 PMC passes
-    (profiles/*_traffic.json, produced by tools/collect_profiles.sh at B = 6): the newest file that holds launches of
-    those kernels; (None, None, 0) if there is none.  Same launches as roofline.algorithmic_bytes_per_launch: the forward
-    conv calls served by the brick / ring kernels (the deep levels' small-grid launches are a different kernel)."""
+    (profiles/*_traffic.json, produced by tools/collect_profiles.sh + summarize_profiles.py at B = 6): the newest file that
+    holds launches of those kernels AND was collected on the conv kernels of this tree (its `kernel_sources_sha16` equals
+    the fingerprint of csrc/tdx_conv*; a file that describes older kernels is refused and named under `refused`).
+    -> (bytes per launch | None, {file, git_head, ...}, launches sampled).  Same launches as
+    roofline.algorithmic_bytes_per_launch: the forward conv calls served by the brick / ring kernels (the deep levels'
+    small-grid launches are a different kernel)."""
     import re
 
+    from turbdiff_amd._lib import kernel_sources_fingerprint
+
     pat = FWD_KERNEL_PATTERNS[mode]
+    now = kernel_sources_fingerprint()
+    refused = []
     for f in sorted((ROOT / "profiles").glob("*_traffic.json"), reverse=True):  # rNN tags: newest round first
         data = json.loads(f.read_text())
         num = den = 0.0
@@ -194,9 +204,15 @@ def measured_traffic(mode="bf16"):
                 n = k["launches_sampled"]
                 num += n * (k["read_bytes_per_launch"] + k["write_bytes_per_launch"])
                 den += n
-        if den:
-            return num / den, f"profiles/{f.name}", int(den)
-    return None, None, 0
+        if not den:
+            continue
+        if data.get("kernel_sources_sha16") != now:
+            refused.append({"file": f"profiles/{f.name}", "git_head": data.get("git_head"),
+                            "why": "collected on other conv-kernel sources than this tree's"})
+            continue
+        return num / den, {"file": f"profiles/{f.name}", "git_head": data.get("git_head"),
+                           "kernel_sources_sha16": now, "side_stream": data.get("side_stream")}, int(den)
+    return None, {"file": None, "kernel_sources_sha16": now, "refused": refused[:3]}, 0
 
 
 CONV_CALLS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add", "tdx_conv3_bwd_weight"}
@@ -249,6 +265,120 @@ def roofline_block(timer, mode, B, K):
 def kernel_table(kern, K):
     return {k: {"launches": v["launches"], "ms_per_step": v["ms"] / K, "tflops": v["work"] / max(v["ms"], 1e-9) / 1e9}
             for k, v in kern.items()}
+
+
+def timed_train_steps(diff, x, C, md, mode, steps, warmup):
+    """ms per training step (fwd + bwd + clip 0.1 + RAdam) of `diff` on (x, C, md) in `mode`, single rank."""
+    from turbdiff_amd.optim import ClipRAdam
+
+    set_mode(diff, mode)
+    opt = ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1)
+
+    def step():
+        loss, _ = diff(x, C, md, None)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps
+
+
+CFG1_GRID = (48, 32, 32)
+
+
+def new_cfg1_denoiser():
+    """BASELINE configs[0] / SURVEY 8(d) cfg1: 2-level U-Net, dim 32, T = 10."""
+    from turbdiff_amd.models.ddpm import DenoisingModel
+
+    torch.manual_seed(0)
+    return DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=10, dim=32,
+                          u_net_levels=2, norm_type="group")
+
+
+def cfg1_leg(dev, with_cpu):
+    """north_star's second volume: one 48x32x32x4 synthetic volume through the 2-level U-Net -- training step and the
+    10-step DDPM loop (the public p_sample_loop) per mode on the GPU, and the CPU oracle (the reference's own
+    CPU-runnable case) beside it."""
+    from turbdiff_amd.models.conditioning import Conditioning
+    from turbdiff_amd.models.ddpm import GaussianDiffusion
+
+    W, H, D = CFG1_GRID
+    v1 = W * H * D
+    res = {"workload": "BASELINE configs[0]: one 48x32x32 (u,p) volume, 2-level U-Net dim 32 GN(8), T = 10, B = 1", "modes": {}}
+    diff = GaussianDiffusion(new_cfg1_denoiser(), timesteps=10, beta_schedule="log-snr-linear", loss_type="l2",
+                             noise_bcs=True).to(dev)
+    x, c, cell_idx = synthetic_inputs(1, dev, CFG1_GRID)
+    C, md = {Conditioning.Type.CELL_TYPE: c}, SimpleNamespace(cell_idx=cell_idx)
+    sd0 = {k: v.detach().cpu().clone() for k, v in diff.model.state_dict().items()}
+    for mode in ("bf16", "f32s", "f32"):
+        diff.model.load_state_dict(sd0)
+        ms = timed_train_steps(diff, x, C, md, mode, 20, 5)
+        diff.p_sample_loop(x, C, cell_idx)  # capture
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            diff.p_sample_loop(x, C, cell_idx)
+        torch.cuda.synchronize()
+        loop_s = (time.perf_counter() - t0) / 5
+        res["modes"][mode] = {"ms_per_step": ms, "voxels_per_s": v1 / (ms * 1e-3), "sample_loop_ms": 1e3 * loop_s,
+                              "ddpm_samples_per_s_T10": 1.0 / loop_s}
+    if with_cpu:
+        from oracle import turbdiff_oracle as O
+
+        nth = torch.get_num_threads()
+        torch.set_num_threads(min(8, nth))
+        sd = {k: v.clone().requires_grad_() for k, v in sd0.items()}
+        buf = O.schedule_buffers("log-snr-linear", 10)
+        xc, cc, ic = x.cpu(), c.cpu(), cell_idx.cpu()
+        noise = torch.randn(xc.shape, generator=torch.Generator().manual_seed(1))
+        t = torch.tensor([5])
+        times = []
+        for it in range(4):
+            t0 = time.perf_counter()
+            loss, _ = O.p_losses(sd, buf, xc, t, cc, ic, noise, timesteps=10, noise_bcs=True)
+            torch.autograd.grad(loss, list(sd.values()))
+            if it:
+                times.append(time.perf_counter() - t0)
+        med = sorted(times)[len(times) // 2]
+        gen = torch.Generator().manual_seed(2)
+        with torch.no_grad():
+            sdn = {k: v.detach() for k, v in sd.items()}
+            t0 = time.perf_counter()
+            O.p_sample_loop(sdn, buf, xc, cc, ic, (torch.randn(xc.shape, generator=gen) for _ in range(64)), timesteps=10,
+                            noise_bcs=True)
+            loop = time.perf_counter() - t0
+        torch.set_num_threads(nth)
+        res["cpu_oracle"] = {"threads": min(8, nth), "s_per_step_fwd_bwd": med, "voxels_per_s": v1 / med,
+                             "sample_loop_s": loop, "ddpm_samples_per_s_T10": 1.0 / loop,
+                             "note": "CPU oracle (PyTorch-CPU port of the reference math, fp32): median of 3 fwd+bwd after 1 "
+                                     "warm-up; one 10-step loop"}
+    return res
+
+
+REAL_GRID = (194, 50, 50)  # the dataset's grid (reference scripts/grid-embedding.py:69)
+
+
+def real_grid_leg(dev, B):
+    """The full 4-level dim-32 U-Net on the reference's real grid 194x50x50 (every axis ragged against the 8x8x8 bricks,
+    every level down to 24x6x6 ragged): ms per training step at the reference batch in bf16 and f32s."""
+    from turbdiff_amd.models.conditioning import Conditioning
+
+    diff = build_model(dev)
+    x, c, cell_idx = synthetic_inputs(B, dev, REAL_GRID)
+    C, md = {Conditioning.Type.CELL_TYPE: c}, SimpleNamespace(cell_idx=cell_idx)
+    vr = REAL_GRID[0] * REAL_GRID[1] * REAL_GRID[2]
+    res = {"grid": list(REAL_GRID), "batch": B, "modes": {}}
+    for mode, k, w in (("bf16", 10, 3), ("f32s", 5, 2)):
+        ms = timed_train_steps(diff, x, C, md, mode, k, w)
+        res["modes"][mode] = {"ms_per_step": ms, "voxels_per_s": B * vr / (ms * 1e-3), "steps": k}
+    return res
 
 
 def self_launch(n):
@@ -530,8 +660,46 @@ def main():
                                  "ddpm_samples_per_s_T1000": Bs * world / (per_step * T),
                                  "ddpm_samples_per_s_T500": Bs * world / (per_step * 500),
                                  "note": "whole-job aggregate; per-step time x T" + ("" if full else " (extrapolated from the timed steps)")}
-            del sampler, sdiff
+            del sampler
+            if world == 1:
+                # the PUBLIC method (what DiffusionTraining.sample / eval_ckpt.py / a dropin user call, reference
+                # diffusion.py:152-158): graph path vs the eager loop (TDX_GRAPH_SAMPLER=0), 30 reverse steps each via
+                # start_from; and the reference's own timing protocol (scripts/evaluate-runtime.py:54-96: B = 1, sync,
+                # wall clock around one full sample()) on the full T = 1000 loop
+                import turbdiff_amd.models.ddpm as D
+
+                def public_loop(xb, start):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    sdiff.p_sample_loop(xb, C, cell_idx, start_from=start)
+                    torch.cuda.synchronize()
+                    return time.perf_counter() - t0
+
+                public_loop(xs, 3)  # capture
+                g_ms = 1e3 * public_loop(xs, 30) / 30
+                D.GRAPH_SAMPLER = False
+                public_loop(xs, 3)
+                e_ms = 1e3 * public_loop(xs, 30) / 30
+                D.GRAPH_SAMPLER = True
+                x1 = xs[:1].contiguous()
+                public_loop(x1, 3)  # capture at B = 1
+                full_s = public_loop(x1, None) if full else None
+                b1_ms = 1e3 * public_loop(x1, 50) / 50
+                extra["sampling"]["public_p_sample_loop"] = {
+                    "graph_ms_per_step": g_ms, "eager_ms_per_step": e_ms, "batch": Bs, "reverse_steps_timed": 30,
+                    "measure_sample_time_B1_s": full_s, "B1_ms_per_reverse_step": b1_ms,
+                    "note": "GaussianDiffusion.p_sample_loop as the callers reach it; B = 1 full T = 1000 sample = the "
+                            "reference's evaluate-runtime.py protocol" + ("" if full else " (full loop only with --steps >= 20)")}
+            del sdiff
         leg_done("forward_and_sampling")
+        if world == 1:
+            extra["cfg1"] = cfg1_leg(dev, with_cpu=not args.no_cpu_baseline)
+            leg_done("cfg1_48x32x32")
+            extra["real_grid"] = real_grid_leg(dev, B)
+            extra["real_grid"]["per_voxel_vs_headline"] = (
+                extra["real_grid"]["modes"]["bf16"]["ms_per_step"] / (REAL_GRID[0] * REAL_GRID[1] * REAL_GRID[2])
+                / (out["ms_per_step"] / V)) if args.dtype == "bf16" else None
+            leg_done("real_grid_194x50x50")
     if extra:
         out["extra"] = extra
 

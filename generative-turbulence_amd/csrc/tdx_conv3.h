@@ -45,10 +45,14 @@ struct Conv3Ext {
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                       const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr,
                       void* d1 = nullptr, int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr,
-                      const void* a2 = nullptr, const Conv3Ext* ext = nullptr);
+                      const void* a2 = nullptr, const Conv3Ext* ext = nullptr, const int* slabs_beyond = nullptr);
+// slabs_beyond = {mx, my, mz}: another kernel has computed the region [0, mx) x [0, my) x [0, mz) of the output; launch
+// only the thin-brick kernel on the remainder slabs beyond it (1-2 voxels thick per axis).
 
-// persistent LDS-DMA ring kernel (tdx_conv3_ring.hip; bf16): forward or main term of the data gradient on grids of whole
-// 8 x 8 x 8 bricks that fill the chip; TDX_ESHAPE = not such a case, take conv3_mfma_launch (results are bit-identical)
+// persistent LDS-DMA ring kernel (tdx_conv3_ring.hip; bf16): forward or main term of the data gradient on grids whose
+// whole 8 x 8 x 8 bricks fill the chip and leave remainders of at most 2 voxels per axis (those go to the thin-brick kernel
+// of tdx_conv3_mfma.hip in a second launch: the reference's 194 x 50 x 50 and its 97 x 25 x 25 level); TDX_ESHAPE = not such a case, take conv3_mfma_launch (results equal up to the
+// fp32 summation order: ~1 bf16 ulp on a few % of the elements)
 bool conv3_ring_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z);
 int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y, int B, int X,
                       int Y, int Z, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr, void* d1 = nullptr,
@@ -69,6 +73,10 @@ int conv3_wgrad_small_launch(const void* x1, int C1, const void* x2, int C2, con
 // waves per workgroup); same contract as conv3_wgrad_mfma_launch, TDX_ESHAPE = not a case for it
 int conv3_wgrad_ring_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias, int B, int X,
                             int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out);
+// CUs the persistent one-workgroup-per-CU kernels (ring conv, producer / consumer weight gradient) may occupy:
+// TDX_PERSISTENT_CUS in the environment (read per call), a multiple of 8 in [8, 256], default 256.  A data-parallel run
+// sets it below 256 to leave CUs to RCCL's kernels.
+int tdx_persistent_cus();
 // the caller-provided scratch arena (tdx_set_scratch, include/tdx.h); nullptr if none
 void* tdx_scratch_ptr();
 size_t tdx_scratch_bytes();

@@ -10,6 +10,7 @@
 // grid Xi+2 with off = -1 and the halo is folded back onto the boundary afterwards).
 #include "tdx_common.h"
 #include "tdx_conv3.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------ weight packing -------
 // element index of operand (tap, k, n) for a conv with K input / N output channels
@@ -540,12 +541,18 @@ conv3_wgrad_direct_kernel(const T* __restrict__ x1, int C1, const T* __restrict_
 // ------------------------------------------------------------------ scratch arena --------
 // caller-provided transient workspace of kernels whose entry points have no argument for one (the K-split slabs of
 // the small-grid conv, tdx_conv3_small.hip).  The first 64 bytes must be zero and stay zero.
+int tdx_persistent_cus() {
+    const char* env = getenv("TDX_PERSISTENT_CUS");
+    int n = env ? atoi(env) : 256;
+    n = n < 8 ? 8 : (n > 256 ? 256 : n);
+    return n & ~7;
+}
 static void* g_scratch = nullptr;
 static size_t g_scratch_bytes = 0;
 void* tdx_scratch_ptr() { return g_scratch; }
 size_t tdx_scratch_bytes() { return g_scratch_bytes; }
 extern "C" int tdx_set_scratch(void* ptr, size_t bytes) {
-    if (ptr != nullptr && bytes < ((size_t)1 << 20)) return TDX_EINVAL;
+    if (ptr != nullptr && bytes < 64) return TDX_EINVAL;  // at least the zero block
     g_scratch = ptr;
     g_scratch_bytes = ptr ? bytes : 0;
     return TDX_OK;
@@ -578,7 +585,8 @@ extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, con
         int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false,
                                     false, as_stream(stream));
         if (rs != TDX_ESHAPE) return rs;
-        // the two finest levels: persistent LDS-DMA ring kernel (same arithmetic, bit for bit)
+        // the two finest levels: persistent LDS-DMA ring kernel (same products, fp32 sums in another order: equal to the brick
+        // kernel up to ~1 bf16 ulp on a few % of the elements, tdx_conv3_ring.hip)
         rs = conv3_ring_launch(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, false, as_stream(stream));
         if (rs != TDX_ESHAPE) return rs;
         return conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));

@@ -389,7 +389,7 @@ static int launch_view(const void* x1, int C1, const void* x2, int C2, const voi
 
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                       const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1,
-                      void* d2, const void* a1, const void* a2, const Conv3Ext* ext) {
+                      void* d2, const void* a1, const void* a2, const Conv3Ext* ext, const int* slabs_beyond) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const void* init = ext ? ext->init : nullptr;
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
@@ -410,6 +410,11 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
         const int rem = Eo[a] % bdim[a];
         thin[a] = !no_thin && rem >= 1 && rem <= 2 && Eo[a] > bdim[a] && big && ext == nullptr;
         main_end[a] = thin[a] ? Eo[a] - rem : Eo[a];
+        if (slabs_beyond != nullptr) {  // the main region is somebody else's (the ring kernel's): only what lies beyond it
+            if (ext != nullptr || slabs_beyond[a] <= 0 || Eo[a] - slabs_beyond[a] > 2 || Eo[a] < slabs_beyond[a]) return TDX_ESHAPE;
+            main_end[a] = slabs_beyond[a];
+            thin[a] = main_end[a] < Eo[a];
+        }
     }
     // view of region [lo, hi) (global output coordinates) with local axis k = global axis perm[k];
     // returns the number of bricks (0: empty region)
@@ -470,7 +475,7 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
     const int nmain = make_view(best, lo, hi, false, mainv.v[0]);
     mainv.v[1] = mainv.v[2] = mainv.v[0];
     mainv.start[0] = 0; mainv.start[1] = mainv.start[2] = mainv.start[3] = nmain;
-    int rc = launch(mainv, false, !(best[0] == 0 && best[1] == 1 && best[2] == 2));
+    int rc = slabs_beyond ? TDX_OK : launch(mainv, false, !(best[0] == 0 && best[1] == 1 && best[2] == 2));
     if (rc != TDX_OK) return rc;
     // remainder slabs, all in ONE launch of the thin-brick kernel (each has too few workgroups to
     // fill the chip alone):

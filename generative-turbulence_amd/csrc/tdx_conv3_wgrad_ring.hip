@@ -27,6 +27,7 @@
 #include "tdx_common.h"
 #include "tdx_conv3.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -71,7 +72,7 @@ __device__ __forceinline__ bf16x8 wr_tr_frag(const unsigned char* lo, const unsi
 // one LDS-DMA instruction (inline assembly: see tdx_conv3_ring.hip)
 __device__ __forceinline__ void wr_dma(const void* gsrc, unsigned lds) {
     lds = __builtin_amdgcn_readfirstlane(lds);
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
 }
 __device__ __forceinline__ void wr_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -310,7 +311,8 @@ int conv3_wgrad_ring_launch(const void* x1, int C1, const void* x2, int C2, cons
     const int nbricks = B * g.nb[0] * g.nb[1] * g.nb[2];
     const int n_ci = (Cin + 31) / 32, n_co = Cout / 64;
     const int ntiles = n_ci * n_co;
-    int nsplit = (256 + ntiles - 1) / ntiles;  // one workgroup per CU
+    const int cus = tdx_persistent_cus();
+    int nsplit = cus >= 256 ? (256 + ntiles - 1) / ntiles : std::max(cus / ntiles, 1);  // one workgroup per CU (at most `cus`)
     if (nsplit > nbricks) nsplit = nbricks;
     if (nsplit < 1) nsplit = 1;
     // a workgroup should walk several bricks, or the double buffering has nothing to overlap

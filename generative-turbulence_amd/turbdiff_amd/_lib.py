@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from pathlib import Path
 
 import torch
@@ -130,11 +131,24 @@ def load() -> C.CDLL:
     return _lib
 
 
-_SCRATCH = {}  # (device index, stream handle) -> arena tensor (kept alive for the life of the process); "active" -> key
+_SCRATCH: "OrderedDict" = None  # (device index, stream handle) -> arena tensor, least recently bound first
+_ACTIVE = None  # key of the arena the library currently points at
 SCRATCH_BYTES = int(os.environ.get("TDX_SCRATCH_MB", "96")) << 20
+SCRATCH_SMALL_BYTES = 4096  # streams that only need the zero block at the arena's head (the weight-gradient side stream)
+SCRATCH_MAX_ARENAS = int(os.environ.get("TDX_SCRATCH_MAX_ARENAS", "6"))
 # entry points that may use the arena (K-split slabs of the small-grid kernels, the zero block of the DMA kernels)
 ARENA_USERS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_fwd_partial", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add",
                "tdx_conv3_bwd_weight"}
+# bind + launch of an arena user is one critical section: the library keeps ONE arena pointer per process and ctypes
+# releases the GIL during a foreign call, so a second launching thread could otherwise re-bind between the two
+_LAUNCH_LOCK = threading.RLock()
+_SMALL_STREAMS = set()  # (device index, stream handle) of streams declared zero-block-only
+
+
+def declare_zero_block_only(stream) -> None:
+    """The given torch stream will only launch arena users that read the 16-byte zero block (tdx_conv3_bwd_weight):
+    it gets a 4-KiB arena instead of TDX_SCRATCH_MB."""
+    _SMALL_STREAMS.add((stream.device.index, stream.cuda_stream))
 
 
 def ensure_scratch(device=None) -> None:
@@ -142,31 +156,44 @@ def ensure_scratch(device=None) -> None:
     small-grid conv kernels on the deep U-Net levels, zero block of the LDS-DMA kernels.  The library keeps ONE arena
     pointer per process and its kernels get it as a launch argument, so the binding is per launch: every stream that
     launches convs owns its own arena (a hipGraph captured on a side stream keeps replaying on that stream's arena while
-    eager work on another stream uses another: no sharing, no race), and `call` re-binds whenever the launching stream
-    changes.  TDX_SCRATCH_MB=0: no arena (those layers then run on the brick kernels)."""
+    eager work on another stream uses another), and `call` re-binds whenever the launching stream changes.  At most
+    TDX_SCRATCH_MAX_ARENAS arenas are kept (least recently bound dropped first; whoever captured a graph on an arena
+    holds its tensor -- `scratch_arena()` -- so a dropped arena stays allocated while its graph lives; torch's pooled
+    stream handles wrap around after 32 streams, which is why long-lived users keep ONE stream instead of making new ones).
+    TDX_SCRATCH_MB=0: no arena (those layers then run on the brick kernels)."""
+    global _SCRATCH, _ACTIVE
+    if _SCRATCH is None:
+        from collections import OrderedDict
+
+        _SCRATCH = OrderedDict()
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
     key = (idx, torch.cuda.current_stream(idx).cuda_stream)
-    if _SCRATCH.get("active") == key:
+    if _ACTIVE == key:
         return
     if SCRATCH_BYTES <= 0:
         load().tdx_set_scratch(None, 0)
-        _SCRATCH["active"] = key
+        _ACTIVE = key
         return
     buf = _SCRATCH.get(key)
     if buf is None:
+        nbytes = SCRATCH_SMALL_BYTES if key in _SMALL_STREAMS else SCRATCH_BYTES
         with torch.cuda.device(idx):
-            buf = _SCRATCH[key] = torch.zeros(SCRATCH_BYTES, dtype=torch.uint8, device=torch.device("cuda", idx))
+            buf = _SCRATCH[key] = torch.zeros(nbytes, dtype=torch.uint8, device=torch.device("cuda", idx))
+        while len(_SCRATCH) > SCRATCH_MAX_ARENAS:
+            _SCRATCH.popitem(last=False)
+    else:
+        _SCRATCH.move_to_end(key)
     rc = load().tdx_set_scratch(buf.data_ptr(), buf.numel())
     if rc != 0:
         raise RuntimeError(f"tdx_set_scratch failed: {rc}")
-    _SCRATCH["active"] = key
+    _ACTIVE = key
 
 
 def scratch_arena(device=None):
-    """The arena tensor bound to (`device`, current stream), or None (tests)."""
+    """The arena tensor bound to (`device`, current stream), or None.  A graph captured on this stream must hold it."""
     ensure_scratch(device)
-    return _SCRATCH.get(_SCRATCH["active"])
+    return _SCRATCH.get(_ACTIVE) if _SCRATCH is not None else None
 
 
 def dtype_code(dt: torch.dtype) -> int:
@@ -240,9 +267,6 @@ def ptr(t: torch.Tensor | None):
         raise RuntimeError("tdx kernels need device tensors (no CPU path exists in the product)")
     if not t.is_contiguous():
         raise RuntimeError("tdx kernels need contiguous tensors")
-    act = _SCRATCH.get("active")
-    if act is None or act[0] != t.device.index:
-        ensure_scratch(t.device)
     return t.data_ptr()
 
 
@@ -284,7 +308,16 @@ TIMER: KernelTimer | None = None
 def call(name: str, *args, work: float = 0.0, meta=None):
     """meta: None, a dict, or a zero-argument callable returning one (evaluated only while a timer is attached)."""
     if name in ARENA_USERS:
-        ensure_scratch()  # the arena of the launching stream
+        with _LAUNCH_LOCK:
+            ensure_scratch()  # the arena of the launching stream
+            rc = _launch(name, args, work, meta)
+    else:
+        rc = _launch(name, args, work, meta)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, f'hipError {rc}')}")
+
+
+def _launch(name, args, work, meta):
     t = TIMER
     if t is not None and name in t.names:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -292,14 +325,29 @@ def call(name: str, *args, work: float = 0.0, meta=None):
         rc = getattr(load(), name)(*args)
         e.record()
         t.records.append((name, s, e, work, meta() if callable(meta) else meta))
-    else:
-        rc = getattr(load(), name)(*args)
-    if rc != 0:
-        raise RuntimeError(f"{name} failed: {_ERR.get(rc, f'hipError {rc}')}")
+        return rc
+    return getattr(load(), name)(*args)
 
 
 def query(name: str, *args) -> int:
     return int(getattr(load(), name)(*args))
+
+
+def kernel_sources_fingerprint(pattern: str = "tdx_conv*") -> str | None:
+    """sha256 (16 hex digits) over the conv kernels' sources next to the library (csrc/tdx_conv*.hip|h, in name order):
+    what a committed profile describes.  tools/summarize_profiles.py stores it in profiles/*_traffic.json and bench.py
+    quotes `roofline.traffic` only from a file whose fingerprint equals the tree's."""
+    import hashlib
+
+    src = _HERE.parent / "csrc"
+    files = sorted(f for f in src.glob(pattern) if f.suffix in (".hip", ".h"))
+    if not files:
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 KERNEL_DIRECT, KERNEL_BRICK, KERNEL_SMALL, KERNEL_RING = 0, 1, 2, 3  # TDX_KERNEL_* (tdx_conv3_fwd_kernel)

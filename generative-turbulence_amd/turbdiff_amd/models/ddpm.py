@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from dataclasses import dataclass
 from functools import partial
 
@@ -525,6 +526,10 @@ def batch_mean(x: torch.Tensor):
 # --------------------------------------------------------------------------- the diffusion
 
 
+GRAPH_SAMPLER = os.environ.get("TDX_GRAPH_SAMPLER", "1") != "0"
+_SAMPLERS = weakref.WeakKeyDictionary()  # GaussianDiffusion -> its GraphSampler (kept off the module: not copyable)
+
+
 class GaussianDiffusion(nn.Module):
     """DDPM training loss and ancestral sampler around a DenoisingModel
     (reference ddpm.py:620-882).
@@ -613,11 +618,40 @@ class GaussianDiffusion(nn.Module):
         return pred.mean, pred.log_var
 
     @torch.no_grad()
-    def p_sample_loop(self, x_bcs, C, cell_idx, pbar=False, start_from: int | None = None, noise_fn=None):
-        """Ancestral sampling.  Noise is drawn in the reference's order (x_T; then per step
-        t > 0: z, and z' if noise_bcs); ``noise_fn(like)`` replaces ``torch.randn_like``."""
+    def p_sample_loop(self, x_bcs, C, cell_idx, pbar=False, start_from: int | None = None, noise_fn=None, seed=None,
+                      trajectory_ids=None):
+        """Ancestral sampling (reference ddpm.py:767-816).
+
+        Default (`noise_fn is None`): the hipGraph-captured reverse step of `sampling.GraphSampler`, replayed T times --
+        this is what `DiffusionTrainer.sample`, `tools/eval_ckpt.py` and a `dropin` user get.  Noise comes from the
+        counter-based generator, one stream per trajectory; the per-call nonce is drawn from torch's global CPU generator
+        (so `torch.manual_seed` / `seed_everything` make the samples reproducible, as they do for the reference's
+        `torch.randn_like`) unless `seed` is given; `trajectory_ids` = global ids of the batch's trajectories when a larger
+        set is sharded over ranks (samples then do not depend on the sharding).  The sampler and its graph are kept per
+        input shape and pointed at the new batch / geometry by copies (`GraphSampler.rebind`); a weight update re-captures.
+        With `noise_fn(like)` -- injected noise in the reference's drawing order (x_T; then per step t > 0: z, and z' if
+        noise_bcs), the golden tests -- or TDX_GRAPH_SAMPLER=0 the loop runs eagerly, one launch sequence per step."""
         if self.learned_variances:
             raise NotImplementedError("sampling with learned variances is not on the accelerated path")
+        if noise_fn is None and GRAPH_SAMPLER and x_bcs.is_cuda and hasattr(self.model, "encode_local"):
+            return self._graph_sample(x_bcs, C, cell_idx, pbar, start_from, seed, trajectory_ids)
+        return self._eager_sample(x_bcs, C, cell_idx, pbar, start_from, noise_fn)
+
+    def _graph_sample(self, x_bcs, C, cell_idx, pbar, start_from, seed, trajectory_ids):
+        from ..sampling import GraphSampler
+
+        nonce = int(torch.randint(0, 2**31 - 1, (1,)).item()) if seed is None else int(seed) % (2**31 - 1)
+        x_bcs = x_bcs.contiguous().float()
+        sig = GraphSampler.signature_of(self, x_bcs, C)
+        gs = _SAMPLERS.get(self)
+        if gs is None or gs.signature() != sig:
+            gs = _SAMPLERS[self] = GraphSampler(self, x_bcs, C, cell_idx, seed=0, trajectory_ids=trajectory_ids, nonce=nonce)
+        else:
+            gs.rebind(x_bcs, C, cell_idx, nonce=nonce,
+                      trajectory_ids=list(range(x_bcs.shape[0])) if trajectory_ids is None else trajectory_ids)
+        return gs.sample(start_from, pbar=pbar)
+
+    def _eager_sample(self, x_bcs, C, cell_idx, pbar, start_from, noise_fn):
         randn = noise_fn if noise_fn is not None else torch.randn_like
         x_bcs = x_bcs.contiguous().float()
         B, Fd = x_bcs.shape[:2]

@@ -766,37 +766,47 @@ def film_projections(c: torch.Tensor, linears) -> list:
 _SIDE = {}  # device index -> side stream of the weight gradients
 
 
+WGRAD_STREAM = os.environ.get("TDX_WGRAD_STREAM", "1") != "0"  # read once (bench.py / tests set it before the import)
+
+
 class _WgradSide:
     """The 3x3x3 weight gradients of a block run on a side stream next to the rest of its backward: they feed nothing
     before the optimiser and are bound by the matrix cores, what runs beside them (GroupNorm backward, 1x1 convs, the
     halo-shell launches) is bound by memory or latency: 22.94 -> 22.59 ms per step (four alternating pairs on one
-    box).  The block joins the streams before it returns (gradient hooks and the optimiser see finished tensors) and holds
-    the tensors the side stream reads until then (the caching allocator knows nothing of those reads).  One join at the
-    end of the whole backward pass instead (engine callback) was measured too: no faster (22.77 vs 22.71 ms); so was putting
-    the 1x1 skip conv (beside the forward conv chain) and its weight gradient on the side stream as well: -0.07 ms, and
-    the forward convs' own durations grow by 9 % under the overlap.
-    TDX_WGRAD_STREAM=0: everything on the launching stream."""
+    box).  The block joins the streams before it returns -- also when its backward raises (`_ResnetBlock.backward` joins
+    in a `finally`) -- so gradient hooks and the optimiser see finished tensors; every tensor the side stream touches is
+    marked with `record_stream`, so one that the block drops early (`del dh2`) goes back to the allocator only once the
+    side stream is past its last use.  One join at the end of the whole backward pass instead (engine callback) was
+    measured too: no faster (22.77 vs 22.71 ms); so was putting the 1x1 skip conv (beside the forward conv chain) and its
+    weight gradient on the side stream as well: -0.07 ms, and the forward convs' own durations grow by 9 % under the overlap.
+    The side stream only needs the zero block of the scratch arena (`_lib.declare_zero_block_only`: 4 KiB, not 96 MiB).
+    TDX_WGRAD_STREAM=0 (read at import; `ops.WGRAD_STREAM`): everything on the launching stream."""
 
     def __init__(self, device):
-        self.on = os.environ.get("TDX_WGRAD_STREAM", "1") != "0"
+        self.on = WGRAD_STREAM
+        self.pending = False
         if self.on:
             idx = device.index
             if idx not in _SIDE:
                 _SIDE[idx] = torch.cuda.Stream(device=device)
-            self.side, self.main, self.keep = _SIDE[idx], torch.cuda.current_stream(device), []
+                L.declare_zero_block_only(_SIDE[idx])
+            self.side, self.main = _SIDE[idx], torch.cuda.current_stream(device)
 
     def run(self, fn, *tensors):
         if not self.on:
             return fn()
-        self.keep.extend(t for t in tensors if t is not None)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.side)
         self.side.wait_stream(self.main)
+        self.pending = True
         with torch.cuda.stream(self.side):
             fn()
 
     def join(self):
-        if self.on:
+        if self.on and self.pending:
             self.main.wait_stream(self.side)
-            self.keep.clear()
+            self.pending = False
 
 
 class _ResnetBlock(torch.autograd.Function):
@@ -887,6 +897,14 @@ class _ResnetBlock(torch.autograd.Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
+        side = _WgradSide(gy.device)
+        try:
+            return _ResnetBlock._backward(ctx, gy, side)
+        finally:
+            side.join()  # also on an exception: no side-stream work may outlive the tensors it touches
+
+    @staticmethod
+    def _backward(ctx, gy, side):
         x1, x2, h1, st1, a1, h2, st2, film, g1, be1, g2, be2, wb1, wb2, wr2, xc = ctx.saved_tensors
         scale, shift = film[0], film[1]
         groups, w1s, w2s, wrs, hb1, hb2, hbr = ctx.cfg
@@ -910,7 +928,6 @@ class _ResnetBlock(torch.autograd.Function):
         # one workspace per (Cin, Cout): the accumulator / slab layout inside depends on both
         wws2 = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cout, Cout, impl), dev, ("w3", Cout, Cout))
         wws1 = _clean_ws(L.query("tdx_conv3_bwd_weight_workspace_bytes", Cc, Cout, impl), dev, ("w3", Cc, Cout))
-        side = _WgradSide(dev)
         side.run(lambda: L.call("tdx_conv3_bwd_weight", L.ptr(a1), Cout, None, 0, L.ptr(dh2), L.ptr(dw2), L.ptr(db2), B, X, Y, Z,
                                 Cout, code, impl | WS_CLEAN, L.ptr(wws2), L.stream(), work=flops(Cout)), a1, dh2, dw2, db2)
         da1 = torch.empty_like(a1)

@@ -15,22 +15,31 @@ from __future__ import annotations
 
 import torch
 
+from . import _lib as L
 from . import ops
 
 
 class GraphSampler:
-    def __init__(self, diffusion, x_bcs, C, cell_idx, seed: int = 0, trajectory_ids=None, use_graph: bool = True):
+    """One captured reverse step, replayed T times.  Everything the captured step reads lives in buffers the sampler
+    OWNS (boundary values, conditioning tensors, in-domain mask, cached conditioning conv), so `rebind` can point an
+    existing graph at another batch / geometry of the same shape by copying into them -- `GaussianDiffusion.
+    p_sample_loop` keeps one sampler per input shape and re-uses its graph from call to call."""
+
+    def __init__(self, diffusion, x_bcs, C, cell_idx, seed: int = 0, trajectory_ids=None, use_graph: bool = True, nonce: int = 0):
         self.d = diffusion
-        self.x_bcs = x_bcs.contiguous().float()
-        self.C = C
+        self.x_bcs = x_bcs.detach().float().contiguous().clone()
+        self.C = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in C.items()} if isinstance(C, dict) else C
         B = self.x_bcs.shape[0]
         dev = self.x_bcs.device
         self.B, self.dev, self.seed = B, dev, int(seed)
         V = self.x_bcs[0, 0].numel()
-        self.mask, _ = diffusion.domain_mask(cell_idx, V)
+        self.mask = diffusion.domain_mask(cell_idx, V)[0].clone()
         ids = list(range(B)) if trajectory_ids is None else list(trajectory_ids)
         assert len(ids) == B
-        self.stream_ids = torch.tensor(ids, dtype=torch.int64, device=dev)
+        # Philox key = `seed` (a launch argument: fixed once captured); counter words = (offset + element, stream id);
+        # stream id = trajectory id in the low 32 bits, `nonce` in the high 31: the nonce lives in device memory, so a
+        # captured graph draws fresh noise per call without a re-capture (p_sample_loop passes one per call)
+        self.stream_ids = torch.tensor(self._sids(ids, nonce), dtype=torch.int64, device=dev)
         self.offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self.t = torch.zeros(1, dtype=torch.int64, device=dev)
         self.x_t = torch.empty_like(self.x_bcs)
@@ -38,9 +47,53 @@ class GraphSampler:
         self.z2 = torch.empty_like(self.x_bcs)
         self.use_graph = use_graph
         self.graph = None
+        self._capture_stream = None  # ONE stream for every capture of this sampler (its scratch arena is per stream)
         with torch.no_grad():
-            self.enc = diffusion.model.encode_local(C)
+            self.enc = diffusion.model.encode_local(self.C)
         self.reset()
+
+    @staticmethod
+    def _sids(ids, nonce):
+        assert 0 <= int(nonce) < 2**31 and all(0 <= int(i) < 2**32 for i in ids)
+        return [(int(nonce) << 32) | int(i) for i in ids]
+
+    @staticmethod
+    def signature_of(diffusion, x_bcs, C):
+        """What must match for `rebind`: shapes / dtypes of everything the captured step reads, and the switches the
+        captured step was built under."""
+        c = tuple(sorted((str(k), tuple(v.shape), str(v.dtype)) for k, v in C.items() if torch.is_tensor(v))) \
+            if isinstance(C, dict) else None
+        m = diffusion.model
+        return (tuple(x_bcs.shape), str(x_bcs.device), c, getattr(m, "compute_dtype", None), getattr(m, "conv_impl", None),
+                L.conv_impl(), diffusion.noise_bcs, diffusion.clip_denoised, diffusion.num_timesteps)
+
+    def signature(self):
+        return self.signature_of(self.d, self.x_bcs, self.C)
+
+    @torch.no_grad()
+    def rebind(self, x_bcs, C, cell_idx, nonce=None, trajectory_ids=None):
+        """Another batch (and possibly another geometry) of the SAME shapes: copy it into the buffers the captured graph
+        reads.  The cached conditioning conv is recomputed into its existing tensors."""
+        self.x_bcs.copy_(x_bcs)
+        if isinstance(self.C, dict):
+            for k, v in C.items():
+                if torch.is_tensor(v):
+                    self.C[k].copy_(v)
+        self.mask.copy_(self.d.domain_mask(cell_idx, self.x_bcs[0, 0].numel())[0])
+        if self.enc is not None:
+            enc = self.d.model.encode_local(self.C)
+            old, new = getattr(self.enc, "first_conv_partial", None), getattr(enc, "first_conv_partial", None)
+            if (old is None) != (new is None) or enc.shape != self.enc.shape or enc.dtype != self.enc.dtype:
+                self.enc, self.graph = enc, None  # another structure than the captured one: capture again on these tensors
+            else:
+                self.enc.copy_(enc)
+                if old is not None:
+                    old[1].copy_(new[1])
+        if nonce is not None or trajectory_ids is not None:
+            ids = [int(i) & 0xFFFFFFFF for i in self.stream_ids.tolist()] if trajectory_ids is None else list(trajectory_ids)
+            nn = int(self.stream_ids[0].item()) >> 32 if nonce is None else nonce
+            self.stream_ids.copy_(torch.tensor(self._sids(ids, nn), dtype=torch.int64))
+        return self
 
     # ---- state
     def _randn(self, out):
@@ -75,18 +128,20 @@ class GraphSampler:
 
     @torch.no_grad()
     def _capture(self):
-        # warm up on a side stream (packs weights, sizes the allocator), then capture
+        # warm up on the sampler's own side stream (packs weights, sizes the allocator, creates that stream's scratch
+        # arena), then capture on the same stream: the conv kernels' arena is bound per stream (_lib.ensure_scratch), so
+        # nothing is allocated inside the capture and the replayed graph never shares an arena with eager work on another
+        # stream.  Re-captures (after a weight update) re-use the stream -- and with it the arena.
         state = (self.x_t.clone(), self.t.clone(), self.offset.clone())
-        s = torch.cuda.Stream()
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream(device=self.dev)
+        s = self._capture_stream
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._step()
+            self._arena = L.scratch_arena(self.dev)  # held for as long as the graph lives (the arena map is bounded)
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        # capture on the warm-up stream: the conv kernels' scratch arena is bound per stream (_lib.ensure_scratch), the
-        # warm-up step created this stream's, so nothing is allocated inside the capture and the replayed graph never
-        # shares an arena with eager work on another stream
-        self._capture_stream = s
         with torch.cuda.graph(self.graph, stream=s):
             self._step()
         self.x_t.copy_(state[0]); self.t.copy_(state[1]); self.offset.copy_(state[2])
@@ -101,11 +156,16 @@ class GraphSampler:
         return any(p._version != v for p, v in self._versions)
 
     @torch.no_grad()
-    def run_steps(self, n: int):
+    def run_steps(self, n: int, pbar: bool = False):
         n = min(n, self.steps_left)
         if self.use_graph and (self.graph is None or self._stale()):
             self._capture()
-        for _ in range(n):
+        steps = range(n)
+        if pbar:
+            from tqdm.auto import tqdm
+
+            steps = tqdm(steps, desc="sampling loop time step", total=n, position=1)
+        for _ in steps:
             if self.use_graph:
                 self.graph.replay()
             else:
@@ -114,10 +174,10 @@ class GraphSampler:
         return self.x_t
 
     @torch.no_grad()
-    def sample(self, start_from: int | None = None):
+    def sample(self, start_from: int | None = None, pbar: bool = False):
         """Full trajectory; returns the (B, F, X, Y, Z) sample with BC cells set to x_bcs."""
         self.reset(start_from)
-        self.run_steps(self.steps_left)
+        self.run_steps(self.steps_left, pbar=pbar)
         return self.x_t.clone()
 
     # ---- the same noise, as tensors, for cross-checks against the eager loop

@@ -62,9 +62,11 @@ int tdx_version(void);
 /* Scratch arena for kernels that need transient device workspace their entry point has no argument for: the K-split
  * slabs of the small-grid 3x3x3 conv (ddpm.py:164 on the 24x8x6 and 12x4x3 levels: several workgroups share an output
  * tile's K range, fp32 partial tiles go through the arena, a reduce kernel finishes them).  The library never
- * allocates: the caller hands over `bytes` (>= 1 MiB; 96 MiB covers the shipped model at B <= 8) of device memory
+ * allocates: the caller hands over `bytes` (>= 64; 96 MiB covers the shipped model at B <= 8) of device memory
  * whose first 64 bytes are zero, keeps it alive and otherwise untouched, and orders all tdx_conv3_* launches on one
- * stream (or re-registers per stream).  Without an arena (ptr = NULL) those layers run on the brick kernels. */
+ * stream (or re-registers per stream).  The first 64 bytes are the zero source of the LDS-DMA kernels (ring conv data
+ * gradient, producer / consumer weight gradient): a stream that launches only those may register a 64-byte arena; a
+ * layer whose slabs do not fit the registered bytes runs on the brick kernels, as all do without an arena (ptr = NULL). */
 int tdx_set_scratch(void* ptr, size_t bytes);
 /* name of the gfx target the library was built for ("gfx950") */
 const char* tdx_arch(void);
@@ -115,8 +117,13 @@ int tdx_transpose_many(const TdxTransposeJob* jobs, int n, void* stream);
 int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, const void* wf, const float* bias, void* y,
                   int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* stream);
 
-/* Which bf16 matrix-core kernel serves this shape (same call, same results bit for bit; a host needs this only for
- * bookkeeping, e.g. bench.py's per-kernel roofline): 1 = the persistent LDS-DMA ring kernel (tdx_conv3_ring.hip: grids
+/* Which bf16 matrix-core kernel serves this shape (same call; the kernels form the same products and sum them in fp32
+ * in different orders, so their bf16 results agree up to ~1 ulp on a few % of the elements, not bit for bit.  Kernel
+ * selection depends on the grid, on B -- a launch must fill the chip -- and on whether a scratch arena is bound
+ * (tdx_set_scratch), so the last bit of a sample's output can change with the batch size it is computed in (B = 1
+ * sampling vs B = 6 training) and with the arena setting; TDX_CONV3_RING=0 in the environment keeps every shape on the
+ * brick kernels for batch-invariant results.  A host needs this query only for bookkeeping, e.g. bench.py's per-kernel
+ * roofline): 1 = the persistent LDS-DMA ring kernel (tdx_conv3_ring.hip: grids
  * of whole 8x8x8 bricks that fill the chip, i.e. the two finest U-Net levels), 0 = the brick / small-grid kernels.
  * For a data gradient pass the layer's (Cout, 0, Cin) as (C1, C2, Cout). */
 int tdx_conv3_uses_ring(int C1, int C2, int Cout, int B, int X, int Y, int Z);

@@ -288,7 +288,19 @@ def test_profiles_index_names_existing_files():
     sys.path.insert(0, str(root))
     import bench
 
+    # roofline.traffic is quoted only from a PMC file collected on THIS tree's conv kernels: a file
+    # carries the fingerprint of csrc/tdx_conv* it was collected on; one that describes other kernels is refused by name
+    from turbdiff_amd._lib import kernel_sources_fingerprint
+
     bytes_per_launch, src, n = bench.measured_traffic("bf16")
-    assert src == "profiles/r10bf16_traffic.json" and n >= 60 and bytes_per_launch > 1e8
-    kernels = json.loads((root / src).read_text())["kernels"]
-    assert any("conv3_ring_kernel<2, false" in k for k in kernels)
+    now = kernel_sources_fingerprint()
+    assert now is not None and src["kernel_sources_sha16"] == now
+    if bytes_per_launch is not None:
+        assert n >= 60 and bytes_per_launch > 1e8
+        data = json.loads((root / src["file"]).read_text())
+        assert data["kernel_sources_sha16"] == now and data.get("git_head")
+        assert any("conv3_ring_kernel<2, false" in k for k in data["kernels"])
+    else:
+        assert src["file"] is None and any(r["file"].endswith("_traffic.json") for r in src["refused"])
+    stale = json.loads((root / "profiles" / "r10bf16_traffic.json").read_text())
+    assert stale.get("kernel_sources_sha16") != now, "the round-3 file describes the round-3 kernels"

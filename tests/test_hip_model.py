@@ -291,6 +291,83 @@ def test_reference_grid_194x50x50_four_levels_forward(monkeypatch):
     assert rel_l2(y.cpu(), ref) < 1e-4 and rel_l2(ys.cpu(), ref) < 1e-4 and rel_l2(yb.cpu(), ref) < 3e-2
 
 
+@pytest.mark.timeout(900)
+def test_reference_grid_194x50x50_gradients_match_oracle(monkeypatch):
+    """the reference's real grid (scripts/grid-embedding.py:69; levels 194x50x50 -> 97x25x25 -> 48x12x12
+    -> 24x6x6 -> 12x3x3 via max(int(s/2), 3), ddpm.py:358) through the full 4-level dim-32 net, BACKWARD included: loss and
+    the 18 watched parameter gradients of p_losses against the CPU oracle in f32 / f32s (1e-3) and bf16 (0.1), B = 1.  This is
+    where the thin-slab data gradient, the ragged weight-gradient bricks and the halo shell run at the real size."""
+    from turbdiff_amd.models.ddpm import GaussianDiffusion
+
+    net, sd = _full_size_problem(seed=3)
+    X, Y, Z = 194, 50, 50
+    x = torch.randn(1, 4, X, Y, Z, generator=torch.Generator().manual_seed(5))
+    c_local = torch.randn(4, X, Y, Z, generator=torch.Generator().manual_seed(6))
+    noise = torch.randn(1, 4, X, Y, Z, generator=torch.Generator().manual_seed(7))
+    t = torch.tensor([77])
+    m = torch.zeros(X, Y, Z, dtype=torch.bool)
+    m[1:-1, 1:-1, 1:-1] = True
+    m[40:60, 17:33, 0:25] = False
+    cell_idx = m.flatten().nonzero().flatten()
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    buf = O.schedule_buffers("log-snr-linear", 500)
+    ref_loss, _ = O.p_losses(leaves, buf, x, t, c_local, cell_idx, noise, timesteps=500, noise_bcs=True)
+    ref_loss.backward()
+    diff = GaussianDiffusion(net, timesteps=500, beta_schedule="log-snr-linear", noise_bcs=True).to(dev())
+    md = SimpleNamespace(cell_idx=cell_idx.to(dev()))
+    _check_modes_against_oracle(monkeypatch, diff, (x, t, c_local, noise), md, ref_loss, leaves, WATCHED_FULL_SIZE)
+
+
+@pytest.mark.timeout(600)
+def test_config0_48x32x32_two_levels_training_and_sampling_vs_oracle(monkeypatch):
+    """VERDICT r3 item 1b -- BASELINE configs[0] as a whole on the GPU: DenoisingModel(dim=32, u_net_levels=2, T=10) at
+    48x32x32, (i) loss and EVERY parameter gradient of p_losses vs the oracle in the three modes, (ii) the 10-step
+    p_sample_loop with injected noise vs oracle.p_sample_loop (fp32 modes 1e-4 on the sample; bf16 3e-2), for both
+    noise_bcs settings."""
+    from turbdiff_amd.models.ddpm import DenoisingModel, GaussianDiffusion
+
+    torch.manual_seed(0)
+    net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=10, dim=32,
+                         u_net_levels=2, norm_type="group")
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    X, Y, Z = 48, 32, 32
+    gen = torch.Generator().manual_seed(1234)
+    x = torch.randn(1, 4, X, Y, Z, generator=gen)
+    c_local = torch.randn(4, X, Y, Z, generator=torch.Generator().manual_seed(1235))
+    noise = torch.randn(1, 4, X, Y, Z, generator=gen)
+    t = torch.tensor([6])
+    m = torch.zeros(X, Y, Z, dtype=torch.bool)
+    m[1:-1, 1:-1, 1:-1] = True
+    m[13:25, 8:24, 0:16] = False
+    cell_idx = m.flatten().nonzero().flatten()
+    leaves = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    buf = O.schedule_buffers("log-snr-linear", 10)
+    ref_loss, _ = O.p_losses(leaves, buf, x, t, c_local, cell_idx, noise, timesteps=10, noise_bcs=True)
+    ref_loss.backward()
+    diff = GaussianDiffusion(net, timesteps=10, beta_schedule="log-snr-linear", noise_bcs=True).to(dev())
+    md = SimpleNamespace(cell_idx=cell_idx.to(dev()))
+    watched = [n for n, p in net.named_parameters() if leaves[n].grad is not None and leaves[n].grad.abs().max() > 1e-7]
+    assert len(watched) > 50
+    _check_modes_against_oracle(monkeypatch, diff, (x, t, c_local, noise), md, ref_loss, leaves, watched)
+    # (ii) the 10-step loop
+    sdn = {k: v.detach() for k, v in sd.items()}
+    for nb in (True, False):
+        noises = [torch.randn(1, 4, X, Y, Z, generator=gen) for _ in range(1 + 9 * (2 if nb else 1))]
+        with torch.no_grad():
+            ref = O.p_sample_loop(sdn, buf, x, c_local, cell_idx, noises, timesteps=10, noise_bcs=nb)
+        diff.noise_bcs = nb
+        for mode, impl, dtype, tol in (("f32", "auto", torch.float32, 1e-4), ("f32s", "split", torch.float32, 1e-4),
+                                       ("bf16", "auto", torch.bfloat16, 3e-2)):
+            monkeypatch.setenv("TDX_CONV_IMPL", impl)
+            diff.model.set_compute_dtype(dtype)
+            it = iter([n.to(dev()) for n in noises])
+            out = diff.p_sample_loop(x.to(dev()), cond(c_local), md.cell_idx, noise_fn=lambda like: next(it))
+            assert next(it, None) is None
+            assert rel_l2(out.cpu(), ref) < tol, (mode, nb, rel_l2(out.cpu(), ref))
+        monkeypatch.delenv("TDX_CONV_IMPL")
+        diff.model.set_compute_dtype(torch.float32)
+
+
 def test_split_precision_training_step_vs_oracle(monkeypatch):
     """dim 32, 3 levels, 48x32x24, B = 2: loss and every parameter gradient of p_losses with
     TDX_CONV_IMPL=split (fp32 tensors, bf16 hi + lo MFMA convs) against the CPU oracle."""
@@ -365,6 +442,72 @@ def test_graph_sampler_equals_eager_loop(golden, nb):
     # sharding invariance: trajectory 9 alone, on its own "rank", gives the same sample
     solo = GraphSampler(diff, x_bcs[1:], C, cidx, seed=42, trajectory_ids=[9], use_graph=False).sample()
     assert rel_l2(solo[0], out_graph[1]) < 1e-5
+
+
+@pytest.mark.parametrize("nb", [True, False])
+def test_p_sample_loop_default_path_is_the_graph_sampler(golden, nb):
+    """`GaussianDiffusion.p_sample_loop` without injected noise -- what `DiffusionTrainer.sample`,
+    `tools/eval_ckpt.py` and a `dropin` user call (reference diffusion.py:152-158, ddpm.py:767-816) -- runs the captured
+    reverse step.  (a) It equals the eager loop fed with the very noise it drew (seed / trajectory ids given);
+    (b) a second call with ANOTHER geometry and batch of the same shape re-uses the graph (no re-capture) and is again
+    equal to its eager twin; (c) `start_from` works through the same graph; (d) with the nonce drawn from torch's global
+    generator, `torch.manual_seed` makes two calls agree and two different seeds differ; (e) pbar=True runs."""
+    from turbdiff_amd.models import ddpm as D
+    from turbdiff_amd.sampling import GraphSampler
+
+    g = golden("sample_cfg1")
+    diff = build_cfg1(golden, noise_bcs=nb)
+    x_bcs, C, cidx = g["x_bcs"].to(dev()), cond(g["c_local"]), g["cell_idx"].to(dev())
+
+    def eager_twin(xb, Cc, ci, nonce, ids, start=None):
+        ref = GraphSampler(diff, xb, Cc, ci, seed=0, trajectory_ids=ids, nonce=nonce, use_graph=False)
+        stream = ref.noise_stream()
+        return diff.p_sample_loop(xb, Cc, ci, start_from=start, noise_fn=lambda like: next(stream))
+
+    out = diff.p_sample_loop(x_bcs, C, cidx, seed=123, trajectory_ids=[5, 9])
+    gs = D._SAMPLERS[diff]
+    assert gs.graph is not None, "the default path did not capture a graph"
+    assert rel_l2(out, eager_twin(x_bcs, C, cidx, 123, [5, 9])) < 1e-5
+    first_graph = gs.graph
+    # (b) another geometry: shifted obstacle, other boundary values and conditioning
+    X, Y, Z = x_bcs.shape[-3:]
+    m = torch.zeros(X, Y, Z, dtype=torch.bool)
+    m[1:-1, 1:-1, 2:-1] = True
+    m[2:4, 3:6, 2:5] = False
+    cidx2 = m.flatten().nonzero().flatten().to(dev())
+    gen = torch.Generator().manual_seed(77)
+    x2 = torch.randn(x_bcs.shape, generator=gen).to(dev())
+    C2 = cond(torch.randn(g["c_local"].shape, generator=gen))
+    out2 = diff.p_sample_loop(x2, C2, cidx2, seed=7, trajectory_ids=[0, 1])
+    assert D._SAMPLERS[diff] is gs and gs.graph is first_graph, "same shapes: the captured graph must be re-used"
+    assert rel_l2(out2, eager_twin(x2, C2, cidx2, 7, [0, 1])) < 1e-5
+    inside = torch.zeros(X * Y * Z, dtype=torch.bool)
+    inside[cidx2.cpu()] = True
+    assert torch.equal(out2.cpu().flatten(-3)[..., ~inside], x2.cpu().flatten(-3)[..., ~inside])
+    # (c) start_from
+    out3 = diff.p_sample_loop(x2, C2, cidx2, seed=9, start_from=5)
+    assert rel_l2(out3, eager_twin(x2, C2, cidx2, 9, [0, 1], start=5)) < 1e-5
+    # (d) reproducible under torch.manual_seed, like the reference's torch.randn_like draws
+    torch.manual_seed(31)
+    a = diff.p_sample_loop(x_bcs, C, cidx)
+    torch.manual_seed(31)
+    b = diff.p_sample_loop(x_bcs, C, cidx, pbar=True)
+    torch.manual_seed(32)
+    c = diff.p_sample_loop(x_bcs, C, cidx)
+    assert rel_l2(a, b) < 1e-5 and rel_l2(a, c) > 1e-2
+    assert gs.graph is first_graph
+
+
+def test_p_sample_loop_eager_switch(golden, monkeypatch):
+    """TDX_GRAPH_SAMPLER=0 (models.ddpm.GRAPH_SAMPLER): the default path is the eager loop with torch.randn_like."""
+    from turbdiff_amd.models import ddpm as D
+
+    g = golden("sample_cfg1")
+    diff = build_cfg1(golden, noise_bcs=True)
+    monkeypatch.setattr(D, "GRAPH_SAMPLER", False)
+    torch.manual_seed(3)
+    out = diff.p_sample_loop(g["x_bcs"].to(dev()), cond(g["c_local"]), g["cell_idx"].to(dev()))
+    assert diff not in D._SAMPLERS and torch.isfinite(out).all()
 
 
 def test_graph_sampler_recaptures_after_a_weight_update(golden):

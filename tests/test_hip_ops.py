@@ -836,7 +836,7 @@ def test_conv3_small_grid_kernel_vs_brick_kernels(case, mode, monkeypatch):
     try:
         brick = run()
     finally:
-        L._SCRATCH.pop("active", None)
+        L._ACTIVE = None
         L.ensure_scratch(d)
     for n, a, b, tol in zip(["y", "stats", "y (plain fwd)", "gx1", "gx2"], small, brick, tols):
         if a is None:
@@ -895,7 +895,8 @@ def test_conv3_data_gradient_deterministic_shell_route(case, mode, monkeypatch):
     ref = nvc(xr.grad.float())
     tol = 4e-3 if mode == "bf16" else (2e-5 if mode == "f32s" else 2e-6)
     assert rel_l2(a, ref) < tol and rel_l2(base, ref) < tol
-    assert rel_l2(a, base) < (4e-3 if mode == "bf16" else 1e-6)
+    # (bf16: the default route's atomics round per add in arrival order; measured 2.5e-3 ... 4.0e-3 on the thin grids)
+    assert rel_l2(a, base) < (6e-3 if mode == "bf16" else 1e-6)
     ws = L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, Ci, L.dtype_code(dt), L.conv_impl())
     assert ws >= 2 * ((X + 2) * (Y + 2) + (X + 2) * Z + Y * Z) * B * Ci * 4
 
@@ -907,6 +908,10 @@ def test_conv3_data_gradient_deterministic_shell_route(case, mode, monkeypatch):
     (2, 32, 0, 64, (16, 16, 16)), (1, 16, 0, 64, (32, 32, 16)), (3, 64, 0, 64, (64, 32, 32)), (2, 32, 32, 32, (64, 64, 32)),
     (1, 64, 64, 128, (48, 32, 24)), (2, 128, 0, 256, (32, 16, 24)), (5, 32, 0, 32, (32, 32, 32)), (2, 64, 0, 64, (192, 64, 48)),
     (6, 16, 0, 64, (96, 32, 24)),
+    # ragged grids (round 4): whole bricks on the ring kernel + 1-2 voxel remainder slabs on the thin-brick kernel --
+    # remainders on every axis / on one axis only / 32-wide tiles (16 x 8 x 8 bricks) / the reference's real grid and its level 1
+    (1, 64, 0, 64, (50, 26, 18)), (2, 32, 32, 64, (24, 17, 16)), (2, 32, 0, 32, (34, 17, 9)), (1, 16, 0, 64, (194, 50, 50)),
+    (2, 64, 64, 128, (97, 25, 25)),
 ])
 def test_conv3_ring_kernel_vs_brick_kernel(case, monkeypatch):
     """The persistent LDS-DMA ring kernel (tdx_conv3_ring.hip) against the brick kernel it replaces on the two finest
@@ -982,6 +987,66 @@ def test_conv3_ring_kernel_vs_brick_kernel(case, monkeypatch):
     # the switch does select the kernel: with one workgroup per CU the ring launch leaves the brick path's timing,
     # not its results; check the dispatcher's own report instead
     assert bool(L.query("tdx_conv3_uses_ring", C1, C2, Co, B, X, Y, Z))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cus", [224, 240, 64, 8])
+@pytest.mark.parametrize("case", [(3, 64, 0, 64, (64, 32, 32)), (2, 32, 32, 32, (64, 64, 32)), (2, 128, 0, 256, (32, 16, 24))])
+def test_persistent_kernels_on_fewer_cus(case, cus, monkeypatch):
+    """TDX_PERSISTENT_CUS: the persistent one-workgroup-per-CU kernels (ring conv forward / data
+    gradient, producer / consumer weight gradient) launched on 224 / 240 / 64 / 8 workgroups instead of 256, so that a
+    data-parallel run can leave CUs to RCCL.  A brick's arithmetic does not depend on which workgroup walks it: forward
+    output and the data gradient's interior are BIT-identical to the 256-workgroup launch; GroupNorm statistics (f64
+    atomics in another order) and the weight gradient (another K split) agree to rounding."""
+    from turbdiff_amd import _lib as L, ops
+
+    B, C1, C2, Co, (X, Y, Z) = case
+    d = dev()
+    Ci = C1 + C2
+    dt, DT = torch.bfloat16, L.BF16
+    g = torch.Generator(device=d).manual_seed(5)
+    rn = lambda *s: torch.randn(*s, device=d, generator=g)
+    x1, x2 = rn(B, X, Y, Z, C1).to(dt), (rn(B, X, Y, Z, C2).to(dt) if C2 else None)
+    w = rn(Co, Ci, 3, 3, 3) * (2.0 / (27 * Ci)) ** 0.5
+    bias, gy = rn(Co), rn(B, X, Y, Z, Co).to(dt)
+    st = L.stream()
+    wf, wb = ops._packed_conv3(w, dt)
+    L.ensure_scratch(d)
+    monkeypatch.setenv("TDX_CONV3_RING", "2")
+
+    def run():
+        y = torch.empty(B, X, Y, Z, Co, device=d, dtype=dt)
+        stats = torch.empty(B, 8, 2, device=d)
+        ws = torch.zeros(L.query("tdx_gn_workspace_bytes", B, Co), dtype=torch.uint8, device=d)
+        L.call("tdx_conv3_fwd_gn", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(wf), L.ptr(bias), L.ptr(y), L.ptr(stats), 8, 1e-5, L.ptr(ws),
+               B, X, Y, Z, Co, DT, L.CONV_AUTO | L.WS_CLEAN, st)
+        gx1, gx2 = torch.empty_like(x1), (torch.empty_like(x2) if C2 else None)
+        dws = torch.empty(L.query("tdx_conv3_bwd_data_workspace_bytes", B, X, Y, Z, Ci, DT, 0), dtype=torch.uint8, device=d)
+        L.call("tdx_conv3_bwd_data", L.ptr(gy), L.ptr(wb), L.ptr(gx1), C1, L.ptr(gx2), C2, 0, B, X, Y, Z, Co, DT, L.CONV_AUTO,
+               L.ptr(dws), st)
+        dw, db = torch.empty(Co, Ci, 3, 3, 3, device=d), torch.empty(Co, device=d)
+        wws = torch.zeros(L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, 0), dtype=torch.uint8, device=d)
+        L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(dw), L.ptr(db), B, X, Y, Z, Co, DT,
+               L.CONV_AUTO | L.WS_CLEAN, L.ptr(wws), st)
+        torch.cuda.synchronize()
+        # TDX_WS_CLEAN covers the accumulators at the head of the weight-gradient workspace (the slabs behind are scratch)
+        assert int(wws[: (27 * Ci * Co + Co) * 4].count_nonzero()) == 0 and int(ws.count_nonzero()) == 0
+        return y, stats, gx1, gx2, dw, db
+
+    full = run()
+    monkeypatch.setenv("TDX_PERSISTENT_CUS", str(cus))
+    ntn = Co // 64 if Co % 64 == 0 else Co // 32
+    assert bool(L.query("tdx_conv3_uses_ring", C1, C2, Co, B, X, Y, Z)) == (ntn <= cus // 8)
+    few = run()
+    assert rel_l2(few[1], full[1]) < 1e-5 and rel_l2(few[2].float(), full[2].float()) < 2e-3
+    if ntn <= cus // 8:
+        inner = lambda t: t[:, 1:-1, 1:-1, 1:-1]
+        assert torch.equal(few[0], full[0]) and torch.equal(inner(few[2]), inner(full[2]))
+        if C2:
+            assert torch.equal(inner(few[3]), inner(full[3]))
+    else:  # more N tiles than an XCD has workgroups left: the call falls back to the brick kernel
+        assert rel_l2(few[0].float(), full[0].float()) < 5e-4
+    assert rel_l2(few[4], full[4]) < 1e-5 and rel_l2(few[5], full[5]) < 1e-5
 
 
 @pytest.mark.gpu

@@ -19,7 +19,8 @@ noise = torch.randn_like(x)
 
 
 def grads(stream):
-    os.environ["TDX_WGRAD_STREAM"] = stream
+    from turbdiff_amd import ops as _ops
+    _ops.WGRAD_STREAM = stream == "1"  # (the environment variable is read once, at import)
     diff.zero_grad(set_to_none=True)
     loss, _ = diff.p_losses(x, t, C, md, None, noise=noise)
     loss.backward()

@@ -9,7 +9,8 @@ import soak_train as S
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 runs = []
 for sw in ("0", "0", "1", "1"):
-    os.environ["TDX_WGRAD_STREAM"] = sw
+    from turbdiff_amd import ops as _ops
+    _ops.WGRAD_STREAM = sw == "1"  # (the environment variable is read once, at import)
     l, dt, mem = S.run("bf16", steps)
     runs.append((sw, l))
     marks = [i for i in (0, 100, 200, 300) if i < steps - 1] + [steps - 1]
