@@ -39,11 +39,22 @@ __device__ __forceinline__ int sw64(int r, int c) { return r * 64 + ((c ^ ((r >>
 // 128-B rows (64 bf16), 8 chunks; chunk c of row r at c ^ (r & 7)
 __device__ __forceinline__ int sw128(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
+// `add` through a normalisation: with gn.stats != nullptr the addend is silu(GroupNorm(add)) -- the tail of a ResnetBlock
+// with a projected skip, y = silu(GN(h2)) + conv1x1(x) (reference ddpm.py:176,197), in ONE pass: the skip tensor is never
+// written or re-read.  Same arithmetic as gn_apply_kernel (tdx_groupnorm.hip): n = fma(h, rstd gamma, beta - mean rstd gamma).
+struct Conv1GnAdd {
+    const float* stats;   // [B][G][2] (mean, rstd), or nullptr: plain addend
+    const float* gamma;   // [Cout]
+    const float* beta;    // [Cout]
+    int G;
+    int64_t V;            // voxels per sample (rows = B V)
+};
+
 template <int NT>
 __global__ void __launch_bounds__(256)
 conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                       const float* __restrict__ w, int ldw, const float* __restrict__ bias,
-                      const bf16* __restrict__ add, bf16* __restrict__ y, int64_t rows, int Cout) {
+                      const bf16* __restrict__ add, bf16* __restrict__ y, int64_t rows, int Cout, Conv1GnAdd gn) {
     constexpr int BN = 32 * NT;
     // LDS: staging (x slice 16 KB + w slice BN*64 B) and the output tile [256][64] bf16 (32 KB)
     // share one region
@@ -167,6 +178,16 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
                     Vec8<bf16> a, b;
                     a.load(reinterpret_cast<const bf16*>(&v));
                     b.load(add + off);
+                    if (gn.stats != nullptr) {
+                        const int bs = (int)(rr / gn.V), cb = n0 + np * 32 + c * 8, cpg = Cout / gn.G;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float2 st = *reinterpret_cast<const float2*>(gn.stats + ((size_t)bs * gn.G + (cb + e) / cpg) * 2);
+                            const float gam = gn.gamma[cb + e];
+                            const float ka = st.y * gam * 1.0f, c0 = gn.beta[cb + e] - st.x * st.y * gam;
+                            b.v[e] = silu_f(__builtin_fmaf(b.v[e], ka, c0));
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) a.v[e] += b.v[e];
                     a.store(y + off);
@@ -179,12 +200,14 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
 }
 
 int conv1_mfma_fwd_launch(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
-                          const void* add, void* y, int64_t rows, int Cout, hipStream_t st) {
+                          const void* add, void* y, int64_t rows, int Cout, hipStream_t st, const float* gn_stats,
+                          const float* gn_gamma, const float* gn_beta, int gn_groups, int64_t gn_voxels) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;  // NT = 4 needs 270 registers: 1 wave/SIMD, too few loads in flight
     dim3 grid(ceil_div(rows, C1M_ROWS), Cout / (32 * NT));
+    const Conv1GnAdd gn = {gn_stats, gn_gamma, gn_beta, gn_groups, gn_voxels};
 #define C1M_LAUNCH(NTV)                                                                                             \
     hipLaunchKernelGGL((conv1_mfma_fwd_kernel<NTV>), grid, dim3(256), 0, st, (const bf16*)x1, C1, (const bf16*)x2, \
-                       C2, w, ldw, bias, (const bf16*)add, (bf16*)y, rows, Cout)
+                       C2, w, ldw, bias, (const bf16*)add, (bf16*)y, rows, Cout, gn)
     if (NT == 2) C1M_LAUNCH(2); else C1M_LAUNCH(1);
 #undef C1M_LAUNCH
     return tdx_launch_status();

@@ -47,6 +47,7 @@ SIGNATURES = {
     "tdx_conv3_bwd_weight_workspace_bytes": (_sz, [_i, _i, _i]),
     "tdx_conv3_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "tdx_conv1_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "tdx_conv1_fwd_gn": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i64, _i, _i, _vp]),
     "tdx_conv1_bwd_weight": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i64, _i, _vp]),
     "tdx_conv1_bwd_weight_oc": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp]),
     "tdx_encode_fwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _vp]),

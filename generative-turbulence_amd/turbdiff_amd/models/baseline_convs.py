@@ -4,7 +4,9 @@
 (turbdiff/models/tfnet.py:185-208), with the reference's parameter containers (``nn.Conv3d`` /
 ``nn.ConvTranspose3d`` / ``nn.BatchNorm3d`` in the same attribute paths, so ``state_dict``s are interchangeable)
 and NDHWC activations ``(B, X, Y, Z, C)`` executed by ``ops.conv3d`` / ``ops.conv_transpose3d``.  These layers are
-off the benchmark path: vector-ALU kernels, no fusion beyond the bias.  ``to_ndhwc`` / ``to_ncdhw`` convert at a
+off the benchmark path: bf16 tensors run the matrix-core gather / transposed / weight-gradient kernels of
+``csrc/tdx_convg_mfma.hip`` (unstaged 16-B fragment loads; 20x the vector-ALU kernels, 2-60x MIOpen on the same GPU),
+fp32 tensors the vector-ALU family of ``csrc/tdx_convg.hip``; no fusion beyond the bias.  ``to_ndhwc`` / ``to_ncdhw`` convert at a
 model boundary (``ops.to_nvc`` / ``ops.to_ncv``)."""
 
 from __future__ import annotations

@@ -159,11 +159,74 @@ class SampleStore:
     def reset(self):
         self._cases.clear()
 
-    def save(self, path=None):
+    def save(self, path=None, opener=None):
+        """``.h5`` / ``.hdf5``: the reference's samples file (``save_h5``); anything else: one ``.npz`` with the arrays
+        ``<case>/<variable>``."""
         import numpy as np
 
         path = path or self.samples_file
+        if str(path).endswith((".h5", ".hdf5")):
+            return self.save_h5(path, opener=opener)
         arrays = {f"{case}/{v.name.lower()}": torch.cat(parts).numpy()
                   for case, per_var in self._cases.items() for v, parts in per_var.items() if parts}
         np.savez(path, **arrays)
         return path
+
+    def save_h5(self, path=None, opener=None):
+        """Append the stored samples to an HDF5 samples file laid out as the reference's ``SampleStore.add_samples``
+        writes it (metrics.py:60-88): group ``<case>/data`` with one resizable dataset per variable, ``(n_samples, n_cells,
+        dims)`` float32 chunked one sample per chunk, and the attribute ``n_samples``; a file that already holds
+        samples of a case grows.  ``opener(path, mode)``: a context manager with h5py's File interface (default:
+        ``h5py.File``, imported here -- the build image has none)."""
+        from pathlib import Path
+
+        path = path or self.samples_file
+        op = opener or _open_h5py
+        if opener is None:
+            Path(path).parent.mkdir(parents=True, exist_ok=True)
+        with op(path, "a") as f:
+            for case, per_var in self._cases.items():
+                data_group = f.require_group(case).require_group("data")
+                n_prev = int(data_group.attrs.get("n_samples", 0))
+                n_new = 0
+                for v, parts in per_var.items():
+                    if not parts:
+                        continue
+                    arr = torch.cat(parts).numpy()  # (n, n_cells, dims): scalars keep their unit axis, as torch.split leaves it
+                    n_new = arr.shape[0]
+                    name = v.name.lower()
+                    if name not in data_group:
+                        data_group.create_dataset(name, data=arr, chunks=arr[:1].shape, maxshape=(None, *arr.shape[1:]))
+                    else:
+                        ds = data_group[name]
+                        if ds.shape[0] < n_prev + n_new:
+                            ds.resize(n_prev + n_new, axis=0)
+                        ds[n_prev : n_prev + n_new] = arr
+                data_group.attrs["n_samples"] = n_prev + n_new
+        return path
+
+    @classmethod
+    def from_h5(cls, path, variables, opener=None):
+        """A store holding every case of a samples file written by the reference's store or by ``save_h5``."""
+        import numpy as np
+
+        store = cls(path, variables)
+        with (opener or _open_h5py)(path, "r") as f:
+            for case in f.keys():
+                data_group = f[case]["data"]
+                n = int(data_group.attrs.get("n_samples", -1))
+                per = {}
+                for v in store.variables:
+                    t = torch.tensor(np.array(data_group[v.name.lower()]))
+                    per[v] = [t[:n] if n >= 0 else t]
+                store._cases[case] = per
+        return store
+
+
+def _open_h5py(path, mode="r"):
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError("HDF5 sample files need h5py (pip install h5py), or pass opener= (an object with h5py's File "
+                          "interface); SampleStore.save('x.npz') needs nothing") from e
+    return h5py.File(path, mode)

@@ -766,6 +766,9 @@ def film_projections(c: torch.Tensor, linears) -> list:
 _SIDE = {}  # device index -> side stream of the weight gradients
 
 
+# TDX_FUSE_SKIP_TAIL=0: the projected skip of a fused ResnetBlock as two launches (1x1 conv into a temporary, then the
+# GroupNorm / SiLU / add pass) instead of tdx_conv1_fwd_gn's one (A/B switch, read at import)
+FUSE_SKIP_TAIL = os.environ.get("TDX_FUSE_SKIP_TAIL", "1") != "0"
 WGRAD_STREAM = os.environ.get("TDX_WGRAD_STREAM", "1") != "0"  # read once (bench.py / tests set it before the import)
 
 
@@ -877,17 +880,25 @@ class _ResnetBlock(torch.autograd.Function):
                B, V, Cout, groups, 1, code, st)
         h2, st2 = conv_gn(a1, Cout, None, 0, wf2, b2)
         wr2 = None
+        y = torch.empty_like(h1)
+        fused_tail = False
         if wr is None:
             assert x2 is None and Cin == Cout
             res = x1
         else:
             wr2 = wr.detach().reshape(Cout, Cin).contiguous()
-            res = torch.empty_like(h1)
-            L.call("tdx_conv1_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(_conv1_wt(wr)), Cout, L.ptr(br), None,
-                   L.ptr(res), B * V, Cout, code, st)
-        y = torch.empty_like(h1)
-        L.call("tdx_gn_apply", L.ptr(h2), L.ptr(st2), L.ptr(g2), L.ptr(be2), None, None, L.ptr(res), L.ptr(y), B, V, Cout,
-               groups, 1, code, st)
+            if FUSE_SKIP_TAIL and dt == torch.bfloat16 and C1 % 32 == 0 and C2 % 32 == 0 and Cout % 32 == 0:
+                # y = silu(GN(h2)) + conv1x1([x1|x2]) in one pass: the skip tensor is never written or re-read
+                L.call("tdx_conv1_fwd_gn", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(_conv1_wt(wr)), Cout, L.ptr(br), L.ptr(h2),
+                       L.ptr(st2), L.ptr(g2), L.ptr(be2), groups, L.ptr(y), B, V, Cout, code, st)
+                fused_tail = True
+            else:
+                res = torch.empty_like(h1)
+                L.call("tdx_conv1_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(_conv1_wt(wr)), Cout, L.ptr(br), None,
+                       L.ptr(res), B * V, Cout, code, st)
+        if not fused_tail:
+            L.call("tdx_gn_apply", L.ptr(h2), L.ptr(st2), L.ptr(g2), L.ptr(be2), None, None, L.ptr(res), L.ptr(y), B, V, Cout,
+                   groups, 1, code, st)
         ctx.save_for_backward(x1, x2, h1, st1, a1, h2, st2, film, g1, be1, g2, be2, wb1, wb2, wr2, xc)
         ctx.cfg = (groups, tuple(w1.shape), tuple(w2.shape), None if wr is None else tuple(wr.shape),
                    b1 is not None, b2 is not None, br is not None)

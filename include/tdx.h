@@ -196,6 +196,15 @@ int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int C2, const v
  * x2/add/bias may be NULL. */
 int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
                   const void* add, void* y, int64_t rows, int Cout, int dtype, void* stream);
+/* The tail of a ResnetBlock with a projected skip in one pass (ddpm.py:176 + 188 + 197):
+ *   y[b, v, :] = silu(GroupNorm(h)[b, v, :]) + bias + x1[b, v, :] @ w[0:C1, :] + x2[b, v, :] @ w[C1:, :]
+ * h: the block's second conv output (B, V, Cout), stats: its (B, groups, 2) mean / rstd from tdx_conv3_fwd_gn, gamma /
+ * beta: the GroupNorm affine.  Same arithmetic as tdx_conv1_fwd(..., add = NULL) into a temporary followed by
+ * tdx_gn_apply(h, ..., res = temporary, act = 1), without writing or re-reading the temporary.  bf16 tensors on the
+ * matrix-core kernel only: TDX_EDTYPE / TDX_ESHAPE otherwise (run the two calls). */
+int tdx_conv1_fwd_gn(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
+                     const void* h, const float* stats, const float* gamma, const float* beta, int groups, void* y,
+                     int B, int64_t V, int Cout, int dtype, void* stream);
 /* dw[ci][co] (+)= sum_r x[r, ci] dy[r, co]  (f32, [Cin][ldw]); dbias[co] = sum_r dy[r, co].
  * Overwrites (buffers are zeroed inside).  x has Cin channels (call twice for a concat). */
 int tdx_conv1_bwd_weight(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,

@@ -28,6 +28,22 @@ class Dataset:
     def shape(self):
         return self.data.shape
 
+    # -- the write side used by models.metrics.SampleStore.save_h5 (h5py.Dataset.resize / __setitem__)
+    def resize(self, size, axis=0):
+        assert self.maxshape is not None and self.maxshape[axis] is None, "only a dataset created resizable can grow"
+        new = list(self.data.shape)
+        new[axis] = size
+        grown = np.zeros(new, dtype=self.data.dtype)
+        sl = tuple(slice(0, min(a, b)) for a, b in zip(self.data.shape, new))
+        grown[sl] = self.data[sl]
+        self.data = grown
+
+    def __setitem__(self, idx, value):
+        self.data[idx] = value
+
+    maxshape = None
+    chunks = None
+
 
 class Group:
     def __init__(self):
@@ -59,9 +75,23 @@ class Group:
             node = node.children.setdefault(part, Group())
         return node
 
+    # -- the write side of h5py.Group
+    require_group = group
+
+    def __contains__(self, name):
+        return name in self.children
+
+    def create_dataset(self, name, data=None, chunks=None, maxshape=None):
+        assert name not in self.children
+        ds = self.children[name] = Dataset(np.array(data, copy=True))
+        ds.chunks, ds.maxshape = chunks, maxshape
+        return ds
+
 
 class File:
     def __init__(self, path, mode="r"):
+        if mode in ("a", "w") and (mode == "w" or str(path) not in TREES):
+            TREES[str(path)] = Group()
         self.root = TREES[str(path)]
 
     def __enter__(self):
@@ -121,3 +151,23 @@ def install_cases(root_dir="/fake", phases=("train", "val"), per_phase=2):
             out[phase].append(path)
             seed += 1
     return out
+
+
+def dump_to_h5py(tree: Group, path):
+    """Write a fake tree as a REAL HDF5 file (needs h5py: tests that call this importorskip it): the same groups,
+    datasets and attributes, so the reader can be run over real files wherever h5py exists."""
+    import h5py
+
+    def rec(src, dst):
+        for k, v in src.attrs.items():
+            dst.attrs[k] = v
+        for name, child in src.children.items():
+            if isinstance(child, Group):
+                rec(child, dst.require_group(name))
+            else:
+                ds = dst.create_dataset(name, data=child.data)
+                for k, v in child.attrs.items():
+                    ds.attrs[k] = v
+
+    with h5py.File(path, "w") as f:
+        rec(tree, f)

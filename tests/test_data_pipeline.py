@@ -296,3 +296,90 @@ def test_data_module_builds_datasets_and_loaders():
         d2.setup("fit", stats=stats)
         shards.append([tuple(np.round(b.data.t.numpy(), 4)) + (b.data.metadata.case_name,) for b in d2.train_dataloader()])
     assert len(shards[0]) == len(shards[1]) and not set(shards[0]) & set(shards[1])
+
+
+def _store_with_samples(seed=0):
+    from turbdiff_amd.data.ofles import OpenFOAMMetadata, Variable
+    from turbdiff_amd.models.metrics import SampleStore
+
+    import numpy as np
+
+    g = torch.Generator().manual_seed(seed)
+    V = (Variable.U, Variable.P)
+    store = SampleStore(None, V)
+    metas = []
+    for i, n_cells in enumerate((37, 50)):
+        md = OpenFOAMMetadata(cell_counts=np.array([6, 5, 4]), cell_idx=torch.arange(n_cells), boundaries={}, boundary_conditions={},
+                              file=Path(f"/x/case-{i:02d}/data.h5"))
+        metas.append(md)
+        for b in (2, 3):  # two batches per case
+            store.add_cells({Variable.U: torch.randn(b, n_cells, 3, generator=g), Variable.P: torch.randn(b, n_cells, 1, generator=g)}, md)
+    return store, metas, V
+
+
+def test_sample_store_hdf5_layout_over_the_h5py_interface():
+    """SampleStore.save_h5 writes the reference's samples file (metrics.py:60-88): <case>/data/<variable> resizable
+    datasets (n_samples, n_cells, dims), one sample per chunk, attribute n_samples, appending to cases the file already
+    holds; from_h5 reads it back.  Through tests/h5fake.py (h5py's File / Group / Dataset interface; the image has no
+    h5py) -- the same code runs over real files in test_sample_store_and_reader_over_real_hdf5_files."""
+    import h5fake
+    from turbdiff_amd.models.metrics import SampleStore
+
+    store, metas, V = _store_with_samples()
+    path = "/fake/samples/val.h5"
+    h5fake.TREES.pop(path, None)
+    store.save(path, opener=h5fake.File)
+    root = h5fake.TREES[path]
+    assert sorted(root.keys()) == sorted(md.case_name for md in metas)
+    for md in metas:
+        dg = root[md.case_name]["data"]
+        assert dg.attrs["n_samples"] == 5 and sorted(dg.keys()) == ["p", "u"]
+        assert dg["u"].shape == (5, md.cell_idx.numel(), 3) and dg["p"].shape == (5, md.cell_idx.numel(), 1)
+        assert dg["u"].chunks == (1, md.cell_idx.numel(), 3) and dg["u"].maxshape == (None, md.cell_idx.numel(), 3)
+        assert dg["u"].data.dtype == np.float32
+    # a second save appends (the reference's add_samples grows the datasets)
+    store.save_h5(path, opener=h5fake.File)
+    assert root[metas[0].case_name]["data"].attrs["n_samples"] == 10 and root[metas[0].case_name]["data"]["u"].shape[0] == 10
+    back = SampleStore.from_h5(path, V, opener=h5fake.File)
+    for md in metas:
+        a, b = back.load_samples(md).samples, store.load_samples(md).samples
+        for v in V:
+            assert torch.equal(a[v][:5], b[v]) and torch.equal(a[v][5:], b[v])
+    assert back.load_samples(metas[1], range=3).samples[V[0]].shape == (1, 50, 3)
+
+
+def test_sample_store_and_reader_over_real_hdf5_files(tmp_path):
+    """Wherever h5py exists (not in the build image): (i) the samples file round-trips through real HDF5 and h5py itself
+    sees the reference's layout; (ii) OpenFOAMDataRepository with its DEFAULT opener reads a real data.h5 written from
+    the same seeded case tree the in-memory stand-in serves, and returns the same metadata and rows."""
+    h5py = pytest.importorskip("h5py")
+    import h5fake
+    from turbdiff_amd.data.ofles import OpenFOAMDataRepository, Variable
+    from turbdiff_amd.models.metrics import SampleStore
+
+    store, metas, V = _store_with_samples(seed=4)
+    path = tmp_path / "samples" / "test.h5"
+    store.save(path)
+    store.save_h5(path)
+    with h5py.File(path, "r") as f:
+        ds = f[metas[0].case_name]["data"]["u"]
+        assert ds.shape == (10, 37, 3) and ds.chunks == (1, 37, 3) and ds.maxshape == (None, 37, 3)
+        assert f[metas[0].case_name]["data"].attrs["n_samples"] == 10
+    back = SampleStore.from_h5(path, V)
+    assert torch.equal(back.load_samples(metas[1]).samples[V[1]][:5], store.load_samples(metas[1]).samples[V[1]])
+    # (ii) the case-file reader over a real file vs over the stand-in
+    tree = h5fake.make_case(3, counts=(9, 7, 6), n_times=12)
+    real = tmp_path / "train" / "case-00" / "data.h5"
+    real.parent.mkdir(parents=True)
+    h5fake.dump_to_h5py(tree, real)
+    h5fake.TREES[str(real)] = tree
+    vars_ = (Variable.U, Variable.P, Variable.NUT)
+    a = OpenFOAMDataRepository([real], vars_)                      # h5py.File
+    b = OpenFOAMDataRepository([real], vars_, opener=h5fake.File)   # the stand-in
+    assert np.array_equal(a.times[0], b.times[0])
+    idx = [7, 2, 2, 11, 0]  # unsorted with a duplicate: the reader sorts / uniquifies for HDF5 and spreads back
+    da, db = a.read(0, idx), b.read(0, idx)
+    for v in vars_:
+        assert torch.equal(da.samples[v], db.samples[v])
+    assert torch.equal(da.metadata.cell_idx, db.metadata.cell_idx) and da.metadata.nu == db.metadata.nu
+    assert sorted(da.metadata.boundaries) == sorted(db.metadata.boundaries)

@@ -1050,6 +1050,47 @@ def test_persistent_kernels_on_fewer_cus(case, cus, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,V,C1,C2,Co", [(2, 1000, 64, 0, 128), (3, 777, 64, 64, 32), (1, 256, 32, 0, 32), (6, 4097, 128, 128, 64)])
+def test_conv1_fused_with_groupnorm_tail(B, V, C1, C2, Co):
+    """tdx_conv1_fwd_gn -- y = silu(GN(h)) + bias + [x1|x2] @ w, the tail of a ResnetBlock with a projected skip
+    (reference ddpm.py:176,188,197) in one pass -- against the two calls it replaces (tdx_conv1_fwd into a temporary,
+    tdx_gn_apply with that residual): same arithmetic, so equal up to the last bf16 bit of a few elements (fp32
+    contraction of the coefficient), and against a float64 evaluation of the formula.  Rows not a multiple of the
+    256-row tile, sample boundaries inside a tile, one / two inputs, 32- and 64-wide channel tiles."""
+    from turbdiff_amd import _lib as L
+
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(3)
+    rn = lambda *s: torch.randn(*s, device=d, generator=g)
+    dt, DT, G = torch.bfloat16, L.BF16, 8
+    x1, x2 = rn(B, V, C1).to(dt), (rn(B, V, C2).to(dt) if C2 else None)
+    w, bias = rn(C1 + C2, Co) * (C1 + C2) ** -0.5, rn(Co)
+    h = (rn(B, V, Co) * 1.7 + 0.3).to(dt)
+    gamma, beta = rn(Co) * 0.5 + 1.0, rn(Co) * 0.2
+    hf = h.float().view(B, V, G, Co // G)
+    mean = hf.mean(dim=(1, 3))
+    rstd = (hf.var(dim=(1, 3), unbiased=False) + 1e-5).rsqrt()
+    stats = torch.stack((mean, rstd), dim=-1).contiguous()
+    st = L.stream()
+    y = torch.empty(B, V, Co, device=d, dtype=dt)
+    L.call("tdx_conv1_fwd_gn", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(w), Co, L.ptr(bias), L.ptr(h), L.ptr(stats), L.ptr(gamma),
+           L.ptr(beta), G, L.ptr(y), B, V, Co, DT, st)
+    res, y2 = torch.empty_like(y), torch.empty_like(y)
+    L.call("tdx_conv1_fwd", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(w), Co, L.ptr(bias), None, L.ptr(res), B * V, Co, DT, st)
+    L.call("tdx_gn_apply", L.ptr(h), L.ptr(stats), L.ptr(gamma), L.ptr(beta), None, None, L.ptr(res), L.ptr(y2), B, V, Co, G, 1, DT, st)
+    torch.cuda.synchronize()
+    assert rel_l2(y.float(), y2.float()) < 1e-3 and (y != y2).float().mean() < 0.01
+    xr = torch.cat([x1] + ([x2] if C2 else []), dim=-1).double()
+    n = (h.double().view(B, V, G, -1) - mean.double()[:, None, :, None]) * rstd.double()[:, None, :, None]
+    n = n.view(B, V, Co) * gamma.double() + beta.double()
+    ref = n * torch.sigmoid(n) + (xr @ w.to(dt).double() + bias.double()).to(dt).double()
+    assert rel_l2(y.float(), ref.float()) < 6e-3
+    # fp32 tensors: not this kernel's (the caller runs the two launches)
+    assert L.load().tdx_conv1_fwd_gn(L.ptr(x1), C1, None, 0, L.ptr(w), Co, None, L.ptr(h), L.ptr(stats), L.ptr(gamma), L.ptr(beta),
+                                     G, L.ptr(y), B, V, Co, L.F32, st) == -3
+
+
+@pytest.mark.gpu
 def test_scratch_arena_is_per_stream():
     """The library holds one arena pointer, bound per launch to the launching stream's arena (_lib.ensure_scratch): convs
     that use it (K-split slabs of the small-grid kernel) run concurrently on two streams, many times over, with different
