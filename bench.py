@@ -414,6 +414,8 @@ def main():
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="fused: ClipRAdam (clip + RAdam in 3 launches); torch: clip_grad_norm_ + torch.optim.RAdam")
     ap.add_argument("--compress", default=None, choices=[None, "bf16"], help="N > 1: gradients travel as bf16")
+    ap.add_argument("--persistent-cus", type=int, default=224,
+                    help="N > 1: CUs the persistent conv kernels occupy (TDX_PERSISTENT_CUS; the rest is left to RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-parity-modes", action="store_true", help="skip the f32s / f32 legs of extra.parity_modes")
@@ -437,6 +439,12 @@ def main():
     if os.environ.get("TDX_BENCH_ONE_DEVICE") == "1":
         local = 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        # The ring conv / producer-consumer weight-gradient kernels launch one workgroup per CU and fill its registers and
+        # LDS; RCCL's kernels need CUs of their own, and a persistent launch that finds some taken runs in two rounds.
+        # Under data parallelism they therefore use 224 of the 256 CUs (28 per XCD) unless the caller chose a number
+        # (single-GPU cost: profiles/r11_persistent_cus_ab.txt; --persistent-cus 256 restores the full chip).
+        os.environ.setdefault("TDX_PERSISTENT_CUS", str(args.persistent_cus))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -579,6 +587,7 @@ def main():
         # still had to wait for (the part of the all-reduce backward did not hide)
         exposed_ev = ddp.exposed_ms()
         bwd_ms = [a.elapsed_time(b) for a, b in bwd_events]
+        per_bucket = ddp.bucket_report([a for a, _ in bwd_events])
         ddp.enabled = False
         barrier()
         t0 = time.perf_counter()
@@ -603,6 +612,11 @@ def main():
                                       "mean over the timed steps, max over ranks",
                             "hidden_fraction": (1.0 - exposed / t_comm) if t_comm > 0 else None,
                             "buckets": ddp.bucket_layout(), "compress": args.compress,
+                            # per bucket: when in backward its all-reduce was enqueued, how long it takes alone, what
+                            # finish() still waited for it, and the fraction backward hid
+                            "per_bucket": [dict(r, alone_ms=a, hidden_fraction=(1.0 - r["exposed_ms"] / a) if a > 0 else None)
+                                           for r, a in zip(per_bucket, ddp.allreduce_alone_ms())],
+                            "persistent_cus": int(os.environ.get("TDX_PERSISTENT_CUS", "256")),
                             "payload_MB": sum(b for _, b in (ddp.bucket_layout() or [])) / 1e6}
 
     # ---- the modes that meet the 1e-4 parity gate, same run, same model (N = 1 only: they are not scaling legs)

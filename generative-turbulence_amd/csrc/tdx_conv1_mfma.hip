@@ -324,19 +324,35 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfv[n], acc[m][n], 0, 0, 0);
         }
     }
+    // ---- merge.  Each wave holds a private (32 MT) x (32 NT) tile: the four are summed through LDS first (fixed order), so
+    // that a workgroup issues one tile's worth of atomics instead of four -- on the deep U-Net levels, where a workgroup
+    // walks one or two row chunks, the atomics WERE the kernel (32 MB per launch at the chip's 1.3 TB/s of atomic adds:
+    // 45-50 us per launch whatever the batch, profiles/r11_batch_scaling.txt).
     const int r = lane & 31, hh = lane >> 5;
+    constexpr int TILE_F = (32 * MT) * (32 * NT);              // floats per tile; 4 tiles = (MT NT) x 16 KB <= the staging LDS
+    static_assert(4 * TILE_F * 4 <= (MT + NT) * C1W_PLANE, "the four wave tiles fit the staging buffers");
+    __syncthreads();                                            // everybody is done reading the last chunk
+    float* tiles = reinterpret_cast<float*>(smem);              // [wave][row of the result][col]
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int q = (i & 3) + 8 * (i >> 2) + 4 * hh;  // the tile row this accumulator register holds
-                if (TR)
-                    atomicAdd(&dw[(size_t)(co0 + n * 32 + q) * ldw + ci0 + m * 32 + r], acc[m][n][i]);
-                else
-                    atomicAdd(&dw[(size_t)(ci0 + m * 32 + q) * ldw + co0 + n * 32 + r], acc[m][n][i]);
+                const int q = (i & 3) + 8 * (i >> 2) + 4 * hh;  // the MFMA tile row this accumulator register holds
+                // result row / column: TR stores dw[co][ci] (rows = co), else dw[ci][co]
+                const int rr = TR ? n * 32 + q : m * 32 + q, cc = TR ? m * 32 + r : n * 32 + r;
+                tiles[(wave * (TR ? 32 * NT : 32 * MT) + rr) * (TR ? 32 * MT : 32 * NT) + cc] = acc[m][n][i];
             }
+    __syncthreads();
+    {
+        constexpr int ROWS = TR ? 32 * NT : 32 * MT, COLS = TR ? 32 * MT : 32 * NT;
+        const int row_base = TR ? co0 : ci0, col_base = TR ? ci0 : co0;
+        for (int e = tid; e < ROWS * COLS; e += 256) {
+            const float t = (tiles[e] + tiles[ROWS * COLS + e]) + (tiles[2 * ROWS * COLS + e] + tiles[3 * ROWS * COLS + e]);
+            atomicAdd(&dw[(size_t)(row_base + e / COLS) * ldw + col_base + e % COLS], t);
+        }
+    }
     if (do_bias) {
         // threads with equal (tid & 3, (tid >> 2) % NT) hold partial sums of the same 8 channels
         __syncthreads();

@@ -39,7 +39,10 @@ def _clean_ws(nbytes: int, device, tag=None) -> torch.Tensor:
     it zero and leave it zero, so a training step launches no memsets for accumulator buffers."""
     if not WS_CLEAN:
         return _ws(nbytes, device)
-    key = (str(device), int(nbytes), tag)  # tag: buffers are shared only by calls with the same internal layout
+    # tag: buffers are shared only by calls with the same internal layout; and only by calls issued from the same
+    # stream: two streams (two captured graphs, two threads) running the same layer concurrently must not meet in one
+    # accumulator buffer
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, int(nbytes), tag)
     buf = _CLEAN.get(key)
     if buf is None:
         buf = _CLEAN[key] = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=device)

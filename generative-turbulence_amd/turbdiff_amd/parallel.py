@@ -104,6 +104,8 @@ class BucketedDataParallel:
         self.stats = {"wait_s": 0.0, "steps": 0}
         self.timing = False                            # True: finish() brackets its waits with events on the compute stream
         self._wait_events: list = []
+        self._bucket_events: list = []                 # timing: per step {bucket: (launch event, wait start, wait end)}
+        self._step_launch: dict = {}
         if self.active and broadcast:
             with torch.no_grad():
                 for p in self.params:
@@ -206,6 +208,10 @@ class BucketedDataParallel:
         else:
             self._work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), b))
         self._launched.add(b)
+        if self.timing and flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()  # on the compute stream: where in backward this bucket's collective was enqueued
+            self._step_launch[b] = ev
 
     # -- per-step API ----------------------------------------------------------------------
     def finish(self):
@@ -233,13 +239,23 @@ class BucketedDataParallel:
             # (and widens the bf16 wire buffers); everything enqueued before e0 is backward work
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        per_bucket = {}
         for w, b in self._work:
+            if timed:
+                w0 = torch.cuda.Event(enable_timing=True)
+                w0.record()
             w.wait()
             if self.compress == "bf16":
                 self._flat[b].copy_(self._wire[b])
+            if timed:
+                w1 = torch.cuda.Event(enable_timing=True)
+                w1.record()
+                per_bucket[b] = (self._step_launch.get(b), w0, w1)
         if timed:
             e1.record()
             self._wait_events.append((e0, e1))
+            self._bucket_events.append(per_bucket)
+        self._step_launch = {}
         self.stats["wait_s"] += time.perf_counter() - t0
         self.stats["steps"] += 1
         self._work.clear()
@@ -253,6 +269,50 @@ class BucketedDataParallel:
         torch.cuda.synchronize()
         out = [a.elapsed_time(b) for a, b in self._wait_events]
         self._wait_events.clear()
+        return out
+
+    def bucket_report(self, backward_start_events=None) -> list:
+        """Per bucket, averaged over the timed steps since the last call: what finish() still had to wait for it on the
+        compute stream (`exposed_ms`) and, with the events bench.py records in front of every backward(), how far into
+        backward its all-reduce was enqueued (`enqueued_at_ms`).  Needs ``timing = True``; synchronises."""
+        torch.cuda.synchronize()
+        steps, self._bucket_events = self._bucket_events, []
+        if not steps or self._buckets is None:
+            return []
+        layout = self.bucket_layout()
+        out = []
+        for b in range(len(self._buckets)):
+            exposed, at = [], []
+            for k, per in enumerate(steps):
+                if b not in per:
+                    continue
+                launch, w0, w1 = per[b]
+                exposed.append(w0.elapsed_time(w1))
+                if launch is not None and backward_start_events is not None and k < len(backward_start_events):
+                    at.append(backward_start_events[k].elapsed_time(launch))
+            out.append({"bucket": b, "params": layout[b][0], "bytes": layout[b][1],
+                        "exposed_ms": sum(exposed) / max(len(exposed), 1),
+                        "enqueued_at_ms": (sum(at) / len(at)) if at else None})
+        return out
+
+    def allreduce_alone_ms(self, repeats: int = 3) -> list:
+        """Each bucket's all-reduce by itself (nothing else on the GPU), ms, averaged over `repeats`: the denominator
+        of a per-bucket hidden fraction."""
+        if not self.active or self._buckets is None:
+            return []
+        out = []
+        for b in range(len(self._buckets)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(repeats):
+                self._launch(b)
+                for w, _b in self._work:
+                    w.wait()
+                self._work.clear()
+                self._launched.clear()
+            torch.cuda.synchronize()
+            out.append(1e3 * (time.perf_counter() - t0) / repeats)
+        self._step_launch = {}
         return out
 
     def allreduce_only(self):

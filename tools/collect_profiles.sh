@@ -12,7 +12,10 @@ cd /tmp; export TMPDIR=/tmp
 # for the profiled runs (in the product they run on a side stream beside the data-gradient chain -- ops._WgradSide -- and a
 # kernel trace then charges each of two concurrent kernels the whole overlapped span).  The forward launches that
 # bench.py's roofline is quoted on have nothing beside them either way.
-export TDX_WGRAD_STREAM=${TDX_WGRAD_STREAM:-0}
+# TDX_PROFILE_SIDE_STREAM=1 collects the same set with the product's default (side stream on) for comparison; the
+# summariser notes which of the two a set is.
+export TDX_PROFILE_SIDE_STREAM=${TDX_PROFILE_SIDE_STREAM:-0}
+export TDX_WGRAD_STREAM=${TDX_WGRAD_STREAM:-$TDX_PROFILE_SIDE_STREAM}
 BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra ${TDX_BENCH_ARGS:-}"
 # (1) per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
