@@ -43,21 +43,35 @@ __device__ __forceinline__ void block_channel_reduce(float (&s)[NQ][8], int L, i
 
 template <typename T>
 __global__ void __launch_bounds__(GN_THREADS)
-gn_stats_kernel(const T* __restrict__ x, double* __restrict__ acc, int64_t V, int C) {
+gn_stats_kernel(const T* __restrict__ x, double* __restrict__ acc, int64_t V, int C, int vpb) {
     const int b = blockIdx.y;
     const int L = C >> 3;
     const int rows = GN_THREADS / L;
     const int tid = threadIdx.x;
     const int lc = tid % L, r = tid / L;
     const bool active = r < rows;
-    const int64_t v0 = (int64_t)blockIdx.x * GN_VOX_PER_BLOCK;
-    const int64_t v1 = min(V, v0 + GN_VOX_PER_BLOCK);
+    const int64_t v0 = (int64_t)blockIdx.x * vpb;
+    const int64_t v1 = min(V, v0 + vpb);
     float s[2][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[0][j] = s[1][j] = 0.f;
     if (active) {
         const T* xb = x + ((int64_t)b * V) * C + lc * 8;
-        for (int64_t v = v0 + r; v < v1; v += rows) {
+        int64_t v = v0 + r;
+        // four independent loads in flight per trip (a rolled load / add loop is a chain of memory round trips: this pass
+        // runs on the tiny tensors of the deep levels, where latency is all it costs)
+        for (; v + 3 * rows < v1; v += 4 * rows) {
+            Raw8<T> a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u].load(xb + (v + u * rows) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const Vec8<T> t = a[u].get();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[0][j] += t.v[j]; s[1][j] += t.v[j] * t.v[j]; }
+            }
+        }
+        for (; v < v1; v += rows) {
             Vec8<T> a;
             a.load(xb + v * C);
 #pragma unroll
@@ -123,9 +137,14 @@ extern "C" int tdx_gn_stats(const void* x, float* stats, int B, int64_t V, int C
     double* acc = (double*)workspace;
     hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * C * 2 * sizeof(double), as_stream(stream));
     if (e != hipSuccess) return (int)e;
-    dim3 grid(ceil_div(V, GN_VOX_PER_BLOCK), B);
+    // voxels per block: 1024 on big tensors; on the small ones of the deep U-Net levels (where this pass is used: the
+    // small-grid conv kernels do not accumulate moments) enough blocks to put ~128 on the chip -- 12 blocks of 256 serial
+    // trips took 27 us for 7 MB, profiles/r11_batch_scaling.txt -- but not so many that the f64 atomics take over
+    int64_t vpb = ((int64_t)B * V + 127) / 128;
+    vpb = vpb < 32 ? 32 : (vpb > GN_VOX_PER_BLOCK ? GN_VOX_PER_BLOCK : (vpb + 31) / 32 * 32);
+    dim3 grid(ceil_div(V, vpb), B);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(GN_THREADS), 0, as_stream(stream),
-                                                  (const T*)x, acc, V, C));
+                                                  (const T*)x, acc, V, C, (int)vpb));
     hipLaunchKernelGGL(gn_stats_finalize, dim3(B * G), dim3(64), 0, as_stream(stream), acc, stats, B, C, G, V, eps, 1);
     return tdx_launch_status();
 }
