@@ -227,6 +227,45 @@ masked_loss_kernel(const float* __restrict__ e, const float* __restrict__ n, con
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
 }
+// the same pass with 16-B accesses, two independent trips in flight per thread (V % 4 == 0: every sample and feature
+// plane starts on a 16-B boundary).  The scalar kernel above walks 36 dependent-free but ROLLED trips of 4-B loads per
+// thread at 192 x 64 x 48: 67 us for 170 MB (profiles/r11_batch_scaling.txt); this one streams.
+__global__ void __launch_bounds__(256)
+masked_loss_vec_kernel(const float* __restrict__ e, const float* __restrict__ n, const uint8_t* __restrict__ mask, int l1,
+                       double* __restrict__ acc, float* __restrict__ grad, float gscale, int64_t V) {
+    const int64_t base = (int64_t)blockIdx.y * V;
+    const int64_t V4 = V >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    float s = 0.f;
+    auto one = [&](const float4& a, const float4& b, unsigned m, int64_t i) {
+        const float d[4] = {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w};
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            g[k] = 0.f;
+            if ((m >> (8 * k)) & 0xffu) {
+                if (l1) { s += fabsf(d[k]); g[k] = (d[k] > 0.f) ? gscale : ((d[k] < 0.f) ? -gscale : 0.f); }
+                else { s += d[k] * d[k]; g[k] = 2.0f * d[k] * gscale; }
+            }
+        }
+        if (grad) *reinterpret_cast<float4*>(grad + base + 4 * i) = make_float4(g[0], g[1], g[2], g[3]);
+    };
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < V4; i += 2 * stride) {
+        const float4 a0 = *reinterpret_cast<const float4*>(e + base + 4 * i), b0 = *reinterpret_cast<const float4*>(n + base + 4 * i);
+        const float4 a1 = *reinterpret_cast<const float4*>(e + base + 4 * (i + stride)), b1 = *reinterpret_cast<const float4*>(n + base + 4 * (i + stride));
+        const unsigned m0 = *reinterpret_cast<const unsigned*>(mask + 4 * i), m1 = *reinterpret_cast<const unsigned*>(mask + 4 * (i + stride));
+        one(a0, b0, m0, i);
+        one(a1, b1, m1, i + stride);
+    }
+    for (; i < V4; i += stride)
+        one(*reinterpret_cast<const float4*>(e + base + 4 * i), *reinterpret_cast<const float4*>(n + base + 4 * i),
+            *reinterpret_cast<const unsigned*>(mask + 4 * i), i);
+    __shared__ double part[4];
+    double ws = wave_sum((double)s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
 __global__ void masked_loss_finish(const double* acc, float* loss, double inv) { loss[0] = (float)(acc[0] * inv); }
 
 extern "C" size_t tdx_masked_loss_workspace_bytes(void) { return 16; }
@@ -236,9 +275,17 @@ extern "C" int tdx_masked_loss(const float* eps_hat, const float* noise, const u
     hipError_t err = hipMemsetAsync(workspace, 0, 16, as_stream(stream));
     if (err != hipSuccess) return (int)err;
     const double inv = 1.0 / ((double)B * F * (double)n_cells);
-    dim3 grid((unsigned)min((int64_t)64, (V + 255) / 256), B * F);
-    hipLaunchKernelGGL(masked_loss_kernel, grid, dim3(256), 0, as_stream(stream), eps_hat, noise, mask, l1,
-                       (double*)workspace, grad, (float)inv, V);
+    const bool vec = (V % 4) == 0 && ((uintptr_t)eps_hat % 16) == 0 && ((uintptr_t)noise % 16) == 0 && ((uintptr_t)mask % 4) == 0 &&
+                     (grad == nullptr || ((uintptr_t)grad % 16) == 0);
+    if (vec) {
+        dim3 grid((unsigned)min((int64_t)128, (V / 4 + 511) / 512), B * F);
+        hipLaunchKernelGGL(masked_loss_vec_kernel, grid, dim3(256), 0, as_stream(stream), eps_hat, noise, mask, l1,
+                           (double*)workspace, grad, (float)inv, V);
+    } else {
+        dim3 grid((unsigned)min((int64_t)64, (V + 255) / 256), B * F);
+        hipLaunchKernelGGL(masked_loss_kernel, grid, dim3(256), 0, as_stream(stream), eps_hat, noise, mask, l1,
+                           (double*)workspace, grad, (float)inv, V);
+    }
     hipLaunchKernelGGL(masked_loss_finish, dim3(1), dim3(1), 0, as_stream(stream), (const double*)workspace, loss, inv);
     return tdx_launch_status();
 }

@@ -15,6 +15,7 @@
 #include "tdx_common.h"
 
 #define GN_THREADS 256
+#define GN_MAX_BLOCKS 512  // streaming blocks per sample; bounds the backward partial-sum buffer
 #define GN_VOX_PER_BLOCK 1024
 
 // per-channel partial sums of two quantities, reduced over the block and added (f64 atomics)
@@ -91,13 +92,25 @@ gn_stats_finalize(double* __restrict__ acc, float* __restrict__ stats, int B, in
     const int b = i / G, g = i - b * G;
     const int cpg = C / G;
     double s = 0.0, ss = 0.0;
-    for (int k = threadIdx.x; k < R * cpg; k += 64) {
-        const int r = k / cpg, c = g * cpg + (k - r * cpg);
-        double* a = acc + (((size_t)r * B + b) * C + c) * 2;
-        s += a[0];
-        ss += a[1];
-        a[0] = 0.0;  // the accumulators are left all-zero for the next use (TDX_WS_CLEAN)
-        a[1] = 0.0;
+    // four (replica, channel) pairs per trip, their loads issued before the first add / clearing store (the stores may
+    // alias the loads as far as the compiler knows: a rolled loop is one memory round trip per pair)
+    for (int k0 = threadIdx.x; k0 < R * cpg; k0 += 4 * 64) {
+        double2 v[4];
+        double* a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(k0 + u * 64, R * cpg - 1);
+            const int r = k / cpg, c = g * cpg + (k - r * cpg);
+            a[u] = acc + (((size_t)r * B + b) * C + c) * 2;
+            v[u] = *reinterpret_cast<const double2*>(a[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * 64 < R * cpg) {
+                s += v[u].x;
+                ss += v[u].y;
+                *reinterpret_cast<double2*>(a[u]) = make_double2(0.0, 0.0);  // left all-zero for the next use (TDX_WS_CLEAN)
+            }
     }
     s = wave_sum(s);
     ss = wave_sum(ss);
@@ -196,7 +209,6 @@ __device__ __forceinline__ void gn_load_coef(GnCoef& k, float (&mean)[8], float 
 // flight, no branches between them); the grid is sized to about 8 resident blocks per CU so the
 // per-block set-up (coefficient loads) is paid once per ~MB streamed.
 #define GN_UNROLL 4
-#define GN_MAX_BLOCKS 512  // per sample; bounds the backward partial-sum buffer
 
 static int gn_blocks_per_sample(int B, int64_t V, int C) {
     const int rows = GN_THREADS / (C >> 3);
@@ -364,10 +376,17 @@ gn_bwd_group_kernel(const float* __restrict__ partial, double* __restrict__ acc,
     for (int cc = wave; cc < cpg; cc += 4) {
         const int c = g * cpg + cc;
         double p = 0.0, q = 0.0;
-        for (int k = lane; k < nblk; k += 64) {
-            const float2 t = *reinterpret_cast<const float2*>(partial + (((size_t)b * nblk + k) * C + c) * 2);
-            p += (double)t.x;
-            q += (double)t.y;
+        // nblk <= GN_MAX_BLOCKS = 8 x 64: all of a lane's loads go out together (fixed summation order as before)
+        float2 t[GN_MAX_BLOCKS / 64];
+#pragma unroll
+        for (int i = 0; i < GN_MAX_BLOCKS / 64; ++i) {
+            const int k = lane + 64 * i;
+            t[i] = k < nblk ? *reinterpret_cast<const float2*>(partial + (((size_t)b * nblk + k) * C + c) * 2) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < GN_MAX_BLOCKS / 64; ++i) {
+            p += (double)t[i].x;
+            q += (double)t[i].y;
         }
         p = wave_sum(p);
         q = wave_sum(q);
