@@ -290,6 +290,37 @@ conv3_unpack_wgrad_kernel(float* __restrict__ dwp, float* __restrict__ dw, float
     }
 }
 
+// The same unpack for launches that stored MANY per-split slabs (round 4: the fine levels' weight gradients split K over
+// 32-512 workgroups; their fp32 atomic merge was 56 MB per launch at the chip's 1.3 TB/s of atomic adds = 30-43 us of
+// every launch, and summed in arrival order).  Workgroup = (8 ci x 32 co) of ONE tap: a thread adds its element over the
+// slabs in slab order (128-B runs per slab row, eight loads in flight) and writes dw in the parameter layout -- plain
+// stores in the weight-gradient kernel, a fixed summation order here: the weight gradient is bit-reproducible.
+__global__ void __launch_bounds__(256)
+conv3_unpack_sum_kernel(float* __restrict__ dw, float* __restrict__ dbw, float* __restrict__ dbias, int Cin, int Cout,
+                        const float* __restrict__ slabs, int nslab) {
+    const int tap = blockIdx.z, ci = blockIdx.x * 8 + (threadIdx.x >> 5), co = blockIdx.y * 32 + (threadIdx.x & 31);
+    const int64_t stride = (int64_t)27 * Cin * Cout;
+    if (ci < Cin && co < Cout) {
+        const float* p = slabs + ((int64_t)tap * Cin + ci) * Cout + co;
+        float v = 0.f;
+        int k = 0;
+        for (; k + 8 <= nslab; k += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p[(int64_t)(k + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; k < nslab; ++k) v += p[(int64_t)k * stride];
+        dw[((int64_t)co * Cin + ci) * 27 + tap] = v;
+    }
+    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x < 32 && co < Cout) {
+        const float b = dbw[co];
+        dbw[co] = 0.f;
+        if (dbias) dbias[co] = b;
+    }
+}
+
 // ------------------------------------------------------------------ direct implicit GEMM -
 #define D3_BM 64
 #define D3_BN 64
@@ -759,11 +790,16 @@ extern "C" int tdx_conv3_bwd_data_add(const void* dy, const void* wb, void* dx1,
 }
 
 #define W3_MAX_SLABS 8
+// per-split slabs a workspace holds: 8 for the wide layers (few K splits), up to 512 for the narrow ones of the fine
+// levels, whose launches split K over 32-512 workgroups -- about 2 MB x 27 of slabs either way
+static int w3_slab_capacity(int Cin, int Cout) {
+    const int64_t c = ((int64_t)1 << 19) / ((int64_t)Cin * Cout);
+    return (int)(c < W3_MAX_SLABS ? W3_MAX_SLABS : (c > 512 ? 512 : c));
+}
 extern "C" size_t tdx_conv3_bwd_weight_workspace_bytes(int Cin, int Cout, int impl) {
     (void)impl;
-    // dw + dbias accumulators (the part covered by TDX_WS_CLEAN), then W3_MAX_SLABS partial-sum slabs for
-    // launches with few K-splits (scratch, never needs zeroing)
-    return (size_t)(1 + W3_MAX_SLABS) * 27 * Cin * Cout * sizeof(float) + (size_t)Cout * sizeof(float) + 512;
+    // dw + dbias accumulators (the part covered by TDX_WS_CLEAN), then the partial-sum slabs (scratch, never needs zeroing)
+    return (size_t)(1 + w3_slab_capacity(Cin, Cout)) * 27 * Cin * Cout * sizeof(float) + (size_t)Cout * sizeof(float) + 512;
 }
 
 extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dw,
@@ -802,10 +838,17 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
         if (dtype != TDX_BF16) return TDX_EDTYPE;
         if (!conv3_wgrad_mfma_supported(C1, C2, Cout)) return TDX_ESHAPE;
         float* slabs = dbw + ((Cout + 63) / 64) * 64;
-        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs,
-                                         W3_MAX_SLABS, &nslab);
+        // TDX_WGRAD_MANY_SLABS=0 (A/B switch, read per call): at most 8 slabs, more K splits merge by fp32 atomics (round 3)
+        const char* ms = getenv("TDX_WGRAD_MANY_SLABS");
+        const int cap = (ms && atoi(ms) == 0) ? W3_MAX_SLABS : w3_slab_capacity(Cin, Cout);
+        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs, cap, &nslab);
         slab_ptr = slabs;
         if (rc != TDX_OK) return rc;
+        if (nslab > W3_MAX_SLABS) {
+            hipLaunchKernelGGL(conv3_unpack_sum_kernel, dim3(ceil_div(Cin, 8), ceil_div(Cout, 32), 27), dim3(256), 0, st, dw, dbw,
+                               dbias, Cin, Cout, slab_ptr, nslab);
+            return tdx_launch_status();
+        }
     } else {
         const int64_t nvox = (int64_t)B * X * Y * Z;
         const int nci = ceil_div(Cin, D3_BM), nco = ceil_div(Cout, D3_BN);

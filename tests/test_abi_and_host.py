@@ -269,7 +269,7 @@ def test_trainer_from_config_accepts_the_model_group_and_overrides():
 
 
 def test_profiles_index_names_existing_files():
-    """profiles/README.md is the index the design document's round-3 citations go through: every r10 file it names exists,
+    """profiles/README.md is the index the design documents' citations go through: every r10 / r11 file it names exists,
     and the traffic file bench.py's roofline block reads carries launches of the forward kernels it filters for."""
     import json
     import re
@@ -278,8 +278,8 @@ def test_profiles_index_names_existing_files():
 
     root = Path(__file__).resolve().parent.parent
     text = (root / "profiles" / "README.md").read_text()
-    names = set(re.findall(r"`(r10[\w]*\.(?:json|txt|md|csv))`", text))
-    assert len(names) >= 12
+    names = set(re.findall(r"`(r1[01][\w]*\.(?:json|txt|md|csv))`", text))
+    assert len(names) >= 24 and any(n.startswith("r11") for n in names)
     missing = sorted(n for n in names if not (root / "profiles" / n).exists())
     assert not missing, missing
     for stem in ("r10bf16", "r10f32s"):

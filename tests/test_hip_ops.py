@@ -1091,6 +1091,45 @@ def test_conv1_fused_with_groupnorm_tail(B, V, C1, C2, Co):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 0, 64, (32, 32, 32)), (2, 32, 0, 32, (48, 32, 16)), (1, 64, 64, 32, (32, 32, 16)),
+                                  (3, 16, 0, 64, (32, 16, 16))])
+def test_conv3_weight_gradient_is_run_to_run_reproducible(case, monkeypatch):
+    """Round 4: the fine levels' weight gradients (K split over 32-512 workgroups) store per-split slabs that
+    conv3_unpack_sum_kernel adds in slab order, instead of merging by fp32 atomics in arrival order: the weight gradient
+    of the ring and brick kernels is bit-identical from run to run (the bias gradient still merges by atomics), equal to
+    the atomic route (TDX_WGRAD_MANY_SLABS=0) up to fp32 summation order, and the accumulator part of the workspace stays
+    all-zero (TDX_WS_CLEAN)."""
+    from turbdiff_amd import _lib as L
+
+    B, C1, C2, Co, (X, Y, Z) = case
+    d = dev()
+    Ci = C1 + C2
+    g = torch.Generator(device=d).manual_seed(9)
+    rn = lambda *s: torch.randn(*s, device=d, generator=g)
+    x1, x2 = rn(B, X, Y, Z, C1).bfloat16(), (rn(B, X, Y, Z, C2).bfloat16() if C2 else None)
+    gy = rn(B, X, Y, Z, Co).bfloat16()
+    st = L.stream()
+    L.ensure_scratch(d)
+    wws = torch.zeros(L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, 0), dtype=torch.uint8, device=d)
+
+    def run():
+        dw, db = torch.empty(Co, Ci, 3, 3, 3, device=d), torch.empty(Co, device=d)
+        L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(dw), L.ptr(db), B, X, Y, Z, Co, L.BF16,
+               L.CONV_AUTO | L.WS_CLEAN, L.ptr(wws), st)
+        torch.cuda.synchronize()
+        assert int(wws[: (27 * Ci * Co + Co) * 4].count_nonzero()) == 0
+        return dw, db
+
+    runs = [run() for _ in range(4)]
+    for dw, db in runs[1:]:
+        assert torch.equal(dw, runs[0][0])
+        assert rel_l2(db, runs[0][1]) < 1e-5
+    monkeypatch.setenv("TDX_WGRAD_MANY_SLABS", "0")
+    dwa, dba = run()
+    assert rel_l2(dwa, runs[0][0]) < 1e-5 and rel_l2(dba, runs[0][1]) < 1e-5
+
+
+@pytest.mark.gpu
 def test_scratch_arena_is_per_stream():
     """The library holds one arena pointer, bound per launch to the launching stream's arena (_lib.ensure_scratch): convs
     that use it (K-split slabs of the small-grid kernel) run concurrently on two streams, many times over, with different

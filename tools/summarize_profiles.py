@@ -72,6 +72,8 @@ from turbdiff_amd._lib import kernel_sources_fingerprint  # noqa: E402
 import os, subprocess  # noqa: E402
 
 head = subprocess.run(["git", "-C", str(root), "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+if not head and (root / "tools" / ".git_head").exists():  # the GPU box has no .git: the commit the snapshot was taken from
+    head = (root / "tools" / ".git_head").read_text().strip() + " (+ uncommitted changes, if any, of the snapshot)"
 json.dump({"source": f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)",
            # what the counters describe: bench.py refuses this file once the conv kernels' sources differ from these
            "git_head": head or None, "kernel_sources_sha16": kernel_sources_fingerprint(),
