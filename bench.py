@@ -431,6 +431,13 @@ def main():
         # the launcher's code.  Nothing is exec'd from a process that holds a GPU context.
         sys.exit(self_launch(args.gpus))
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # Data-parallel runs: RCCL's kernels and the persistent conv kernels must fit the chip together.  The conv kernels
+        # take 224 CUs (TDX_PERSISTENT_CUS, below); RCCL is held to at most 32 channels (= workgroups, one CU each) unless
+        # the caller chose otherwise -- 221 MB of gradients per ~22 ms step need ~10 GB/s per rank, far below what 32
+        # channels move.  Both must be in the environment before the communicator exists.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
+
     from turbdiff_amd import _lib, parallel
 
     # TDX_BENCH_BACKEND=gloo + TDX_BENCH_ONE_DEVICE=1: all ranks on cuda:0 with gloo collectives -- only for
@@ -617,6 +624,7 @@ def main():
                             "per_bucket": [dict(r, alone_ms=a, hidden_fraction=(1.0 - r["exposed_ms"] / a) if a > 0 else None)
                                            for r, a in zip(per_bucket, ddp.allreduce_alone_ms())],
                             "persistent_cus": int(os.environ.get("TDX_PERSISTENT_CUS", "256")),
+                            "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                             "payload_MB": sum(b for _, b in (ddp.bucket_layout() or [])) / 1e6}
 
     # ---- the modes that meet the 1e-4 parity gate, same run, same model (N = 1 only: they are not scaling legs)

@@ -15,6 +15,29 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
+def _run_bench(cmd, env, attempts=2, timeout=300):
+    """Two ranks time-sharing ONE GPU over gloo is a test-only arrangement (normally 15-20 s).  Once in ~10 full-suite runs of
+    round 4 such a launch sat until its 900-s limit on a fresh box and could not be reproduced in 8 repetitions of the same
+    command (alone, and behind the same preceding test files): a stuck launch is cut after `timeout` seconds and tried once
+    more; if it sticks twice the test fails with both outputs."""
+    import signal
+    from types import SimpleNamespace
+
+    notes = []
+    for k in range(attempts):
+        # own session: on a cut, the launcher AND its rank processes go (they would otherwise keep the GPU)
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT,
+                                start_new_session=True)
+        try:
+            out, err = proc.communicate(timeout=timeout)
+            return SimpleNamespace(returncode=proc.returncode, stdout=out, stderr=err)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            out, err = proc.communicate()
+            notes.append(f"attempt {k}: no result after {timeout} s\nstdout: {(out or '')[-1500:]}\nstderr: {(err or '')[-1500:]}")
+    pytest.fail("bench.py --gpus 2 did not finish:\n" + "\n".join(notes))
+
+
 def test_bench_two_ranks_one_gpu():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -23,7 +46,7 @@ def test_bench_two_ranks_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
            "--no-cpu-baseline", "--sample-steps", "3", "--sample-batch", "1"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    out = _run_bench(cmd, env)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(lines[0])
@@ -48,7 +71,7 @@ def test_bench_bare_command_launches_its_own_ranks():
         env.pop(k, None)
     cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
            "--no-cpu-baseline", "--sample-steps", "0"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    out = _run_bench(cmd, env)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads(lines[0])
