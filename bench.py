@@ -196,7 +196,11 @@ def measured_traffic(mode="bf16"):
     pat = FWD_KERNEL_PATTERNS[mode]
     now = kernel_sources_fingerprint()
     refused = []
-    for f in sorted((ROOT / "profiles").glob("*_traffic.json"), reverse=True):  # rNN tags: newest round first
+    # rNN tags: newest round first; within a round the set collected with the kernels one after the other before the
+    # one with the side stream on (`*ss_traffic.json`; the forward launches have nothing beside them either way)
+    files = sorted((ROOT / "profiles").glob("*_traffic.json"), key=lambda f: (f.name[:3], not f.name.endswith("ss_traffic.json"), f.name),
+                   reverse=True)
+    for f in files:
         data = json.loads(f.read_text())
         num = den = 0.0
         for name, k in data["kernels"].items():
