@@ -53,15 +53,29 @@ conv3_small_reduce_kernel(const float* __restrict__ slab, const float* __restric
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[cg * 8 + j] : 0.f;
-    for (int s = 0; s < nsplit; ++s)
-        for (int v0 = lo[0]; v0 <= hi[0]; ++v0)
-            for (int v1 = lo[1]; v1 <= hi[1]; ++v1)
-                for (int v2 = lo[2]; v2 <= hi[2]; ++v2) {
-                    const float* p = slab + (((int64_t)s * B + b) * Vv + ((int64_t)v0 * E[1] + v1) * E[2] + v2) * N + cg * 8;
-                    const float4 a = *reinterpret_cast<const float4*>(p), bq = *reinterpret_cast<const float4*>(p + 4);
-                    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-                    acc[4] += bq.x; acc[5] += bq.y; acc[6] += bq.z; acc[7] += bq.w;
-                }
+    // (position, split) pairs in a fixed order, four pairs' loads in flight per trip: a rolled load / add loop is a chain of
+    // memory round trips, and this pass runs on the tiny tensors of the deep levels, where latency is all it costs
+    const int n0 = hi[0] - lo[0] + 1, n1 = hi[1] - lo[1] + 1, n2 = hi[2] - lo[2] + 1, npos = n0 * n1 * n2, total_pairs = npos * nsplit;
+    auto pair_ptr = [&](int k) {
+        const int s = k / npos, q = k - s * npos;
+        const int v0 = lo[0] + q / (n1 * n2), v1 = lo[1] + (q / n2) % n1, v2 = lo[2] + q % n2;
+        return slab + (((int64_t)s * B + b) * Vv + ((int64_t)v0 * E[1] + v1) * E[2] + v2) * N + cg * 8;
+    };
+    for (int k0 = 0; k0 < total_pairs; k0 += 4) {
+        float4 a[4], bq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* p = pair_ptr(min(k0 + u, total_pairs - 1));
+            a[u] = *reinterpret_cast<const float4*>(p);
+            bq[u] = *reinterpret_cast<const float4*>(p + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u < total_pairs) {
+                acc[0] += a[u].x; acc[1] += a[u].y; acc[2] += a[u].z; acc[3] += a[u].w;
+                acc[4] += bq[u].x; acc[5] += bq[u].y; acc[6] += bq[u].z; acc[7] += bq[u].w;
+            }
+    }
     const int n = cg * 8;
     const int64_t vox = idx / groups;
     const bool first = n < D1;

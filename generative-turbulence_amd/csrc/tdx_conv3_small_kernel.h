@@ -31,12 +31,21 @@ struct SmallGeom {
 // x w ~ xh wh + xl wh + xh wl, as tdx_conv3_mfma_split.hip): the image is staged as raw fp32 (four 16-B quarter planes of
 // 4 channels) and split into hi / lo when a fragment is read; the weights arrive pre-split ([2 parts][K/16][27][N][16]
 // bf16, lo_offset elements apart).  fp32 images and two weight parts do not fit twice: that mode is single-buffered.
+// Round 4: FOUR LOADER WAVES beside the four computing waves (512 threads; one computing + one loader wave per SIMD).  An
+// LDS-DMA instruction blocks its issuing wave for ~150 cycles (profiles/r10_ring_stamps.txt); a slice is 16-23 of them per
+// wave against 27 x MTW MFMAs of 32 cycles, and with ONE wave per SIMD nothing else could issue meanwhile: the matrix pipe
+// was busy 24-33 % of the kernel (profiles/r11bf16_summary.md).  The loader waves issue every copy, wait for it and meet
+// the computing waves at the slice barrier, as in tdx_conv3_ring.hip; the computing waves carry no vector-memory
+// instruction besides their final stores.
+#define SM_LOADERS 4
 template <int MTW, bool SPLIT>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256 + 64 * SM_LOADERS, 1)
 conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict__ x2_, int C2, const bf16* __restrict__ wp,
                    float* __restrict__ slab, const void* __restrict__ zero16, SmallGeom g, int64_t lo_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool loader = tid >= 256;               // waves 4-7: issue the LDS-DMA copies; waves 0-3: compute
+    const int wave = (tid >> 6) & 3;              // index among the waves of its kind
     const int r = lane & 31, hh = lane >> 5;
     constexpr int NPL = SPLIT ? 4 : 2;            // 16-B planes per image entry (8 bf16 / 4 fp32 channels each)
     constexpr int NBUF = SPLIT ? 1 : 2;           // LDS buffers of image and weights
@@ -120,6 +129,26 @@ conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict_
         }
     };
 
+    const int c_first = split * g.per_split, c_end = min(g.K / SM_KC, c_first + g.per_split);
+    if (loader) {
+        // ---- loader waves: the copies of slice c + 1 go out while slice c computes (double-buffered), or behind the
+        // barrier that ends slice c (split precision: one buffer); every barrier below has its twin in the computing waves
+        if (c_first < c_end) dma_slice(c_first, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int c = c_first; c < c_end; ++c) {
+            const int buf = SPLIT ? 0 : ((c - c_first) & 1);
+            if (!SPLIT && c + 1 < c_end) dma_slice(c + 1, buf ^ 1);
+            if (SPLIT) {
+                __syncthreads();
+                if (c + 1 < c_end) dma_slice(c + 1, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        return;
+    }
+
     // ---- rows of this lane: M tile m = wave + 4 i, row = 32 m + r -> image entry of its centre
     int a_ent[MTW];
 #pragma unroll
@@ -144,11 +173,6 @@ conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict_
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    const int c_first = split * g.per_split, c_end = min(g.K / SM_KC, c_first + g.per_split);
-    auto drain_and_sync = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
     // 8 fp32 -> 8 bf16 hi and 8 bf16 lo
     auto split8 = [](const float4& a, const float4& b, bf16x8& hi, bf16x8& lo) {
         const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -162,11 +186,9 @@ conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict_
         hi = *reinterpret_cast<const bf16x8*>(&uh);
         lo = *reinterpret_cast<const bf16x8*>(&ul);
     };
-    if (c_first < c_end) dma_slice(c_first, 0);
-    drain_and_sync();
+    __syncthreads();  // the first slice has landed (the loader waves waited for it)
     for (int c = c_first; c < c_end; ++c) {
         const int buf = SPLIT ? 0 : ((c - c_first) & 1);
-        if (!SPLIT && c + 1 < c_end) dma_slice(c + 1, buf ^ 1);  // lands while this slice's taps run (buffer last read one slice ago)
         const unsigned char* A = sImg + buf * NPL * IMG_HALF;
         const unsigned char* W = sW + buf * WPARTS * 2 * (W_HALF + 512) + w_off;
         // fragments of tap t + 1 are read while the MFMAs of tap t issue (two register sets, pinned with
@@ -235,11 +257,8 @@ conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict_
                 }
             }
         }
-        if (SPLIT) {  // single-buffered: the next slice is copied only after every wave is done with this one
-            __syncthreads();
-            if (c + 1 < c_end) dma_slice(c + 1, 0);
-        }
-        drain_and_sync();
+        if (SPLIT) __syncthreads();  // single-buffered: the next slice is copied only after every wave is done with this one
+        __syncthreads();             // the next slice has landed, everybody is done with this one
     }
 
     // ---- partial tile -> slab[split][b][virtual voxel][N] (fp32).  Lane (r, hh) holds, for tile i, row 32 m + r and
@@ -273,7 +292,7 @@ static int small_go(SMALL_GO_ARGS) {
         attr = lds;
     }
     const int ngroups = ceil_div(g.B, g.nbg) * g.gx;
-    hipLaunchKernelGGL(kern, dim3(g.N / SM_BN, ngroups, g.nsplit), dim3(256), lds, st, x1, C1, x2, C2, (const bf16*)wp, slab,
+    hipLaunchKernelGGL(kern, dim3(g.N / SM_BN, ngroups, g.nsplit), dim3(256 + 64 * SM_LOADERS), lds, st, x1, C1, x2, C2, (const bf16*)wp, slab,
                        zero16, g, lo_offset);
     return tdx_launch_status();
 }
