@@ -304,3 +304,37 @@ def test_profiles_index_names_existing_files():
         assert src["file"] is None and any(r["file"].endswith("_traffic.json") for r in src["refused"])
     stale = json.loads((root / "profiles" / "r10bf16_traffic.json").read_text())
     assert stale.get("kernel_sources_sha16") != now, "the round-3 file describes the round-3 kernels"
+
+
+def test_graph_sampler_stream_ids_and_signature():
+    """Host logic of the default sampling path (no GPU needed): the Philox stream id of a trajectory is
+    (per-call nonce << 32 | trajectory id) -- independent of how trajectories are sharded over ranks -- and the signature
+    that decides whether a captured graph can be re-used covers shapes, device, conditioning tensors and the switches the
+    captured step was built under."""
+    from turbdiff_amd.models.conditioning import Conditioning
+    from turbdiff_amd.sampling import GraphSampler
+
+    assert GraphSampler._sids([0, 1, 9], 0) == [0, 1, 9]
+    assert GraphSampler._sids([5], 3) == [(3 << 32) | 5]
+    # the same trajectory has the same stream id whichever rank / batch position holds it
+    assert GraphSampler._sids([4, 5, 6, 7], 11)[1] == GraphSampler._sids([5], 11)[0]
+    with pytest.raises(AssertionError):
+        GraphSampler._sids([1 << 32], 0)
+    with pytest.raises(AssertionError):
+        GraphSampler._sids([0], 1 << 31)
+
+    class M:  # stand-ins with the attributes the signature reads
+        compute_dtype, conv_impl = torch.float32, None
+
+    class D:
+        model, noise_bcs, clip_denoised, num_timesteps = M(), True, False, 10
+
+    x = torch.zeros(2, 4, 6, 5, 4)
+    C = {Conditioning.Type.CELL_TYPE: torch.zeros(4, 6, 5, 4)}
+    sig = GraphSampler.signature_of(D(), x, C)
+    assert sig == GraphSampler.signature_of(D(), x.clone(), {k: v.clone() for k, v in C.items()})
+    assert sig != GraphSampler.signature_of(D(), x[:1], C)
+    d2 = D(); d2.noise_bcs = False
+    assert sig != GraphSampler.signature_of(d2, x, C)
+    m2 = D(); m2.model = M(); m2.model.compute_dtype = torch.bfloat16
+    assert sig != GraphSampler.signature_of(m2, x, C)
