@@ -711,9 +711,13 @@ def main():
                 public_loop(x1, 3)  # capture at B = 1
                 full_s = public_loop(x1, None) if full else None
                 b1_ms = 1e3 * public_loop(x1, 50) / 50
+                D.GRAPH_SAMPLER = False
+                public_loop(x1, 3)
+                b1_eager_ms = 1e3 * public_loop(x1, 50) / 50  # where the graph matters: one trajectory is host-bound in eager mode
+                D.GRAPH_SAMPLER = True
                 extra["sampling"]["public_p_sample_loop"] = {
                     "graph_ms_per_step": g_ms, "eager_ms_per_step": e_ms, "batch": Bs, "reverse_steps_timed": 30,
-                    "measure_sample_time_B1_s": full_s, "B1_ms_per_reverse_step": b1_ms,
+                    "measure_sample_time_B1_s": full_s, "B1_ms_per_reverse_step": b1_ms, "B1_eager_ms_per_reverse_step": b1_eager_ms,
                     "note": "GaussianDiffusion.p_sample_loop as the callers reach it; B = 1 full T = 1000 sample = the "
                             "reference's evaluate-runtime.py protocol" + ("" if full else " (full loop only with --steps >= 20)")}
             del sdiff
