@@ -369,6 +369,98 @@ extern "C" int tdx_randn_batched(float* out, int B, int64_t n, uint64_t seed, co
     return tdx_launch_status();
 }
 
+// ------------------------------------------------------------------ reverse step, noise drawn in the kernel ---
+// The same update as p_sample_step_kernel with z and z2 generated where they are consumed: lane i of sample b draws the
+// four normals randn_batched_kernel would have written to z[b][4i..4i+3] (counter off + i) and to z2 (counter
+// off + n4 + i), so a run is bit-identical to tdx_randn_batched(z); tdx_randn_batched(z2); tdx_p_sample_step(...).
+// Saves two 4-byte writes and two reads per value; the Philox rounds are a few microseconds of VALU per launch.
+__device__ __forceinline__ void philox_normal4(uint64_t ctr, uint64_t sid, uint64_t seed, float (&r)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float u1 = ((float)c[2 * k] + 1.0f) * 2.3283064365386963e-10f;
+        float u2 = (float)c[2 * k + 1] * 2.3283064365386963e-10f;
+        float rad = sqrtf(-2.0f * __logf(u1));
+        float sn, cs;
+        __sincosf(6.283185307179586f * u2, &sn, &cs);
+        r[2 * k] = rad * cs; r[2 * k + 1] = rad * sn;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+p_sample_step_rng_kernel(const float* __restrict__ x_t, const float* __restrict__ eps, const float* __restrict__ x_bcs,
+                         const uint8_t* __restrict__ mask, const float* __restrict__ sched, int T,
+                         const int64_t* __restrict__ tp, int noise_bcs, int clip, float* __restrict__ out, int64_t V,
+                         int64_t n4, uint64_t seed, const uint64_t* __restrict__ sids,
+                         const uint64_t* __restrict__ offp) {
+    const int64_t t = *tp;
+    const uint64_t off = *offp, sid = sids[blockIdx.y];
+    const float recip = sched[t], recipm1 = sched[T + t], c1 = sched[2 * T + t], c2 = sched[3 * T + t];
+    const float sigma = __expf(sched[4 * T + t] * 0.5f);
+    const float sa = sched[5 * T + t], sb = sched[6 * T + t];
+    const bool last = (t == 0);
+    const int64_t base4 = (int64_t)blockIdx.y * n4;
+    const int64_t v4 = V >> 2;
+    const float4* xt4 = reinterpret_cast<const float4*>(x_t) + base4;
+    const float4* e4 = reinterpret_cast<const float4*>(eps) + base4;
+    const float4* xb4 = reinterpret_cast<const float4*>(x_bcs) + base4;
+    const uchar4* m4 = reinterpret_cast<const uchar4*>(mask);
+    float4* o4 = reinterpret_cast<float4*>(out) + base4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 xv = xt4[i], ev = e4[i];
+        const uchar4 mv = m4[i % v4];
+        const bool in[4] = {mv.x != 0, mv.y != 0, mv.z != 0, mv.w != 0};
+        const bool any_in = in[0] | in[1] | in[2] | in[3], any_out = !(in[0] & in[1] & in[2] & in[3]);
+        const float xt[4] = {xv.x, xv.y, xv.z, xv.w}, ee[4] = {ev.x, ev.y, ev.z, ev.w};
+        float xb[4] = {0.f, 0.f, 0.f, 0.f}, z[4] = {0.f, 0.f, 0.f, 0.f}, z2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (any_out && (last || noise_bcs)) {
+            const float4 bv = xb4[i];
+            xb[0] = bv.x; xb[1] = bv.y; xb[2] = bv.z; xb[3] = bv.w;
+        }
+        if (!last) {
+            if (any_in) philox_normal4(off + (uint64_t)i, sid, seed, z);
+            if (noise_bcs && any_out) philox_normal4(off + (uint64_t)n4 + (uint64_t)i, sid, seed, z2);
+        }
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x0h = recip * xt[k] - recipm1 * ee[k];
+            if (!noise_bcs && !in[k]) x0h = xt[k];
+            if (clip) x0h = fminf(fmaxf(x0h, -1.0f), 1.0f);
+            float v = c1 * x0h + c2 * xt[k];
+            if (last) {
+                if (!in[k]) v = xb[k];
+            } else if (in[k]) {
+                v += sigma * z[k];
+            } else if (noise_bcs) {
+                v = sa * xb[k] + sb * z2[k];
+            }
+            r[k] = v;
+        }
+        o4[i] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+// offset += by; t -= 1: the two scalar updates that close a reverse step, in one launch
+__global__ void advance_step(uint64_t* offp, uint64_t by, int64_t* tp) { *offp += by; *tp -= 1; }
+
+extern "C" int tdx_p_sample_step_rng(const float* x_t, const float* eps, const float* x_bcs, const uint8_t* mask,
+                                     const float* sched, int T, int64_t* t, int noise_bcs, int clip, float* out, int B,
+                                     int F, int64_t V, uint64_t seed, const uint64_t* stream_ids, uint64_t* offset_dev,
+                                     void* stream) {
+    TDX_CHECK_ARG(x_t && eps && x_bcs && mask && sched && t && out && stream_ids && offset_dev);
+    TDX_CHECK_ARG(T > 0 && B > 0 && F > 0 && V > 0 && (V & 3) == 0);
+    TDX_CHECK_ARG(((uintptr_t)x_t | (uintptr_t)eps | (uintptr_t)x_bcs | (uintptr_t)out) % 16 == 0 && (uintptr_t)mask % 4 == 0);
+    const int64_t n4 = (int64_t)F * V / 4;
+    dim3 grid((unsigned)min((int64_t)256, (n4 + 255) / 256), B);
+    hipLaunchKernelGGL(p_sample_step_rng_kernel, grid, dim3(256), 0, as_stream(stream), x_t, eps, x_bcs, mask, sched, T,
+                       (const int64_t*)t, noise_bcs, clip, out, V, n4, seed, stream_ids, (const uint64_t*)offset_dev);
+    hipLaunchKernelGGL(advance_step, dim3(1), dim3(1), 0, as_stream(stream), offset_dev,
+                       (uint64_t)(noise_bcs ? 2 * n4 : n4), t);
+    return tdx_launch_status();
+}
+
 extern "C" int tdx_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t* offset_dev, void* stream) {
     TDX_CHECK_ARG(out && offset_dev && n > 0);
     const int64_t n4 = (n + 3) >> 2;

@@ -66,6 +66,7 @@ SIGNATURES = {
     "tdx_cell_mask": (_i, [_vp, _i64, _vp, _i64, _vp]),
     "tdx_q_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i64, _vp]),
     "tdx_p_sample_step": (_i, [_vp] * 7 + [_i, _vp, _i, _i, _vp, _i, _i, _i64, _vp]),
+    "tdx_p_sample_step_rng": (_i, [_vp] * 5 + [_i, _vp, _i, _i, _vp, _i, _i, _i64, _u64, _vp, _vp, _vp]),
     "tdx_masked_loss": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i64, _vp, _vp]),
     "tdx_masked_loss_workspace_bytes": (_sz, []),
     "tdx_grid_embed": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _vp]),

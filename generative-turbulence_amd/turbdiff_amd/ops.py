@@ -643,6 +643,21 @@ def p_sample_step(x_t, eps, z, z2, x_bcs, mask, sched, T, t_dev, noise_bcs, clip
     return out
 
 
+def p_sample_step_rng_supported(x_t) -> bool:
+    return x_t.dtype == torch.float32 and x_t[0, 0].numel() % 4 == 0 and x_t.is_contiguous()
+
+
+def p_sample_step_rng(x_t, eps, x_bcs, mask, sched, T, t_dev, noise_bcs, clip, seed, stream_ids, offset_dev, out=None):
+    """The reverse step with z (and z2) drawn in the kernel; advances offset_dev and decrements t_dev on the device."""
+    B, F = x_t.shape[:2]
+    V = x_t[0, 0].numel()
+    if out is None:
+        out = torch.empty_like(x_t)
+    L.call("tdx_p_sample_step_rng", L.ptr(x_t), L.ptr(eps), L.ptr(x_bcs), L.ptr(mask), L.ptr(sched), T, L.ptr(t_dev),
+           int(noise_bcs), int(clip), L.ptr(out), B, F, V, seed, L.ptr(stream_ids), L.ptr(offset_dev), L.stream())
+    return out
+
+
 class _MaskedLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, eps_hat, noise, mask, n_cells, l1):

@@ -2,8 +2,9 @@
 
 The reference's loop (ddpm.py:767-816) pays per step: a host->device scalar for t, ~12 small
 elementwise kernels, two index scatters and the Python/launch overhead of ~400 kernels of the
-U-Net.  Here ONE reverse step -- U-Net forward, the two Philox noise draws, the fused update
-and the on-device decrement of t -- is captured once into a hipGraph and replayed T times;
+U-Net.  Here ONE reverse step -- U-Net forward, then one kernel that draws the two Philox
+noises where they are consumed and applies the update, then the on-device advance of the RNG
+offset and decrement of t -- is captured once into a hipGraph and replayed T times;
 nothing in the step touches the host.  The timestep and the RNG offset live in device memory,
 so a replay needs no new arguments.
 
@@ -13,10 +14,16 @@ not depend on how trajectories are sharded over GPUs.
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib as L
 from . import ops
+
+# TDX_FUSED_STEP_NOISE=0: draw z / z2 into tensors with tdx_randn_batched and run tdx_p_sample_step on them (the same
+# values; the A/B switch for the in-kernel draw)
+FUSED_STEP_NOISE = os.environ.get("TDX_FUSED_STEP_NOISE", "1") != "0"
 
 
 class GraphSampler:
@@ -43,8 +50,11 @@ class GraphSampler:
         self.offset = torch.zeros(1, dtype=torch.int64, device=dev)
         self.t = torch.zeros(1, dtype=torch.int64, device=dev)
         self.x_t = torch.empty_like(self.x_bcs)
-        self.z = torch.empty_like(self.x_bcs)
-        self.z2 = torch.empty_like(self.x_bcs)
+        # noise drawn inside the update kernel (tdx_p_sample_step_rng) unless the layout rules that out; only then do the
+        # two noise tensors exist at all
+        self.fused_noise = FUSED_STEP_NOISE and ops.p_sample_step_rng_supported(self.x_t)
+        self.z = None if self.fused_noise else torch.empty_like(self.x_bcs)
+        self.z2 = None if self.fused_noise or not diffusion.noise_bcs else torch.empty_like(self.x_bcs)
         self.use_graph = use_graph
         self.graph = None
         self._capture_stream = None  # ONE stream for every capture of this sampler (its scratch arena is per stream)
@@ -119,6 +129,11 @@ class GraphSampler:
         d = self.d
         kw = {"encoded_local": self.enc} if self.enc is not None else {}
         eps = d.model(self.x_t, self.t.expand(self.B), self.C, **kw)
+        if self.fused_noise:
+            # same draws, same counters, bit-identical x_{t-1}; also advances the offset and decrements t
+            ops.p_sample_step_rng(self.x_t, eps, self.x_bcs, self.mask, d.step_tables, d.num_timesteps, self.t,
+                                  d.noise_bcs, d.clip_denoised, self.seed, self.stream_ids, self.offset, out=self.x_t)
+            return
         self._randn(self.z)
         if d.noise_bcs:
             self._randn(self.z2)

@@ -299,6 +299,15 @@ int tdx_p_sample_step(const float* x_t, const float* eps, const float* z, const 
                       const uint8_t* mask, const float* sched, int T, const int64_t* t, int noise_bcs, int clip,
                       float* out, int B, int F, int64_t V, void* stream);
 
+/* The same reverse step with its noise drawn inside the kernel (needs V % 4 == 0 and 16-byte aligned tensors): bit-identical
+ * to tdx_randn_batched(z, ...); [tdx_randn_batched(z2, ...) if noise_bcs;] tdx_p_sample_step(...) with the same seed,
+ * stream ids and offset -- lane i of trajectory b draws the normals those calls would have written to z[b][4i..4i+3] -- without
+ * the two noise tensors ever touching HBM.  Afterwards *offset_dev += (noise_bcs ? 2 : 1) * F V / 4 and *t -= 1 (both on the
+ * device, so a captured graph replays the whole ddpm.py:789-813 loop body). */
+int tdx_p_sample_step_rng(const float* x_t, const float* eps, const float* x_bcs, const uint8_t* mask, const float* sched,
+                          int T, int64_t* t, int noise_bcs, int clip, float* out, int B, int F, int64_t V, uint64_t seed,
+                          const uint64_t* stream_ids, uint64_t* offset_dev, void* stream);
+
 /* Masked loss (ddpm.py:845-852): loss = mean_b mean_{f, cells} err(eps_hat, noise),
  * err = squared (l1 = 0) or absolute (l1 = 1) error.  n_cells = number of mask ones.
  * Writes loss[0] and, if grad != NULL, d loss / d eps_hat (zero outside the mask). */

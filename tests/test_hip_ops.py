@@ -314,6 +314,50 @@ def test_p_sample_step(noise_bcs, t):
     assert torch.allclose(out.cpu(), ref, rtol=2e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("noise_bcs", [True, False])
+@pytest.mark.parametrize("clip", [False, True])
+@pytest.mark.parametrize("t", [0, 1, 7])
+def test_p_sample_step_rng_matches_separate_draws_bitwise(noise_bcs, clip, t):
+    """tdx_p_sample_step_rng == tdx_randn_batched(z); [tdx_randn_batched(z2);] tdx_p_sample_step, bit for bit, and it leaves
+    the same RNG offset and t - 1 behind (the contract include/tdx.h states)."""
+    from turbdiff_amd import ops, schedules
+
+    T, d = 10, dev()
+    shape = (3, 4, 6, 5, 4)
+    V = 120
+    x_t, eps, xb = (rnd(*shape, seed=s).to(d) for s in range(3))
+    mask = ops.cell_mask(_mask_idx(V).to(d), V)
+    sched = schedules.pack_step_tables(schedules.diffusion_tables("log-snr-linear", T)).to(d)
+    sids = torch.tensor([(5 << 32) | 7, 11, (1 << 32) | 2], dtype=torch.int64, device=d)
+    seed, off0 = 1234, 4096
+
+    off = torch.full((1,), off0, dtype=torch.int64, device=d)
+    z = ops.randn_philox_batched(torch.empty_like(x_t), seed, sids, off)
+    z2 = ops.randn_philox_batched(torch.empty_like(x_t), seed, sids, off) if noise_bcs else None
+    tt = torch.tensor([t], device=d)
+    ref = ops.p_sample_step(x_t, eps, z, z2, xb, mask, sched, T, tt, noise_bcs, clip)
+
+    off_f = torch.full((1,), off0, dtype=torch.int64, device=d)
+    tf = torch.tensor([t], device=d)
+    assert ops.p_sample_step_rng_supported(x_t)
+    out = ops.p_sample_step_rng(x_t, eps, xb, mask, sched, T, tf, noise_bcs, clip, seed, sids, off_f)
+    assert torch.equal(out, ref)
+    assert int(off_f) == int(off) == off0 + (2 if noise_bcs else 1) * (4 * V // 4)
+    assert int(tf) == t - 1
+    # in place, as the sampler calls it
+    x_in = x_t.clone()
+    off_f.fill_(off0); tf.fill_(t)
+    ops.p_sample_step_rng(x_in, eps, xb, mask, sched, T, tf, noise_bcs, clip, seed, sids, off_f, out=x_in)
+    assert torch.equal(x_in, ref)
+
+
+def test_p_sample_step_rng_refuses_unaligned_planes():
+    from turbdiff_amd import ops
+
+    x = torch.zeros(1, 4, 3, 3, 3, device=dev())
+    assert not ops.p_sample_step_rng_supported(x)
+
+
 @pytest.mark.parametrize("l1", [False, True])
 def test_masked_loss(l1):
     from turbdiff_amd import ops
