@@ -66,7 +66,7 @@ encode_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wx, con
         for (int j = 0; j < 8; ++j) {
             float a = br[j];
 #pragma unroll
-            for (int k = 0; k < F; ++k) a += wr[j][k] * in[k];
+            for (int k = 0; k < F; ++k) a = __builtin_fmaf(wr[j][k], in[k], a);  // explicit: gn_apply_encoded_kernel repeats it
             o.v[j] = a;
         }
         o.store(y + ((int64_t)b * V + v) * Dtot + lc * 8);

@@ -286,6 +286,96 @@ extern "C" int tdx_gn_apply(const void* x, const float* stats, const float* gamm
     return tdx_launch_status();
 }
 
+// ---- y = silu(GN(x)) + encode(raw): the tail of the U-Net's FIRST block, whose identity skip is the encoder output
+// cat(Wx x_raw + bx, Wc c_raw + bc) (ddpm.py:495-501).  The skip is recomputed here from the 4 + 4 raw f32 planes instead
+// of being written by tdx_encode_fwd and read back: per voxel 2 x (C x 2 B) of HBM traffic become 8 x 4 B.  The skip value
+// is rounded to T before the add, exactly what a stored encoder output would have held, so the result is bit-identical
+// to tdx_encode_fwd + tdx_gn_apply(res = that tensor).
+template <typename T> __device__ __forceinline__ float round_as(float a);
+template <> __device__ __forceinline__ float round_as<float>(float a) { return a; }
+template <> __device__ __forceinline__ float round_as<bf16>(float a) { return __uint_as_float(pack_bf16x2(a, 0.f) << 16); }
+template <> __device__ __forceinline__ float round_as<f16>(float a) { return (float)(_Float16)a; }
+
+template <typename T, int F>
+__global__ void __launch_bounds__(GN_THREADS)
+gn_apply_encoded_kernel(const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                        const float* __restrict__ beta, const float* __restrict__ xr, const float* __restrict__ wx,
+                        const float* __restrict__ bx, const float* __restrict__ cr, const float* __restrict__ wc,
+                        const float* __restrict__ bc, T* __restrict__ y, int64_t V, int C, int D, int G) {
+    const int b = blockIdx.y;
+    const int L = C >> 3;
+    const int rows = GN_THREADS / L;
+    const int tid = threadIdx.x;
+    const int lc = tid % L, r = tid / L;
+    if (r >= rows) return;
+    GnCoef k;
+    float mean[8], rstd[8], gam[8], film[8];
+    gn_load_coef(k, mean, rstd, gam, film, stats, gamma, beta, nullptr, nullptr, b, C, G, lc * 8);
+    const bool is_x = lc * 8 < D;
+    const int ch0 = is_x ? lc * 8 : lc * 8 - D;
+    const float* w = is_x ? wx : wc;
+    const float* bias = is_x ? bx : bc;
+    const float* src = is_x ? xr + (int64_t)b * F * V : cr;
+    float wr[8][F], br[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        br[j] = bias[ch0 + j];
+#pragma unroll
+        for (int q = 0; q < F; ++q) wr[j][q] = w[(ch0 + j) * F + q];
+    }
+    const int64_t base = ((int64_t)b * V) * C + lc * 8;
+    const int64_t stride = (int64_t)gridDim.x * rows;
+    auto one = [&](const Vec8<T>& a, const float (&in)[F], int64_t vv) {
+        Vec8<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float e = br[j];
+#pragma unroll
+            for (int q = 0; q < F; ++q) e = __builtin_fmaf(wr[j][q], in[q], e);  // encode_fwd_kernel's chain, bit for bit
+            const float n = __builtin_fmaf(a.v[j], k.a[j], k.c0[j]);
+            o.v[j] = silu_f(n) + round_as<T>(e);
+        }
+        o.store(y + base + vv * C);
+    };
+    int64_t v = (int64_t)blockIdx.x * rows + r;
+    for (; v + (GN_UNROLL - 1) * stride < V; v += stride * GN_UNROLL) {
+        Raw8<T> a[GN_UNROLL];
+        float in[GN_UNROLL][F];
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            a[u].load(x + base + (v + u * stride) * C);
+#pragma unroll
+            for (int q = 0; q < F; ++q) in[u][q] = src[(int64_t)q * V + v + u * stride];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // all loads of the trip are issued before any arithmetic
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) one(a[u].get(), in[u], v + u * stride);
+    }
+    for (; v < V; v += stride) {
+        Vec8<T> a;
+        float in[F];
+        a.load(x + base + v * C);
+#pragma unroll
+        for (int q = 0; q < F; ++q) in[q] = src[(int64_t)q * V + v];
+        one(a, in, v);
+    }
+}
+
+extern "C" int tdx_gn_apply_encoded(const void* x, const float* stats, const float* gamma, const float* beta,
+                                    const float* x_raw, int Fx, const float* wx, const float* bx, const float* c_raw,
+                                    int Fc, const float* wc, const float* bc, void* y, int B, int64_t V, int D, int G,
+                                    int dtype, void* stream) {
+    TDX_CHECK_ARG(x && stats && gamma && beta && x_raw && wx && bx && y && B > 0 && V > 0 && D > 0);
+    TDX_CHECK_ARG(c_raw == nullptr || (wc && bc));
+    const int C = c_raw ? 2 * D : D;
+    if (!gn_shape_ok(C, G) || (D % 8) || Fx != 4 || (c_raw && Fc != 4)) return TDX_ESHAPE;
+    dim3 grid(gn_blocks_per_sample(B, V, C), B);
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_encoded_kernel<T, 4>), grid, dim3(GN_THREADS), 0,
+                                                 as_stream(stream), (const T*)x, stats, gamma, beta, x_raw, wx, bx, c_raw,
+                                                 wc, bc, (T*)y, V, C, D, G));
+    return tdx_launch_status();
+}
+
 // ------------------------------------------------------------------ backward -------------
 // With n = a x + c0 (GroupNorm affine + FiLM folded), dn = dy act'(n), xhat = (x - mean) rstd:
 //   reduce pass : P[b,c] = sum_v dn, Q[b,c] = sum_v dn xhat     (per-block partials, no atomics)

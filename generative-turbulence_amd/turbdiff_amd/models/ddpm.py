@@ -81,6 +81,8 @@ import os as _os
 FUSE_BLOCKS = _os.environ.get("TDX_FUSE_BLOCKS", "1") != "0"
 # TDX_COMPOSE_FIRST_CONV=0: the first U-Net conv runs on the 64 encoded channels as written in the reference
 COMPOSE_FIRST_CONV = _os.environ.get("TDX_COMPOSE_FIRST_CONV", "1") != "0"
+# TDX_DEFER_ENCODE=0: the encoder output is written by tdx_encode_fwd and read back by the first block's skip (A/B switch)
+DEFER_ENCODE = _os.environ.get("TDX_DEFER_ENCODE", "1") != "0"
 # TDX_CACHE_COND_CONV=0: sampling recomputes the conditioning half of the first conv every step (A/B switch)
 CACHE_COND_CONV = _os.environ.get("TDX_CACHE_COND_CONV", "1") != "0"
 
@@ -132,11 +134,12 @@ class ResnetBlock(nn.Module):
         identity = isinstance(self.conv, nn.Identity)
         return self.block1._fused_act and self.block2._fused_act and not (identity and x2 is not None) and FUSE_BLOCKS
 
-    def forward(self, x, c, x2=None, partial=None, conv1=None, films=None):
+    def forward(self, x, c, x2=None, partial=None, conv1=None, films=None, skip_encoded=None):
         """partial = (n_lead, init): inference only -- block1's conv runs over the leading n_lead channels
         of x and continues from `init`, the precomputed conv of the batch-shared remaining channels.
         conv1 = (input, weight, bias): block1's conv replaced by an equivalent conv on another input
-        (DenoisingModel.compose_first_conv); x still feeds the identity skip.
+        (DenoisingModel.compose_first_conv); x still feeds the identity skip -- or, with skip_encoded (an
+        ops.DeferredEncoding whose stand-in x is), the skip is evaluated from the encoders' operands in the tail kernel.
         films = {id(block): (2, B, dim_out) scale | shift}: the projections of all blocks computed up front in one
         launch (DenoisingModel.film_table); without it the block projects `c` itself."""
         film = films.get(id(self)) if films is not None else None
@@ -154,12 +157,13 @@ class ResnetBlock(nn.Module):
                 return ops.resnet_block(x, None, scale, shift, (conv1[1], conv1[2]), (b1.norm.weight, b1.norm.bias),
                                         (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias), None,
                                         _norm_groups(b1.norm), b1.norm.eps, conv1_input=conv1[0],
-                                        conv1_real_channels=conv1[3] if len(conv1) > 3 else None, film=film)
+                                        conv1_real_channels=conv1[3] if len(conv1) > 3 else None, film=film,
+                                        skip_encoded=skip_encoded)
             return ops.resnet_block(x, x2, scale, shift, (b1.conv.weight, b1.conv.bias), (b1.norm.weight, b1.norm.bias),
                                     (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias),
                                     None if identity else (self.conv.weight, self.conv.bias), _norm_groups(b1.norm),
                                     b1.norm.eps, partial=partial, film=film)
-        assert partial is None and conv1 is None
+        assert partial is None and conv1 is None and skip_encoded is None
         h = self.block1(x, scale_shift=(scale, shift), x2=x2)
         if isinstance(self.conv, nn.Identity):
             skip = x if x2 is None else torch.cat((x, x2), dim=-1)
@@ -228,11 +232,12 @@ class UNet(nn.Module):
         self.downsampling_factor = downsampling_factor
         self.scale_factor = 1 / downsampling_factor
 
-    def forward(self, x, c, first_partial=None, first_conv=None, films=None):
+    def forward(self, x, c, first_partial=None, first_conv=None, films=None, first_skip=None):
         skips = []
+        assert first_skip is None or first_conv is not None
         for i, blk in enumerate(self.downsampling_blocks):
             if i == 0 and first_conv is not None:
-                x = blk(x, c, conv1=first_conv, films=films)
+                x = blk(x, c, conv1=first_conv, films=films, skip_encoded=first_skip)
             elif i == 0 and first_partial is not None:
                 x = blk(x, c, partial=first_partial, films=films)
             else:
@@ -461,13 +466,20 @@ class DenoisingModel(nn.Module):
         B = x.shape[0]
         c = self.conditioning_vector(t, C, B)
         c_local = local_conditioning(C) if self.c_local_features > 0 else None
-        first_conv = None
+        first_conv = first_skip = None
         if ops.encode_supported(x, c_local, self.encode_x.weight):
             # both encoders + NCDHW->NDHWC + concat in one kernel
             wc = self.encode_c_local.weight if c_local is not None else None
             bc = self.encode_c_local.bias if c_local is not None else None
-            h = ops.encode(x, c_local, self.encode_x.weight, self.encode_x.bias, wc, bc, self.compute_dtype)
             first_conv = self.compose_first_conv(x, c_local)
+            if first_conv is not None and DEFER_ENCODE:
+                # the encoder output's only reader is then the first block's identity skip: it is evaluated inside that
+                # block's tail kernel and the (B, X, Y, Z, 2 dim) tensor never exists
+                first_skip = ops.encode_deferred(x, c_local, self.encode_x.weight, self.encode_x.bias, wc, bc,
+                                                 self.compute_dtype)
+                h = first_skip.standin
+            else:
+                h = ops.encode(x, c_local, self.encode_x.weight, self.encode_x.bias, wc, bc, self.compute_dtype)
         else:
             h = ops.conv1(ops.to_nvc(x, self.compute_dtype), self.encode_x.weight, self.encode_x.bias)
             e = encoded_local if encoded_local is not None else self.encode_local(C)
@@ -476,7 +488,7 @@ class DenoisingModel(nn.Module):
         partial = getattr(encoded_local, "first_conv_partial", None) if not torch.is_grad_enabled() else None
         self.prefetch_weights(skip_first_conv=first_conv is not None)
         films = self.film_table(c)
-        h = self.u_net(h, c, first_partial=partial, first_conv=first_conv, films=films)
+        h = self.u_net(h, c, first_partial=partial, first_conv=first_conv, films=films, first_skip=first_skip)
         h = self.decode[0](h, c, films=films)
         if ops.decode_supported(h, self.decode[1].weight):
             return ops.decode(h, self.decode[1].weight, self.decode[1].bias)

@@ -117,7 +117,7 @@ class _Encode(torch.autograd.Function):
     layout change and the channel concat in one pass."""
 
     @staticmethod
-    def forward(ctx, x, c_local, wx, bx, wc, bc, dtype):
+    def forward(ctx, x, c_local, wx, bx, wc, bc, dtype, lazy=None):
         B, Fx, X, Y, Z = x.shape
         V, D = X * Y * Z, wx.shape[0]
         x = x.contiguous().float()
@@ -126,9 +126,16 @@ class _Encode(torch.autograd.Function):
         wx2, bx2 = wx.detach().reshape(D, Fx).contiguous(), bx.detach().contiguous()
         wc2 = wc.detach().reshape(D, -1).contiguous() if has_c else None
         bc2 = bc.detach().contiguous() if has_c else None
-        y = torch.empty((B, X, Y, Z, 2 * D if has_c else D), dtype=dtype, device=x.device)
-        L.call("tdx_encode_fwd", L.ptr(x), Fx, L.ptr(wx2), L.ptr(bx2), L.ptr(c), c.shape[0] if has_c else 0, L.ptr(wc2),
-               L.ptr(bc2), L.ptr(y), B, V, D, L.dtype_code(dtype), L.stream())
+        if lazy is not None:
+            # encode_deferred: nothing is computed -- the one consumer (the first ResnetBlock's identity skip) evaluates
+            # the encoders itself from these operands (tdx_gn_apply_encoded).  The returned tensor is a shape-only stand-in
+            # (one element, expanded) that ties the consumer's gradient back to this node.
+            lazy.extend((x, Fx, wx2, bx2, c, c.shape[0] if has_c else 0, wc2, bc2, D))
+            y = torch.empty(1, dtype=dtype, device=x.device).expand(B, X, Y, Z, 2 * D if has_c else D)
+        else:
+            y = torch.empty((B, X, Y, Z, 2 * D if has_c else D), dtype=dtype, device=x.device)
+            L.call("tdx_encode_fwd", L.ptr(x), Fx, L.ptr(wx2), L.ptr(bx2), L.ptr(c), c.shape[0] if has_c else 0, L.ptr(wc2),
+                   L.ptr(bc2), L.ptr(y), B, V, D, L.dtype_code(dtype), L.stream())
         ctx.save_for_backward(x, c, wc2)
         ctx.shapes = (tuple(wx.shape), tuple(wc.shape) if has_c else None, tuple(c_local.shape) if has_c else None)
         return y
@@ -151,7 +158,24 @@ class _Encode(torch.autograd.Function):
         dc = torch.empty(c_shape, dtype=torch.float32, device=dev) if (has_c and ctx.needs_input_grad[1]) else None
         L.call("tdx_encode_bwd", L.ptr(gy), L.ptr(x), Fx, L.ptr(c), c.shape[0] if has_c else 0, L.ptr(wc2), L.ptr(dwx),
                L.ptr(dbx), L.ptr(dwc), L.ptr(dbc), L.ptr(dc), B, V, D, L.dtype_code(gy.dtype), L.stream())
-        return None, dc, dwx, dbx, dwc, dbc, None
+        return None, dc, dwx, dbx, dwc, dbc, None, None
+
+
+class DeferredEncoding:
+    """What `encode_deferred` returns: `.standin` -- a shape-only tensor (never read) that carries the autograd edge to
+    the encoders -- and `.operands`, from which `resnet_block(..., skip_encoded=...)` evaluates the encoder output inside
+    its tail kernel."""
+
+    def __init__(self, standin, operands):
+        self.standin, self.operands = standin, tuple(operands)
+
+
+def encode_deferred(x, c_local, wx, bx, wc, bc, dtype) -> DeferredEncoding:
+    """`encode` without the (B, X, Y, Z, 2D) tensor: for the case where its only reader is the identity skip of a fused
+    ResnetBlock whose conv runs on another input (DenoisingModel.compose_first_conv)."""
+    ops_ = []
+    standin = _Encode.apply(x, c_local, wx, bx, wc, bc, dtype, ops_)
+    return DeferredEncoding(standin, ops_)
 
 
 def encode_supported(x, c_local, wx):
@@ -843,22 +867,25 @@ class _ResnetBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, film, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps, partial=None, xc=None,
-                xc_real=None):
+                xc_real=None, enc=None):
         """xc: optional separate input of block1's conv (w1 then has xc's channel count); the residual
         path still uses x1.  Used for the U-Net's first block, whose conv is composed with the 1x1
         encoders and therefore runs on the raw input channels (models/ddpm.py, compose_first_conv)."""
-        B, X, Y, Z, C1 = _grid(x1)
+        B, X, Y, Z, C1 = x1.shape if enc is not None else _grid(x1)
         C2 = 0 if x2 is None else x2.shape[-1]
         Cin, Cout = C1 + C2, w1.shape[0]
         if xc is not None:
             assert x2 is None and wr is None and partial is None and xc.shape[:4] == x1.shape[:4]
             xc = xc.contiguous()
+        if enc is not None:
+            # enc: operands of the encoders whose output x1 stands for (encode_deferred); x1 itself is never read
+            assert xc is not None and wr is None and C1 == Cout
         Cc = xc.shape[-1] if xc is not None else Cin
         assert w1.shape[1] == Cc
         V = X * Y * Z
         dev, dt = x1.device, x1.dtype
         code, impl, st = L.dtype_code(dt), L.conv_impl(), L.stream()
-        x1 = x1.contiguous()
+        x1 = x1.contiguous() if enc is None else None
         x2 = None if x2 is None else x2.contiguous()
         wf1, wb1 = _packed_conv3(w1, dt)
         wf2, wb2 = _packed_conv3(w2, dt)
@@ -900,7 +927,12 @@ class _ResnetBlock(torch.autograd.Function):
         wr2 = None
         y = torch.empty_like(h1)
         fused_tail = False
-        if wr is None:
+        if enc is not None:
+            xr, Fx, wx2, bx2, cr, Fc, wc2, bc2, D = enc
+            L.call("tdx_gn_apply_encoded", L.ptr(h2), L.ptr(st2), L.ptr(g2), L.ptr(be2), L.ptr(xr), Fx, L.ptr(wx2), L.ptr(bx2),
+                   L.ptr(cr), Fc, L.ptr(wc2), L.ptr(bc2), L.ptr(y), B, V, D, groups, code, st)
+            fused_tail = True
+        elif wr is None:
             assert x2 is None and Cin == Cout
             res = x1
         else:
@@ -920,7 +952,7 @@ class _ResnetBlock(torch.autograd.Function):
         ctx.save_for_backward(x1, x2, h1, st1, a1, h2, st2, film, g1, be1, g2, be2, wb1, wb2, wr2, xc)
         ctx.cfg = (groups, tuple(w1.shape), tuple(w2.shape), None if wr is None else tuple(wr.shape),
                    b1 is not None, b2 is not None, br is not None)
-        ctx.xc_real, ctx.impl = xc_real, impl
+        ctx.xc_real, ctx.impl, ctx.c1 = xc_real, impl, C1
         return y
 
     @staticmethod
@@ -937,7 +969,8 @@ class _ResnetBlock(torch.autograd.Function):
         x1, x2, h1, st1, a1, h2, st2, film, g1, be1, g2, be2, wb1, wb2, wr2, xc = ctx.saved_tensors
         scale, shift = film[0], film[1]
         groups, w1s, w2s, wrs, hb1, hb2, hbr = ctx.cfg
-        B, X, Y, Z, C1 = _grid(x1)
+        B, X, Y, Z, _ = _grid(h1)
+        C1 = ctx.c1  # (x1 is None when the skip was evaluated from the encoders' operands)
         C2 = 0 if x2 is None else x2.shape[-1]
         Cin, Cout = C1 + C2, w1s[0]
         Cc = w1s[1]  # input channels of block1's conv (= Cin unless the conv has its own input xc)
@@ -984,7 +1017,7 @@ class _ResnetBlock(torch.autograd.Function):
                 L.call("tdx_conv3_bwd_data", L.ptr(dh1), L.ptr(wb1), L.ptr(dxc), Cc, None, 0, 0, B, X, Y, Z, Cout, code, impl,
                        L.ptr(dws), st, work=flops(ctx.xc_real or Cc))
             side.join()
-            return (gy, None, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, dxc, None)
+            return (gy, None, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, dxc, None, None)
         side.run(lambda: L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z,
                                 Cout, code, impl | WS_CLEAN, L.ptr(wws1), L.stream(), work=flops(Cin)), x1, x2, dh1, dw1, db1)
         # ---- input gradient = conv1 data gradient + residual-path gradient
@@ -1007,25 +1040,31 @@ class _ResnetBlock(torch.autograd.Function):
             dwr, dbr = _conv1_weight_grad(x1, C1, x2, C2, gy, Cout, hbr, B * V, code, st)
             dwr = dwr.view(wrs)
         side.join()
-        return (gx1, gx2, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None, None)
+        return (gx1, gx2, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None, None, None)
 
 
 def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, skip_wb, groups, eps=1e-5, partial=None,
-                 conv1_input=None, conv1_real_channels=None, film=None):
+                 conv1_input=None, conv1_real_channels=None, film=None, skip_encoded=None):
     """Fused ResnetBlock; *_wb are (weight, bias) pairs, skip_wb is None for an identity skip.
     Requires SiLU activations and bf16/f32 NDHWC inputs; scale/shift are (B, Cout), or film = the (2, B, Cout)
     [scale, shift] tensor of film_projections (then scale and shift are ignored: no slicing copies either way).
     partial = (n_lead, init): no-grad only, see conv3_shared_tail.
     conv1_input: separate input tensor of block1's conv (conv1_wb then matches ITS channel count);
     conv1_real_channels: how many of its channels carry data (the rest is zero padding) -- bookkeeping for the
-    kernel timers only."""
+    kernel timers only.
+    skip_encoded: a DeferredEncoding whose `.standin` is x1 -- the identity skip is then evaluated from the encoders'
+    operands inside the tail kernel (needs conv1_input: x1 has no data to convolve)."""
     wr, br = skip_wb if skip_wb is not None else (None, None)
+    enc = None
+    if skip_encoded is not None:
+        assert x1 is skip_encoded.standin and conv1_input is not None and skip_wb is None and x2 is None
+        enc = skip_encoded.operands
     if film is None:
         B, Cout = x1.shape[0], conv1_wb[0].shape[0]
         film = torch.stack((scale.reshape(B, Cout).float(), shift.reshape(B, Cout).float()))
     return _ResnetBlock.apply(x1, x2, film, conv1_wb[0], conv1_wb[1], norm1_wb[0], norm1_wb[1], conv2_wb[0],
                               conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps, partial, conv1_input,
-                              conv1_real_channels)
+                              conv1_real_channels, enc)
 
 
 # --------------------------------------------------------------------------- baseline conv variants (SURVEY §8 f4)

@@ -245,6 +245,14 @@ int tdx_gn_stats(const void* x, float* stats, int B, int64_t V, int C, int G, fl
 int tdx_gn_apply(const void* x, const float* stats, const float* gamma, const float* beta, const float* scale,
                  const float* shift, const void* res, void* y, int B, int64_t V, int C, int G, int act, int dtype,
                  void* stream);
+/* y = silu(GroupNorm(x)) + encode(x_raw, c_raw): the tail of the U-Net's first ResnetBlock (ddpm.py:180-197), whose identity
+ * skip is the encoder output cat(encode_x(x), encode_c_local(c_local)) of ddpm.py:495-501.  The skip is evaluated here from
+ * the raw planes (x_raw (B, Fx, V) f32, c_raw (Fc, V) f32 shared by the batch or NULL; wx/wc [D][F], bx/bc [D]; C = 2 D, or D
+ * without c_raw) instead of being written by tdx_encode_fwd and read back, and is rounded to `dtype` before the add: the
+ * result is bit-identical to tdx_encode_fwd + tdx_gn_apply(res = its output, act = 1).  Fx = Fc = 4. */
+int tdx_gn_apply_encoded(const void* x, const float* stats, const float* gamma, const float* beta, const float* x_raw, int Fx,
+                         const float* wx, const float* bx, const float* c_raw, int Fc, const float* wc, const float* bc,
+                         void* y, int B, int64_t V, int D, int G, int dtype, void* stream);
 /* Backward of tdx_gn_apply w.r.t. x, gamma, beta, scale, shift (the residual's gradient is
  * dy itself).  dgamma/dbeta [C], dscale/dshift [B][C] (NULL when no FiLM); overwritten.
  * workspace: tdx_gn_workspace_bytes(). */

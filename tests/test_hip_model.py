@@ -729,6 +729,52 @@ def test_cached_conditioning_conv_matches_plain_forward():
     assert getattr(enc2, "first_conv_partial", None) is None
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_deferred_encoder_output_is_bit_identical(dtype, monkeypatch):
+    """The encoder output feeds only the first block's identity skip once the first conv is composed with the encoders;
+    it is then evaluated inside that block's tail kernel (tdx_gn_apply_encoded, ops.encode_deferred) instead of being
+    written and read back.  Same output and same parameter gradients, bit for bit, as with TDX_DEFER_ENCODE=0 -- in the
+    forward (no-grad: what sampling runs) and through the backward (the stand-in tensor carries the skip's gradient to
+    the encoders)."""
+    from turbdiff_amd import ops as ops_mod
+    from turbdiff_amd.models import ddpm as D
+
+    torch.manual_seed(0)
+    net = D.DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=500, dim=32,
+                           u_net_levels=2, norm_type="group")
+    x = torch.randn(3, 4, 26, 12, 17, generator=torch.Generator().manual_seed(1)).to(dev())
+    c_local = torch.randn(4, 26, 12, 17, generator=torch.Generator().manual_seed(2)).to(dev())
+    t = torch.tensor([3, 250, 499]).to(dev())
+    net.to(dev()).set_compute_dtype(dtype)
+    C = cond(c_local)
+    gy = torch.randn(3, 4, 26, 12, 17, generator=torch.Generator().manual_seed(3)).to(dev())
+
+    def run(defer):
+        monkeypatch.setattr(D, "DEFER_ENCODE", defer)
+        calls = []
+        orig = ops_mod.encode_deferred
+        monkeypatch.setattr(ops_mod, "encode_deferred", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        with torch.no_grad():
+            y0 = net(x, t, C).clone()
+        net.zero_grad(set_to_none=True)
+        y = net(x, t, C)
+        (y * gy).sum().backward()
+        monkeypatch.setattr(ops_mod, "encode_deferred", orig)
+        assert (len(calls) == 2) == defer
+        return y0, y.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()}
+
+    a0, a1, ga = run(True)
+    b0, b1, gb = run(False)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    # gradients: to the run-to-run spread of the backward pass itself -- f32: atomics' summation order (1e-6); bf16: that
+    # order flips a few bf16 roundings of the activation gradients, 5e-3 between two IDENTICAL runs
+    # (tools/micro/dbg_defer_grads.py)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for n in ga:
+        assert rel_l2(ga[n], gb[n]) < tol, n
+    assert ga["encode_x.weight"].abs().sum() > 0
+
+
 OPTION_VARIANTS = {
     "instance": (dict(norm_type="instance"), {}),
     "layer": (dict(norm_type="layer"), {}),

@@ -358,6 +358,38 @@ def test_p_sample_step_rng_refuses_unaligned_planes():
     assert not ops.p_sample_step_rng_supported(x)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("with_c", [True, False])
+def test_gn_apply_encoded_equals_encode_then_apply_bitwise(dtype, with_c):
+    """include/tdx.h: tdx_gn_apply_encoded == tdx_encode_fwd + tdx_gn_apply(res = its output, act = 1), bit for bit;
+    V chosen so that the kernel runs full trips and a ragged tail."""
+    from turbdiff_amd import _lib as L, ops
+
+    d = dev()
+    B, D, G, grid = 2, 32, 8, (13, 9, 11)
+    V = grid[0] * grid[1] * grid[2]
+    C = 2 * D if with_c else D
+    x = rnd(B, 4, *grid, seed=1).to(d)
+    c = rnd(4, *grid, seed=2).to(d) if with_c else None
+    wx, bx = rnd(D, 4, 1, 1, 1, seed=3).to(d), rnd(D, seed=4).to(d)
+    wc, bc = (rnd(D, 4, 1, 1, 1, seed=5).to(d), rnd(D, seed=6).to(d)) if with_c else (None, None)
+    h2 = rnd(B, *grid, C, seed=7).to(d).to(dtype)
+    stats = torch.stack((rnd(B, G, seed=8) * 0.1, rnd(B, G, seed=9).abs() + 0.5), dim=-1).contiguous().to(d)
+    gamma, beta = rnd(C, seed=10).to(d), rnd(C, seed=11).to(d)
+    code = L.dtype_code(dtype)
+
+    res = ops.encode(x, c, wx, bx, wc, bc, dtype)
+    ref = torch.empty_like(h2)
+    L.call("tdx_gn_apply", L.ptr(h2), L.ptr(stats), L.ptr(gamma), L.ptr(beta), None, None, L.ptr(res), L.ptr(ref), B, V, C, G,
+           1, code, L.stream())
+    out = torch.empty_like(h2)
+    w2 = lambda w: None if w is None else w.reshape(D, 4).contiguous()
+    wx2, wc2 = w2(wx), w2(wc)
+    L.call("tdx_gn_apply_encoded", L.ptr(h2), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(x), 4, L.ptr(wx2), L.ptr(bx),
+           L.ptr(c), 4 if with_c else 0, L.ptr(wc2), L.ptr(bc), L.ptr(out), B, V, D, G, code, L.stream())
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("l1", [False, True])
 def test_masked_loss(l1):
     from turbdiff_amd import ops
