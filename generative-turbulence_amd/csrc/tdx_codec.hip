@@ -226,7 +226,7 @@ decode_fwd_kernel(const T* __restrict__ h, const float* __restrict__ w, const fl
         for (int f = 0; f < F; ++f) {
             float t = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t += wr[f][j] * a.v[j];
+            for (int j = 0; j < 8; ++j) t = __builtin_fmaf(wr[f][j], a.v[j], t);  // explicit: gn_apply_decode_kernel repeats it
             for (int o = 1; o < L; o <<= 1) t += __shfl_xor(t, o, 64);
             if (ok && lc == 0) y[((int64_t)b * F + f) * V + v] = t + bias[f];
         }

@@ -219,6 +219,10 @@ static int gn_blocks_per_sample(int B, int64_t V, int C) {
     return want < 1 ? 1 : (int)want;
 }
 
+// silu(n) + r as ONE explicit fma: the three tail kernels (apply / apply_encoded / apply_decode) promise bit-identical
+// results, which must not hinge on the compiler contracting n * sigmoid(n) + r the same way in each
+__device__ __forceinline__ float silu_add(float n, float r) { return __builtin_fmaf(n, sigmoid_f(n), r); }
+
 template <typename T, bool HAS_RES, bool ACT>
 __global__ void __launch_bounds__(GN_THREADS)
 gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -240,8 +244,11 @@ gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ stats, const 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float n = __builtin_fmaf(a.v[j], k.a[j], k.c0[j]);
-            o.v[j] = ACT ? silu_f(n) : n;
-            if (HAS_RES) o.v[j] += rr.v[j];
+            if (ACT && HAS_RES) o.v[j] = silu_add(n, rr.v[j]);
+            else {
+                o.v[j] = ACT ? silu_f(n) : n;
+                if (HAS_RES) o.v[j] += rr.v[j];
+            }
         }
         o.store(y + base + vv * C);
     };
@@ -333,7 +340,7 @@ gn_apply_encoded_kernel(const T* __restrict__ x, const float* __restrict__ stats
 #pragma unroll
             for (int q = 0; q < F; ++q) e = __builtin_fmaf(wr[j][q], in[q], e);  // encode_fwd_kernel's chain, bit for bit
             const float n = __builtin_fmaf(a.v[j], k.a[j], k.c0[j]);
-            o.v[j] = silu_f(n) + round_as<T>(e);
+            o.v[j] = silu_add(n, round_as<T>(e));
         }
         o.store(y + base + vv * C);
     };
@@ -373,6 +380,84 @@ extern "C" int tdx_gn_apply_encoded(const void* x, const float* stats, const flo
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_encoded_kernel<T, 4>), grid, dim3(GN_THREADS), 0,
                                                  as_stream(stream), (const T*)x, stats, gamma, beta, x_raw, wx, bx, c_raw,
                                                  wc, bc, (T*)y, V, C, D, G));
+    return tdx_launch_status();
+}
+
+// ---- out = decode(silu(GN(x)) + res): the tail of the model's LAST ResnetBlock (decode[0], ddpm.py:429) followed by the
+// dim -> F 1x1 decoder and the NDHWC -> NCDHW layout change (decode[1], ddpm.py:505), inference only.  The block output
+// (B, V, C) is neither written nor read back: per voxel 2 x (C x 2 B) of HBM traffic disappear.  The block output is
+// rounded to T before the dot product and the dot product is decode_fwd_kernel's explicit FMA chain + the same butterfly,
+// so the result is bit-identical to tdx_gn_apply(res, act = 1) + tdx_decode_fwd.
+template <typename T, int F>
+__global__ void __launch_bounds__(GN_THREADS)
+gn_apply_decode_kernel(const T* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                       const float* __restrict__ beta, const T* __restrict__ res, const float* __restrict__ w,
+                       const float* __restrict__ bias, float* __restrict__ out, int64_t V, int C, int G) {
+    const int b = blockIdx.y;
+    const int L = C >> 3;  // a power of two <= 64 (checked by the host): the L lanes of a voxel are adjacent in a wave
+    const int rows = GN_THREADS / L;
+    const int tid = threadIdx.x;
+    const int lc = tid % L, r = tid / L;
+    GnCoef k;
+    float mean[8], rstd[8], gam[8], film[8];
+    gn_load_coef(k, mean, rstd, gam, film, stats, gamma, beta, nullptr, nullptr, b, C, G, lc * 8);
+    float wr[F][8], bf[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        bf[f] = bias[f];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wr[f][j] = w[f * C + lc * 8 + j];
+    }
+    const int64_t base = ((int64_t)b * V) * C + lc * 8;
+    const int64_t stride = (int64_t)gridDim.x * rows;
+    auto one = [&](const Vec8<T>& a, const Vec8<T>& rr, int64_t vv, bool ok) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float n = __builtin_fmaf(a.v[j], k.a[j], k.c0[j]);
+            o[j] = round_as<T>(silu_add(n, rr.v[j]));
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t = __builtin_fmaf(wr[f][j], o[j], t);
+            for (int q = 1; q < L; q <<= 1) t += __shfl_xor(t, q, 64);
+            if (ok && lc == 0) out[((int64_t)b * F + f) * V + vv] = t + bf[f];
+        }
+    };
+    // every lane of a wave takes part in the butterflies: the loop bound is uniform per voxel group, and lanes past the
+    // end (or the spare threads when 256 % L != 0 -- not with L a power of two) compute on zeros
+    int64_t v = (int64_t)blockIdx.x * rows + r;
+    for (; v + (GN_UNROLL - 1) * stride < V; v += stride * GN_UNROLL) {
+        Raw8<T> a[GN_UNROLL], rr[GN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            a[u].load(x + base + (v + u * stride) * C);
+            rr[u].load(res + base + (v + u * stride) * C);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // all loads of the trip are issued before any arithmetic
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) one(a[u].get(), rr[u].get(), v + u * stride, true);
+    }
+    for (; v < V; v += stride) {
+        Vec8<T> a, rr;
+        a.load(x + base + v * C);
+        rr.load(res + base + v * C);
+        one(a, rr, v, true);
+    }
+}
+
+extern "C" int tdx_gn_apply_decode(const void* x, const float* stats, const float* gamma, const float* beta, const void* res,
+                                   const float* w, const float* bias, float* out, int B, int64_t V, int C, int G, int F,
+                                   int dtype, void* stream) {
+    TDX_CHECK_ARG(x && stats && gamma && beta && res && w && bias && out && B > 0 && V > 0);
+    const int L = C / 8;
+    if (!gn_shape_ok(C, G) || F != 4 || L > 64 || (L & (L - 1)) != 0) return TDX_ESHAPE;
+    dim3 grid(gn_blocks_per_sample(B, V, C), B);
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_apply_decode_kernel<T, 4>), grid, dim3(GN_THREADS), 0,
+                                                 as_stream(stream), (const T*)x, stats, gamma, beta, (const T*)res, w, bias,
+                                                 out, V, C, G));
     return tdx_launch_status();
 }
 

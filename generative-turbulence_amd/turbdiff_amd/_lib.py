@@ -57,6 +57,7 @@ SIGNATURES = {
     "tdx_gn_workspace_bytes": (_sz, [_i, _i]),
     "tdx_gn_stats": (_i, [_vp, _vp, _i, _i64, _i, _i, _f, _i, _vp, _vp]),
     "tdx_gn_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
+    "tdx_gn_apply_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _i, _vp]),
     "tdx_gn_apply_encoded": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "tdx_gn_bwd": (_i, [_vp] * 12 + [_i, _i64, _i, _i, _i, _i, _vp, _vp]),
     "tdx_resize_fwd": (_i, [_vp, _vp] + [_i] * 9 + [_vp]),

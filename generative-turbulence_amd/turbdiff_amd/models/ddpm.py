@@ -83,6 +83,8 @@ FUSE_BLOCKS = _os.environ.get("TDX_FUSE_BLOCKS", "1") != "0"
 COMPOSE_FIRST_CONV = _os.environ.get("TDX_COMPOSE_FIRST_CONV", "1") != "0"
 # TDX_DEFER_ENCODE=0: the encoder output is written by tdx_encode_fwd and read back by the first block's skip (A/B switch)
 DEFER_ENCODE = _os.environ.get("TDX_DEFER_ENCODE", "1") != "0"
+# TDX_FUSE_DECODE=0: inference writes the last block's output and runs tdx_decode_fwd on it, as training does (A/B switch)
+FUSE_DECODE = _os.environ.get("TDX_FUSE_DECODE", "1") != "0"
 # TDX_CACHE_COND_CONV=0: sampling recomputes the conditioning half of the first conv every step (A/B switch)
 CACHE_COND_CONV = _os.environ.get("TDX_CACHE_COND_CONV", "1") != "0"
 
@@ -134,12 +136,14 @@ class ResnetBlock(nn.Module):
         identity = isinstance(self.conv, nn.Identity)
         return self.block1._fused_act and self.block2._fused_act and not (identity and x2 is not None) and FUSE_BLOCKS
 
-    def forward(self, x, c, x2=None, partial=None, conv1=None, films=None, skip_encoded=None):
+    def forward(self, x, c, x2=None, partial=None, conv1=None, films=None, skip_encoded=None, decode_wb=None):
         """partial = (n_lead, init): inference only -- block1's conv runs over the leading n_lead channels
         of x and continues from `init`, the precomputed conv of the batch-shared remaining channels.
         conv1 = (input, weight, bias): block1's conv replaced by an equivalent conv on another input
         (DenoisingModel.compose_first_conv); x still feeds the identity skip -- or, with skip_encoded (an
         ops.DeferredEncoding whose stand-in x is), the skip is evaluated from the encoders' operands in the tail kernel.
+        decode_wb = (weight, bias) of the model's final 1x1 conv: inference only -- returns that conv's (B, F, X, Y, Z)
+        output, computed in the tail kernel (ops.decode_fused_supported).
         films = {id(block): (2, B, dim_out) scale | shift}: the projections of all blocks computed up front in one
         launch (DenoisingModel.film_table); without it the block projects `c` itself."""
         film = films.get(id(self)) if films is not None else None
@@ -162,8 +166,8 @@ class ResnetBlock(nn.Module):
             return ops.resnet_block(x, x2, scale, shift, (b1.conv.weight, b1.conv.bias), (b1.norm.weight, b1.norm.bias),
                                     (b2.conv.weight, b2.conv.bias), (b2.norm.weight, b2.norm.bias),
                                     None if identity else (self.conv.weight, self.conv.bias), _norm_groups(b1.norm),
-                                    b1.norm.eps, partial=partial, film=film)
-        assert partial is None and conv1 is None and skip_encoded is None
+                                    b1.norm.eps, partial=partial, film=film, decode_wb=decode_wb)
+        assert partial is None and conv1 is None and skip_encoded is None and decode_wb is None
         h = self.block1(x, scale_shift=(scale, shift), x2=x2)
         if isinstance(self.conv, nn.Identity):
             skip = x if x2 is None else torch.cat((x, x2), dim=-1)
@@ -448,6 +452,15 @@ class DenoisingModel(nn.Module):
             return None
         raw = ops.encode(x, c_local, eye[0], eye[2], eye[1], eye[2], self.compute_dtype)  # [x | 0 | c | 0]
         W1, b1 = first.block1.conv.weight, first.block1.conv.bias
+        # without autograd (sampling: T forwards on the same weights) the composed weight is kept until one of the six
+        # tensors it is made of changes: no einsum / gather / repack launches per reverse step
+        frozen = not torch.is_grad_enabled()
+        if frozen:
+            made_of = (W1, b1, self.encode_x.weight, self.encode_x.bias, self.encode_c_local.weight, self.encode_c_local.bias)
+            key = (P,) + tuple((id(p), p._version, p.data_ptr()) for p in made_of)
+            hit = getattr(self, "_composed_frozen", None)
+            if hit is not None and hit[0] == key:
+                return raw, hit[1], hit[2], self.in_features + self.c_local_features
         # one contraction of the full weight with the block-diagonal encoder matrix (few autograd nodes on
         # the 3x3x3 weight), then the raw channels are spread to their padded positions by a constant gather
         w_enc = torch.block_diag(self.encode_x.weight.flatten(1), self.encode_c_local.weight.flatten(1))  # (2D, Fx + Fc)
@@ -455,6 +468,8 @@ class DenoisingModel(nn.Module):
         w8 = torch.einsum("octuv,ck->oktuv", W1, w_enc)
         w_eff = torch.cat((w8, eye[3]), dim=1).index_select(1, eye[4])
         b_eff = b1 + torch.einsum("octuv,c->o", W1, b_enc)
+        if frozen:
+            self._composed_frozen = (key, w_eff, b_eff)
         return raw, w_eff, b_eff, self.in_features + self.c_local_features
 
     def forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
@@ -489,7 +504,12 @@ class DenoisingModel(nn.Module):
         self.prefetch_weights(skip_first_conv=first_conv is not None)
         films = self.film_table(c)
         h = self.u_net(h, c, first_partial=partial, first_conv=first_conv, films=films, first_skip=first_skip)
-        h = self.decode[0](h, c, films=films)
+        last = self.decode[0]
+        if (FUSE_DECODE and isinstance(last, ResnetBlock) and last.fused() and isinstance(last.conv, nn.Identity)
+                and self.decode[1].bias is not None and ops.decode_fused_supported(last.dim_out, self.decode[1].weight)):
+            # inference: the last block's output exists only inside its tail kernel, which applies the decoder
+            return last(h, c, films=films, decode_wb=(self.decode[1].weight, self.decode[1].bias))
+        h = last(h, c, films=films)
         if ops.decode_supported(h, self.decode[1].weight):
             return ops.decode(h, self.decode[1].weight, self.decode[1].bias)
         y = ops.conv1(h, self.decode[1].weight, self.decode[1].bias)

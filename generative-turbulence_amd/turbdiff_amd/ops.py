@@ -229,6 +229,13 @@ def decode(h, w, bias):
     return _Decode.apply(h, w, bias)
 
 
+def decode_fused_supported(C: int, w) -> bool:
+    """resnet_block(..., decode_wb=(w, bias)) on a block with C output channels: inference only."""
+    n = C // 8
+    return (not torch.is_grad_enabled() and w.shape[0] == 4 and w.shape[1] == C and C % 8 == 0 and n & (n - 1) == 0
+            and n <= 64)
+
+
 # --------------------------------------------------------------------------- conv 3x3x3
 
 # packed operands are cached per (parameter, version, dtype): repacked once per optimiser
@@ -867,7 +874,7 @@ class _ResnetBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, film, w1, b1, g1, be1, w2, b2, g2, be2, wr, br, groups, eps, partial=None, xc=None,
-                xc_real=None, enc=None):
+                xc_real=None, enc=None, dec=None):
         """xc: optional separate input of block1's conv (w1 then has xc's channel count); the residual
         path still uses x1.  Used for the U-Net's first block, whose conv is composed with the 1x1
         encoders and therefore runs on the raw input channels (models/ddpm.py, compose_first_conv)."""
@@ -927,6 +934,17 @@ class _ResnetBlock(torch.autograd.Function):
         wr2 = None
         y = torch.empty_like(h1)
         fused_tail = False
+        if dec is not None:
+            # inference only: the block output goes straight through the model's 1x1 decoder (tdx_gn_apply_decode) and is
+            # never written; returns the decoded (B, F, X, Y, Z) f32 tensor instead of the block output
+            assert wr is None and enc is None and x2 is None and Cin == Cout and not torch.is_grad_enabled()
+            wd, bd = dec
+            F = wd.shape[0]
+            out = torch.empty((B, F, X, Y, Z), dtype=torch.float32, device=dev)
+            L.call("tdx_gn_apply_decode", L.ptr(h2), L.ptr(st2), L.ptr(g2), L.ptr(be2), L.ptr(x1),
+                   L.ptr(wd.detach().reshape(F, Cout).float().contiguous()), L.ptr(bd.detach().float().contiguous()), L.ptr(out),
+                   B, V, Cout, groups, F, code, st)
+            return out
         if enc is not None:
             xr, Fx, wx2, bx2, cr, Fc, wc2, bc2, D = enc
             L.call("tdx_gn_apply_encoded", L.ptr(h2), L.ptr(st2), L.ptr(g2), L.ptr(be2), L.ptr(xr), Fx, L.ptr(wx2), L.ptr(bx2),
@@ -1017,7 +1035,8 @@ class _ResnetBlock(torch.autograd.Function):
                 L.call("tdx_conv3_bwd_data", L.ptr(dh1), L.ptr(wb1), L.ptr(dxc), Cc, None, 0, 0, B, X, Y, Z, Cout, code, impl,
                        L.ptr(dws), st, work=flops(ctx.xc_real or Cc))
             side.join()
-            return (gy, None, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, dxc, None, None)
+            return (gy, None, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, None, None, None, None, None, dxc, None, None,
+                    None)
         side.run(lambda: L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(dh1), L.ptr(dw1), L.ptr(db1), B, X, Y, Z,
                                 Cout, code, impl | WS_CLEAN, L.ptr(wws1), L.stream(), work=flops(Cin)), x1, x2, dh1, dw1, db1)
         # ---- input gradient = conv1 data gradient + residual-path gradient
@@ -1040,11 +1059,11 @@ class _ResnetBlock(torch.autograd.Function):
             dwr, dbr = _conv1_weight_grad(x1, C1, x2, C2, gy, Cout, hbr, B * V, code, st)
             dwr = dwr.view(wrs)
         side.join()
-        return (gx1, gx2, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None, None, None)
+        return (gx1, gx2, dfilm, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dwr, dbr, None, None, None, None, None, None, None)
 
 
 def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, skip_wb, groups, eps=1e-5, partial=None,
-                 conv1_input=None, conv1_real_channels=None, film=None, skip_encoded=None):
+                 conv1_input=None, conv1_real_channels=None, film=None, skip_encoded=None, decode_wb=None):
     """Fused ResnetBlock; *_wb are (weight, bias) pairs, skip_wb is None for an identity skip.
     Requires SiLU activations and bf16/f32 NDHWC inputs; scale/shift are (B, Cout), or film = the (2, B, Cout)
     [scale, shift] tensor of film_projections (then scale and shift are ignored: no slicing copies either way).
@@ -1053,7 +1072,10 @@ def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, s
     conv1_real_channels: how many of its channels carry data (the rest is zero padding) -- bookkeeping for the
     kernel timers only.
     skip_encoded: a DeferredEncoding whose `.standin` is x1 -- the identity skip is then evaluated from the encoders'
-    operands inside the tail kernel (needs conv1_input: x1 has no data to convolve)."""
+    operands inside the tail kernel (needs conv1_input: x1 has no data to convolve).
+    decode_wb = (weight (F, C, 1, 1, 1), bias): no-grad only, identity-skip blocks only -- returns
+    decode(block output) as (B, F, X, Y, Z) f32 (ops.decode's result) without writing the block output
+    (decode_fused_supported says when)."""
     wr, br = skip_wb if skip_wb is not None else (None, None)
     enc = None
     if skip_encoded is not None:
@@ -1064,7 +1086,7 @@ def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, s
         film = torch.stack((scale.reshape(B, Cout).float(), shift.reshape(B, Cout).float()))
     return _ResnetBlock.apply(x1, x2, film, conv1_wb[0], conv1_wb[1], norm1_wb[0], norm1_wb[1], conv2_wb[0],
                               conv2_wb[1], norm2_wb[0], norm2_wb[1], wr, br, groups, eps, partial, conv1_input,
-                              conv1_real_channels, enc)
+                              conv1_real_channels, enc, decode_wb)
 
 
 # --------------------------------------------------------------------------- baseline conv variants

@@ -253,6 +253,13 @@ int tdx_gn_apply(const void* x, const float* stats, const float* gamma, const fl
 int tdx_gn_apply_encoded(const void* x, const float* stats, const float* gamma, const float* beta, const float* x_raw, int Fx,
                          const float* wx, const float* bx, const float* c_raw, int Fc, const float* wc, const float* bc,
                          void* y, int B, int64_t V, int D, int G, int dtype, void* stream);
+/* out = decode(silu(GroupNorm(x)) + res): the tail of the model's last ResnetBlock (decode[0], ddpm.py:429) fused with the
+ * dim -> F 1x1 decoder and the NDHWC -> NCDHW layout change (decode[1], ddpm.py:505); inference only (the block output, which
+ * the decoder's weight gradient would need, is never written).  w [F][C] f32, bias [F]; out (B, F, V) f32; F = 4, C / 8 a power
+ * of two.  Bit-identical to tdx_gn_apply(res, act = 1) + tdx_decode_fwd. */
+int tdx_gn_apply_decode(const void* x, const float* stats, const float* gamma, const float* beta, const void* res,
+                        const float* w, const float* bias, float* out, int B, int64_t V, int C, int G, int F, int dtype,
+                        void* stream);
 /* Backward of tdx_gn_apply w.r.t. x, gamma, beta, scale, shift (the residual's gradient is
  * dy itself).  dgamma/dbeta [C], dscale/dshift [B][C] (NULL when no FiLM); overwritten.
  * workspace: tdx_gn_workspace_bytes(). */

@@ -775,6 +775,40 @@ def test_deferred_encoder_output_is_bit_identical(dtype, monkeypatch):
     assert ga["encode_x.weight"].abs().sum() > 0
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_inference_decodes_inside_the_last_block_bit_identically(dtype, monkeypatch):
+    """Without autograd the last ResnetBlock's tail kernel applies the 1x1 decoder itself (tdx_gn_apply_decode): same
+    output, bit for bit, as with TDX_FUSE_DECODE=0; with autograd on, the block output is kept (the decoder's weight
+    gradient needs it) and the fused route is not taken."""
+    from turbdiff_amd import _lib as L
+    from turbdiff_amd.models import ddpm as D
+
+    torch.manual_seed(0)
+    net = D.DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=500, dim=32,
+                           u_net_levels=2, norm_type="group")
+    x = torch.randn(3, 4, 26, 12, 17, generator=torch.Generator().manual_seed(1)).to(dev())
+    c_local = torch.randn(4, 26, 12, 17, generator=torch.Generator().manual_seed(2)).to(dev())
+    t = torch.tensor([3, 250, 499]).to(dev())
+    net.to(dev()).set_compute_dtype(dtype)
+    C = cond(c_local)
+    seen = []
+    orig = L.call
+    monkeypatch.setattr(L, "call", lambda name, *a, **k: (seen.append(name), orig(name, *a, **k))[1])
+    with torch.no_grad():
+        fused = net(x, t, C).clone()
+    assert "tdx_gn_apply_decode" in seen and "tdx_decode_fwd" not in seen
+    seen.clear()
+    monkeypatch.setattr(D, "FUSE_DECODE", False)
+    with torch.no_grad():
+        plain = net(x, t, C).clone()
+    assert "tdx_decode_fwd" in seen and "tdx_gn_apply_decode" not in seen
+    assert torch.equal(fused, plain)
+    monkeypatch.setattr(D, "FUSE_DECODE", True)
+    seen.clear()
+    y = net(x, t, C)
+    assert "tdx_decode_fwd" in seen and "tdx_gn_apply_decode" not in seen and y.requires_grad
+
+
 OPTION_VARIANTS = {
     "instance": (dict(norm_type="instance"), {}),
     "layer": (dict(norm_type="layer"), {}),

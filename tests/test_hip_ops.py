@@ -390,6 +390,32 @@ def test_gn_apply_encoded_equals_encode_then_apply_bitwise(dtype, with_c):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("C", [32, 64])
+def test_gn_apply_decode_equals_apply_then_decode_bitwise(dtype, C):
+    """include/tdx.h: tdx_gn_apply_decode == tdx_gn_apply(res, act = 1) + tdx_decode_fwd, bit for bit."""
+    from turbdiff_amd import _lib as L, ops
+
+    d = dev()
+    B, G, grid = 2, 8, (13, 9, 11)
+    V = grid[0] * grid[1] * grid[2]
+    h2 = rnd(B, *grid, C, seed=1).to(d).to(dtype)
+    res = rnd(B, *grid, C, seed=2).to(d).to(dtype)
+    stats = torch.stack((rnd(B, G, seed=8) * 0.1, rnd(B, G, seed=9).abs() + 0.5), dim=-1).contiguous().to(d)
+    gamma, beta = rnd(C, seed=10).to(d), rnd(C, seed=11).to(d)
+    w, bias = rnd(4, C, 1, 1, 1, seed=12).to(d), rnd(4, seed=13).to(d)
+    code = L.dtype_code(dtype)
+    y = torch.empty_like(h2)
+    L.call("tdx_gn_apply", L.ptr(h2), L.ptr(stats), L.ptr(gamma), L.ptr(beta), None, None, L.ptr(res), L.ptr(y), B, V, C, G, 1,
+           code, L.stream())
+    ref = ops.decode(y, w, bias)
+    out = torch.empty_like(ref)
+    w2 = w.reshape(4, C).contiguous()
+    L.call("tdx_gn_apply_decode", L.ptr(h2), L.ptr(stats), L.ptr(gamma), L.ptr(beta), L.ptr(res), L.ptr(w2), L.ptr(bias),
+           L.ptr(out), B, V, C, G, 4, code, L.stream())
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("l1", [False, True])
 def test_masked_loss(l1):
     from turbdiff_amd import ops
