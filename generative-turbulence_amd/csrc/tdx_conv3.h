@@ -112,3 +112,6 @@ int conv3_direct_launch(const void* x1, int C1, const void* x2, int C2, const vo
 #define TDX_GN_REPLICAS 32  // == GN_REPLICAS in tdx_groupnorm.hip (sizes tdx_gn_workspace_bytes)
 int gn_finalize_launch(double* acc, float* stats, int B, int C, int G, int64_t V, float eps, int replicas,
                        hipStream_t st);
+// tdx_gn_stats with the TDX_WS_CLEAN promise passed through (tdx_groupnorm.hip)
+int gn_stats_launch(const void* x, float* stats, int B, int64_t V, int C, int G, float eps, int dtype, void* workspace,
+                    bool clean, hipStream_t stream);

@@ -655,7 +655,7 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
         hipStream_t st = as_stream(stream);
         if (f32_split) {  // deep U-Net levels: small-grid conv, then the statistics pass over its (tiny) result
             int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false, true, st);
-            if (rs == TDX_OK) return tdx_gn_stats(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, stream);
+            if (rs == TDX_OK) return gn_stats_launch(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, clean, st);
             if (rs != TDX_ESHAPE) return rs;
         }
         double* acc = (double*)gn_workspace;
@@ -678,7 +678,7 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     hipStream_t st = as_stream(stream);
     {   // deep U-Net levels: small-grid conv, then the statistics pass over its (tiny) result
         int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false, false, st);
-        if (rs == TDX_OK) return tdx_gn_stats(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, stream);
+        if (rs == TDX_OK) return gn_stats_launch(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, clean, st);
         if (rs != TDX_ESHAPE) return rs;
     }
     double* acc = (double*)gn_workspace;

@@ -143,22 +143,34 @@ int gn_finalize_launch(double* acc, float* stats, int B, int C, int G, int64_t V
     return tdx_launch_status();
 }
 
+int gn_stats_launch(const void* x, float* stats, int B, int64_t V, int C, int G, float eps, int dtype, void* workspace,
+                    bool clean, hipStream_t stream);  // also declared in tdx_conv3.h for tdx_conv3_fwd_gn
+
 extern "C" int tdx_gn_stats(const void* x, float* stats, int B, int64_t V, int C, int G, float eps, int dtype,
                             void* workspace, void* stream) {
+    return gn_stats_launch(x, stats, B, V, C, G, eps, dtype, workspace, false, as_stream(stream));
+}
+
+// clean: the caller vouches that the accumulators are all-zero (TDX_WS_CLEAN: a workspace zeroed once and only ever
+// used by launches whose finalize pass re-zeroes what it read) -- no memset launch then
+int gn_stats_launch(const void* x, float* stats, int B, int64_t V, int C, int G, float eps, int dtype, void* workspace,
+                    bool clean, hipStream_t stream) {
     TDX_CHECK_ARG(x && stats && workspace && B > 0 && V > 0);
     if (!gn_shape_ok(C, G)) return TDX_ESHAPE;
     double* acc = (double*)workspace;
-    hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * C * 2 * sizeof(double), as_stream(stream));
-    if (e != hipSuccess) return (int)e;
+    if (!clean) {
+        hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * C * 2 * sizeof(double), stream);
+        if (e != hipSuccess) return (int)e;
+    }
     // voxels per block: 1024 on big tensors; on the small ones of the deep U-Net levels (where this pass is used: the
     // small-grid conv kernels do not accumulate moments) enough blocks to put ~128 on the chip -- 12 blocks of 256 serial
     // trips took 27 us for 7 MB, profiles/r11_batch_scaling.txt -- but not so many that the f64 atomics take over
     int64_t vpb = ((int64_t)B * V + 127) / 128;
     vpb = vpb < 32 ? 32 : (vpb > GN_VOX_PER_BLOCK ? GN_VOX_PER_BLOCK : (vpb + 31) / 32 * 32);
     dim3 grid(ceil_div(V, vpb), B);
-    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(GN_THREADS), 0, as_stream(stream),
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(GN_THREADS), 0, stream,
                                                   (const T*)x, acc, V, C, (int)vpb));
-    hipLaunchKernelGGL(gn_stats_finalize, dim3(B * G), dim3(64), 0, as_stream(stream), acc, stats, B, C, G, V, eps, 1);
+    hipLaunchKernelGGL(gn_stats_finalize, dim3(B * G), dim3(64), 0, stream, acc, stats, B, C, G, V, eps, 1);
     return tdx_launch_status();
 }
 

@@ -391,6 +391,15 @@ class DenoisingModel(nn.Module):
                 parts.append(self.geometry_embedding(c_local).expand((batch_size, -1)))
         return self.process_c(torch.cat(parts, dim=-1))
 
+    def conditioning_table(self, C, timesteps: int):
+        """(timesteps, c_dim) tensor whose row t is conditioning_vector(t, C, 1) -- when that vector depends on t alone (no
+        global conditioning, no geometry embedding: the shipped configuration, config/model/diffusion.yaml) -- else None.
+        A sampler computes it once and passes its row as `cond=` instead of running the time MLP every reverse step."""
+        if global_conditioning(C) is not None or self.with_geometry_embedding:
+            return None
+        dev = next(self.parameters()).device
+        return self.conditioning_vector(torch.arange(timesteps, device=dev), C, timesteps)
+
     def encode_local(self, C):
         """encode_c_local(c_local) as a (1, X, Y, Z, dim) NDHWC tensor (None without local
         conditioning).  Independent of x and t: sampling computes it once per trajectory batch
@@ -472,14 +481,15 @@ class DenoisingModel(nn.Module):
             self._composed_frozen = (key, w_eff, b_eff)
         return raw, w_eff, b_eff, self.in_features + self.c_local_features
 
-    def forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
+    def forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None, cond=None):
+        """cond: the (B, c_dim) conditioning vectors, if the caller already has them (rows of conditioning_table)."""
         # conv_impl: this model's own choice of the 3x3x3 conv arithmetic (None: the process-wide default)
         with _lib.conv_impl_scope(self.conv_impl):
-            return self._forward(x, t, C, encoded_local)
+            return self._forward(x, t, C, encoded_local, cond)
 
-    def _forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None):
+    def _forward(self, x: torch.Tensor, t: torch.Tensor, C, encoded_local=None, cond=None):
         B = x.shape[0]
-        c = self.conditioning_vector(t, C, B)
+        c = self.conditioning_vector(t, C, B) if cond is None else cond
         c_local = local_conditioning(C) if self.c_local_features > 0 else None
         first_conv = first_skip = None
         if ops.encode_supported(x, c_local, self.encode_x.weight):

@@ -24,6 +24,8 @@ from . import ops
 # TDX_FUSED_STEP_NOISE=0: draw z / z2 into tensors with tdx_randn_batched and run tdx_p_sample_step on them (the same
 # values; the A/B switch for the in-kernel draw)
 FUSED_STEP_NOISE = os.environ.get("TDX_FUSED_STEP_NOISE", "1") != "0"
+# TDX_COND_TABLE=0: the time MLP runs every reverse step instead of one look-up in a per-timestep table (A/B switch)
+COND_TABLE = os.environ.get("TDX_COND_TABLE", "1") != "0"
 
 
 class GraphSampler:
@@ -60,6 +62,8 @@ class GraphSampler:
         self._capture_stream = None  # ONE stream for every capture of this sampler (its scratch arena is per stream)
         with torch.no_grad():
             self.enc = diffusion.model.encode_local(self.C)
+        self.c_table = None  # (T, c_dim) conditioning vectors per timestep (DenoisingModel.conditioning_table) or None
+        self._refresh_tables()
         self.reset()
 
     @staticmethod
@@ -105,6 +109,23 @@ class GraphSampler:
             self.stream_ids.copy_(torch.tensor(self._sids(ids, nn), dtype=torch.int64))
         return self
 
+    @torch.no_grad()
+    def _refresh_tables(self):
+        """What the step reads that is a function of the WEIGHTS alone: recomputed into the same tensors after a weight
+        update (the captured graph keeps their addresses)."""
+        tab = self.d.model.conditioning_table(self.C, self.d.num_timesteps) if COND_TABLE else None
+        old = self.c_table
+        if tab is not None and old is not None and tab.shape == old.shape and tab.dtype == old.dtype:
+            old.copy_(tab)
+        else:
+            if tab is not None or old is not None:
+                self.graph = None  # another structure than the captured one
+            self.c_table = tab
+        self._table_versions = [(p, p._version) for p in self.d.parameters()]
+
+    def _tables_stale(self) -> bool:
+        return any(p._version != v for p, v in self._table_versions)
+
     # ---- state
     def _randn(self, out):
         return ops.randn_philox_batched(out, self.seed, self.stream_ids, self.offset)
@@ -128,6 +149,9 @@ class GraphSampler:
     def _step(self):
         d = self.d
         kw = {"encoded_local": self.enc} if self.enc is not None else {}
+        if self.c_table is not None:
+            # all trajectories are at the same t: one row of the table instead of the time MLP (~12 launches per step)
+            kw["cond"] = self.c_table.index_select(0, self.t).expand(self.B, -1)
         eps = d.model(self.x_t, self.t.expand(self.B), self.C, **kw)
         if self.fused_noise:
             # same draws, same counters, bit-identical x_{t-1}; also advances the offset and decrements t
@@ -173,6 +197,8 @@ class GraphSampler:
     @torch.no_grad()
     def run_steps(self, n: int, pbar: bool = False):
         n = min(n, self.steps_left)
+        if self._tables_stale():
+            self._refresh_tables()
         if self.use_graph and (self.graph is None or self._stale()):
             self._capture()
         steps = range(n)

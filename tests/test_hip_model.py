@@ -532,6 +532,41 @@ def test_graph_sampler_recaptures_after_a_weight_update(golden):
     assert rel_l2(after, eager) < 1e-5 and rel_l2(after, before) > 1e-3
 
 
+def test_conditioning_table_row_equals_the_time_mlp(golden):
+    """DenoisingModel.conditioning_table: row t is the conditioning vector the model computes for timestep t (the sampler
+    looks it up instead of running the time MLP every reverse step); a forward with cond = those rows equals the plain
+    forward; the table is refused (None) when the vector depends on more than t; the sampler refreshes its copy after a
+    weight update (same tensor, new values)."""
+    from turbdiff_amd.sampling import GraphSampler
+
+    g = golden("sample_cfg1")
+    diff = build_cfg1(golden, noise_bcs=True)
+    net = diff.model
+    x_bcs, C, cidx = g["x_bcs"].to(dev()), cond(g["c_local"]), g["cell_idx"].to(dev())
+    T = diff.num_timesteps
+    with torch.no_grad():
+        tab = net.conditioning_table(C, T)
+        assert tab is not None and tab.shape[0] == T
+        t = torch.tensor([0, T - 1], device=dev())
+        direct = net.conditioning_vector(t, C, 2)
+        assert rel_l2(tab[t], direct) < 1e-6
+        x = torch.randn(2, *x_bcs.shape[1:], generator=torch.Generator().manual_seed(3)).to(dev())
+        assert rel_l2(net(x, t, C, cond=tab[t]), net(x, t, C)) < 1e-5
+        net.with_geometry_embedding = True  # the vector would then depend on the geometry too
+        assert net.conditioning_table(C, T) is None
+        net.with_geometry_embedding = False
+    gs = GraphSampler(diff, x_bcs, C, cidx, seed=7)
+    assert gs.c_table is not None and rel_l2(gs.c_table, tab) < 1e-6
+    held = gs.c_table
+    gs.run_steps(1)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.05)
+    gs.run_steps(1)
+    with torch.no_grad():
+        assert gs.c_table is held and rel_l2(gs.c_table, net.conditioning_table(C, T)) < 1e-6 and rel_l2(held, tab) > 1e-3
+
+
 def test_unfused_block_composition_matches_golden(golden, monkeypatch):
     """TDX_FUSE_BLOCKS=0 path (one autograd node per operator) -- same kernels, cross-check of the
     hand-written ResnetBlock backward used by default."""
