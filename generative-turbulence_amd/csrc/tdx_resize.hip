@@ -6,6 +6,7 @@
 // Index arithmetic follows ATen's upsample_trilinear3d exactly (float scale, float source
 // index, truncation, clamped second tap) so that tap selection matches the reference.
 #include "tdx_common.h"
+#include <stdlib.h>
 
 struct AxisMap {
     int in, out;
@@ -94,6 +95,128 @@ resize_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, AxisMap ax, AxisMa
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
         o.store(y + ((((int64_t)b * ax.out + ox) * ay.out + oy) * az.out + oz) * C + lc * 8);
+    }
+}
+
+// ---- up-sampling, 2 x 2 x 2 outputs per lane ---------------------------------------------------------------------------
+// When the grid grows along every axis (the U-Net's up path: 96 x 32 x 24 -> 192 x 64 x 48), the two outputs 2k and 2k + 1
+// of an axis read taps inside one window of three inputs [base, base + 2], base = i0(2k) (host-checked per axis with the
+// kernel's own float arithmetic, pair_window_ok).  A lane then produces a 2 x 2 x 2 block of outputs for its 8 channels from
+// the 3 x 3 x 3 window -- 27 loads for 8 outputs instead of 64 -- interpolating separably (z, then y, then x).  Unused
+// window entries carry weight 0 and a clamped address.  Worth 9 % at 192 x 64 x 48 x 64 (2.4 -> 2.6 TB/s of stores: what
+// is left is the write path itself -- write-dominated kernels top out near 3.2 TB/s on this chip, tdx_encode_fwd too).
+struct PairTaps {
+    int base;
+    float w[2][3];  // w[output of the pair][window entry]
+};
+__host__ __device__ __forceinline__ bool pair_taps(const AxisMap& a, int o_even, PairTaps& p) {
+    int i0, i1;
+    float w1;
+    axis_taps(a, min(o_even, a.out - 1), i0, i1, w1);
+    p.base = i0;
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) p.w[q][s] = 0.f;
+        const int o = min(o_even + q, a.out - 1);
+        axis_taps(a, o, i0, i1, w1);
+        const int d0 = i0 - p.base, d1 = i1 - p.base;
+        ok = ok && d0 >= 0 && d0 <= 2 && d1 >= 0 && d1 <= 2;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (s == d0) p.w[q][s] += 1.0f - w1;
+            if (s == d1) p.w[q][s] += w1;
+        }
+    }
+    return ok;
+}
+static bool pair_window_ok(const AxisMap& a) {
+    if (a.out < a.in) return false;
+    PairTaps p;
+    for (int o = 0; o < a.out; o += 2)
+        if (!pair_taps(a, o, p)) return false;
+    return true;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+resize_up_pairs_kernel(const T* __restrict__ x, T* __restrict__ y, AxisMap ax, AxisMap ay, AxisMap az, int C, TileGrid tg) {
+    __shared__ PairTaps s_p[3][RS_MAXT / 2];
+    int b, ox0, oy0, oz0;
+    tile_origin(tg, b, ox0, oy0, oz0);  // tile extents are even (host-checked), so pairs never straddle tiles
+    if (threadIdx.x < 3 * (RS_MAXT / 2)) {
+        const int a = threadIdx.x / (RS_MAXT / 2), k = threadIdx.x % (RS_MAXT / 2);
+        const AxisMap& m = a == 0 ? ax : (a == 1 ? ay : az);
+        PairTaps p;
+        pair_taps(m, (a == 0 ? ox0 : (a == 1 ? oy0 : oz0)) + 2 * k, p);
+        s_p[a][k] = p;
+    }
+    __syncthreads();
+    const int L = C >> 3;
+    const int per_pass = 256 / L;
+    const int lc = (int)threadIdx.x % L;
+    const int px = tg.tx >> 1, py = tg.ty >> 1, pz = tg.tz >> 1;
+    const int nblk = px * py * pz;
+    if ((int)threadIdx.x >= per_pass * L) return;
+    for (int slot = (int)threadIdx.x / L; slot < nblk; slot += per_pass) {
+        const int kz = slot % pz, ky = (slot / pz) % py, kx = slot / (pz * py);
+        const int ox = ox0 + 2 * kx, oy = oy0 + 2 * ky, oz = oz0 + 2 * kz;
+        if (ox >= ax.out || oy >= ay.out || oz >= az.out) continue;
+        const PairTaps tx = s_p[0][kx], ty = s_p[1][ky], tz = s_p[2][kz];
+        const T* xb = x + ((int64_t)b * ax.in * ay.in * az.in) * C + lc * 8;
+        int zi[3], yi[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            zi[s] = min(tz.base + s, az.in - 1);
+            yi[s] = min(ty.base + s, ay.in - 1);
+        }
+        float acc[2][2][2][8];  // [x out][y out][z out][channel]
+#pragma unroll
+        for (int i = 0; i < 64; ++i) (&acc[0][0][0][0])[i] = 0.f;
+#pragma unroll 1  // one x plane of the window at a time: 9 loads in flight, ~170 VGPRs instead of 256
+        for (int sx = 0; sx < 3; ++sx) {
+            const int xi = min(tx.base + sx, ax.in - 1);
+            Raw8<T> t[3][3];
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+                for (int sz = 0; sz < 3; ++sz) t[sy][sz].load(xb + (((int64_t)xi * ay.in + yi[sy]) * az.in + zi[sz]) * C);
+            // along z: rows[sy][z out]
+            float rz[3][2][8];
+#pragma unroll
+            for (int sy = 0; sy < 3; ++sy) {
+                const Vec8<T> v0 = t[sy][0].get(), v1 = t[sy][1].get(), v2 = t[sy][2].get();
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        rz[sy][q][j] = tz.w[q][0] * v0.v[j] + tz.w[q][1] * v1.v[j] + tz.w[q][2] * v2.v[j];
+            }
+            // along y, then into the two x outputs
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                for (int qz = 0; qz < 2; ++qz)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float r = ty.w[qy][0] * rz[0][qz][j] + ty.w[qy][1] * rz[1][qz][j] + ty.w[qy][2] * rz[2][qz][j];
+                        acc[0][qy][qz][j] += tx.w[0][sx] * r;
+                        acc[1][qy][qz][j] += tx.w[1][sx] * r;
+                    }
+        }
+#pragma unroll
+        for (int qx = 0; qx < 2; ++qx)
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                for (int qz = 0; qz < 2; ++qz) {
+                    if (ox + qx >= ax.out || oy + qy >= ay.out || oz + qz >= az.out) continue;
+                    Vec8<T> o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o.v[j] = acc[qx][qy][qz][j];
+                    o.store(y + ((((int64_t)b * ax.out + ox + qx) * ay.out + oy + qy) * az.out + oz + qz) * C + lc * 8);
+                }
     }
 }
 
@@ -284,6 +407,15 @@ extern "C" int tdx_resize_fwd(const void* x, void* y, int B, int Xi, int Yi, int
     if (C % 8 || C / 8 > 256) return TDX_ESHAPE;
     const TileGrid tg = make_tiles(Xo, Yo, Zo, C);
     const int64_t blocks = (int64_t)B * tg.nx * tg.ny * tg.nz;
+    static const bool no_pairs = getenv("TDX_RESIZE_PAIRS") && atoi(getenv("TDX_RESIZE_PAIRS")) == 0;  // A/B switch
+    const AxisMap mx = make_axis(Xi, Xo), my = make_axis(Yi, Yo), mz = make_axis(Zi, Zo);
+    // measured (tools/micro/resize_bench.py, B = 8): 64 channels 281 -> 256 us, 128 channels 65 -> 69 us: narrow rows only
+    if (!no_pairs && C <= 64 && !((tg.tx | tg.ty | tg.tz) & 1) && Xo > Xi && Yo > Yi && Zo > Zi && pair_window_ok(mx) &&
+        pair_window_ok(my) && pair_window_ok(mz)) {
+        TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_up_pairs_kernel<T>), dim3((unsigned)blocks), dim3(256), 0,
+                                                      as_stream(stream), (const T*)x, (T*)y, mx, my, mz, C, tg));
+        return tdx_launch_status();
+    }
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_fwd_kernel<T>), dim3((unsigned)blocks), dim3(256), 0,
                                                   as_stream(stream), (const T*)x, (T*)y, make_axis(Xi, Xo),
                                                   make_axis(Yi, Yo), make_axis(Zi, Zo), C, tg));
