@@ -103,8 +103,10 @@ resize_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, AxisMap ax, AxisMa
 // of an axis read taps inside one window of three inputs [base, base + 2], base = i0(2k) (host-checked per axis with the
 // kernel's own float arithmetic, pair_window_ok).  A lane then produces a 2 x 2 x 2 block of outputs for its 8 channels from
 // the 3 x 3 x 3 window -- 27 loads for 8 outputs instead of 64 -- interpolating separably (z, then y, then x).  Unused
-// window entries carry weight 0 and a clamped address.  Worth 9 % at 192 x 64 x 48 x 64 (2.4 -> 2.6 TB/s of stores: what
-// is left is the write path itself -- write-dominated kernels top out near 3.2 TB/s on this chip, tdx_encode_fwd too).
+// window entries carry weight 0 and a clamped address.  Worth 5-9 % at 192 x 64 x 48 x 64 (2.4 -> 2.6 TB/s of stores; a
+// plain write-only stream reaches 4.8-6.5 TB/s, profiles/r11_hbm_write_probe.txt): with 216 VGPRs the kernel now waits on
+// its three rounds of L2-latency loads at two waves per SIMD instead of on the L1 load rate; longer z runs per tile
+// (2 x 8 x 16 ... 2 x 2 x 64) were measured and are no faster.
 struct PairTaps {
     int base;
     float w[2][3];  // w[output of the pair][window entry]
