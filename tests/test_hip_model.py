@@ -532,6 +532,36 @@ def test_graph_sampler_recaptures_after_a_weight_update(golden):
     assert rel_l2(after, eager) < 1e-5 and rel_l2(after, before) > 1e-3
 
 
+def test_graph_sampler_on_a_grid_whose_planes_are_not_multiples_of_four():
+    """13 x 7 x 9 = 819 voxels per plane: the in-kernel noise draw (16-B groups per plane) does not apply, the sampler falls
+    back to drawing z / z2 into tensors; graph and eager loops still agree, and so do a fused-noise and a separate-noise
+    sampler on a grid where both work (same Philox counters)."""
+    from turbdiff_amd import sampling
+    from turbdiff_amd.models.ddpm import DenoisingModel, GaussianDiffusion
+    from turbdiff_amd.sampling import GraphSampler
+
+    torch.manual_seed(2)
+    for grid, fused in (((13, 7, 9), False), ((12, 8, 10), True)):
+        net = DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=6, dim=16,
+                             u_net_levels=2, norm_type="group")
+        diff = GaussianDiffusion(net, timesteps=6, beta_schedule="log-snr-linear", noise_bcs=True).to(dev())
+        V = grid[0] * grid[1] * grid[2]
+        x_bcs = torch.randn(2, 4, *grid, generator=torch.Generator().manual_seed(4)).to(dev())
+        C = cond(torch.randn(4, *grid, generator=torch.Generator().manual_seed(5)))
+        cidx = torch.arange(0, V, 3, device=dev())
+        gs = GraphSampler(diff, x_bcs, C, cidx, seed=3, trajectory_ids=[0, 7])
+        assert gs.fused_noise == fused and (gs.z is None) == fused
+        out = gs.sample()
+        stream = gs.noise_stream()
+        eager = diff.p_sample_loop(x_bcs, C, cidx, noise_fn=lambda like: next(stream))
+        assert torch.isfinite(out).all() and rel_l2(out, eager) < 1e-5
+        if fused:
+            import unittest.mock as um
+            with um.patch.object(sampling, "FUSED_STEP_NOISE", False):
+                plain = GraphSampler(diff, x_bcs, C, cidx, seed=3, trajectory_ids=[0, 7])
+            assert not plain.fused_noise and rel_l2(plain.sample(), out) < 1e-5
+
+
 def test_conditioning_table_row_equals_the_time_mlp(golden):
     """DenoisingModel.conditioning_table: row t is the conditioning vector the model computes for timestep t (the sampler
     looks it up instead of running the time MLP every reverse step); a forward with cond = those rows equals the plain
