@@ -932,7 +932,6 @@ class _ResnetBlock(torch.autograd.Function):
                B, V, Cout, groups, 1, code, st)
         h2, st2 = conv_gn(a1, Cout, None, 0, wf2, b2)
         wr2 = None
-        y = torch.empty_like(h1)
         fused_tail = False
         if dec is not None:
             # inference only: the block output goes straight through the model's 1x1 decoder (tdx_gn_apply_decode) and is
@@ -945,6 +944,7 @@ class _ResnetBlock(torch.autograd.Function):
                    L.ptr(wd.detach().reshape(F, Cout).float().contiguous()), L.ptr(bd.detach().float().contiguous()), L.ptr(out),
                    B, V, Cout, groups, F, code, st)
             return out
+        y = torch.empty_like(h1)
         if enc is not None:
             xr, Fx, wx2, bx2, cr, Fc, wc2, bc2, D = enc
             L.call("tdx_gn_apply_encoded", L.ptr(h2), L.ptr(st2), L.ptr(g2), L.ptr(be2), L.ptr(xr), Fx, L.ptr(wx2), L.ptr(bx2),
