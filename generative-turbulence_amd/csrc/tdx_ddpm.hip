@@ -304,26 +304,29 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
+// four N(0,1) draws of counter `ctr` in Philox stream `sid`: (0,1] uniforms from 32 bits each, two Box-Muller pairs
+__device__ __forceinline__ void philox_normal4(uint64_t ctr, uint64_t sid, uint64_t seed, float (&r)[4]) {
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float u1 = ((float)c[2 * k] + 1.0f) * 2.3283064365386963e-10f;
+        float u2 = (float)c[2 * k + 1] * 2.3283064365386963e-10f;
+        float rad = sqrtf(-2.0f * __logf(u1));
+        float sn, cs;
+        __sincosf(6.283185307179586f * u2, &sn, &cs);
+        r[2 * k] = rad * cs; r[2 * k + 1] = rad * sn;
+    }
+}
+
 __global__ void __launch_bounds__(256) randn_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t sid,
                                                     const uint64_t* __restrict__ offp) {
     const uint64_t off = *offp;
     const int64_t n4 = (n + 3) >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        uint64_t ctr = off + (uint64_t)i;
-        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
-        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
         float r[4];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            // (0,1] uniform from 32 bits, Box-Muller pair
-            float u1 = ((float)c[2 * k] + 1.0f) * 2.3283064365386963e-10f;
-            float u2 = (float)c[2 * k + 1] * 2.3283064365386963e-10f;
-            float rad = sqrtf(-2.0f * __logf(u1));
-            float sn, cs;
-            __sincosf(6.283185307179586f * u2, &sn, &cs);
-            r[2 * k] = rad * cs; r[2 * k + 1] = rad * sn;
-        }
+        philox_normal4(off + (uint64_t)i, sid, seed, r);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (4 * i + k < n) out[4 * i + k] = r[k];
@@ -340,19 +343,8 @@ __global__ void __launch_bounds__(256) randn_batched_kernel(float* __restrict__ 
     const int64_t n4 = (n + 3) >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        uint64_t ctr = off + (uint64_t)i;
-        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
-        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
         float r[4];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            float u1 = ((float)c[2 * k] + 1.0f) * 2.3283064365386963e-10f;
-            float u2 = (float)c[2 * k + 1] * 2.3283064365386963e-10f;
-            float rad = sqrtf(-2.0f * __logf(u1));
-            float sn, cs;
-            __sincosf(6.283185307179586f * u2, &sn, &cs);
-            r[2 * k] = rad * cs; r[2 * k + 1] = rad * sn;
-        }
+        philox_normal4(off + (uint64_t)i, sid, seed, r);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (4 * i + k < n) o[4 * i + k] = r[k];
@@ -374,20 +366,6 @@ extern "C" int tdx_randn_batched(float* out, int B, int64_t n, uint64_t seed, co
 // four normals randn_batched_kernel would have written to z[b][4i..4i+3] (counter off + i) and to z2 (counter
 // off + n4 + i), so a run is bit-identical to tdx_randn_batched(z); tdx_randn_batched(z2); tdx_p_sample_step(...).
 // Saves two 4-byte writes and two reads per value; the Philox rounds are a few microseconds of VALU per launch.
-__device__ __forceinline__ void philox_normal4(uint64_t ctr, uint64_t sid, uint64_t seed, float (&r)[4]) {
-    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)sid, (uint32_t)(sid >> 32)};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        float u1 = ((float)c[2 * k] + 1.0f) * 2.3283064365386963e-10f;
-        float u2 = (float)c[2 * k + 1] * 2.3283064365386963e-10f;
-        float rad = sqrtf(-2.0f * __logf(u1));
-        float sn, cs;
-        __sincosf(6.283185307179586f * u2, &sn, &cs);
-        r[2 * k] = rad * cs; r[2 * k + 1] = rad * sn;
-    }
-}
-
 __global__ void __launch_bounds__(256)
 p_sample_step_rng_kernel(const float* __restrict__ x_t, const float* __restrict__ eps, const float* __restrict__ x_bcs,
                          const uint8_t* __restrict__ mask, const float* __restrict__ sched, int T,
