@@ -338,3 +338,17 @@ def test_graph_sampler_stream_ids_and_signature():
     assert sig != GraphSampler.signature_of(d2, x, C)
     m2 = D(); m2.model = M(); m2.model.compute_dtype = torch.bfloat16
     assert sig != GraphSampler.signature_of(m2, x, C)
+
+
+def test_philox_reference_matches_random123_known_answers():
+    """tests/philox_ref.py (what the GPU generator is checked against) reproduces the three known-answer vectors of
+    Random123's philox4x32-10 (kat_vectors: zero counter / key, all-ones, digits of pi)."""
+    from philox_ref import philox4x32_10
+
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF), (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+            (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10(*ctr, *key)
+        assert tuple(int(x) for x in got) == want

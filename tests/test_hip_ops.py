@@ -436,6 +436,25 @@ def test_masked_loss(l1):
     assert rel_l2(ed.grad.cpu(), 2 * er.grad) < 1e-6
 
 
+def test_philox_randn_equals_the_published_generator():
+    """tdx_randn / tdx_randn_batched draw Philox4x32-10 words with counter = (offset + i, trajectory stream id) and key =
+    seed, then Box-Muller: against tests/philox_ref.py (numpy, pinned to Random123's known-answer vectors in the CPU
+    suite).  Tolerance: the kernel's fast log / sincos."""
+    from philox_ref import normals
+    from turbdiff_amd import ops
+
+    d = dev()
+    seed, sid, off0, n = (0x1234 << 32) | 0x9ABCDEF0, (77 << 32) | 5, (1 << 33) + 12345, 4099
+    off = torch.full((1,), off0, dtype=torch.int64, device=d)
+    a = ops.randn_philox(torch.empty(n, device=d), seed, sid, off).cpu().double().numpy()
+    ref = normals(n, seed, sid, off0)
+    assert abs(a - ref).max() < 2e-4 and int(off) == off0 + (n + 3) // 4
+    sids = torch.tensor([sid, 3], dtype=torch.int64, device=d)
+    off.fill_(off0)
+    b = ops.randn_philox_batched(torch.empty(2, n, device=d), seed, sids, off).cpu().double().numpy()
+    assert abs(b[0] - ref).max() < 2e-4 and abs(b[1] - normals(n, seed, 3, off0)).max() < 2e-4
+
+
 def test_philox_randn_moments_and_replay():
     from turbdiff_amd import ops
 
