@@ -63,6 +63,7 @@ class GraphSampler:
         with torch.no_grad():
             self.enc = diffusion.model.encode_local(self.C)
         self.c_table = None  # (T, c_dim) conditioning vectors per timestep (DenoisingModel.conditioning_table) or None
+        self._table_versions = None
         self._refresh_tables()
         self.reset()
 
@@ -94,15 +95,7 @@ class GraphSampler:
                 if torch.is_tensor(v):
                     self.C[k].copy_(v)
         self.mask.copy_(self.d.domain_mask(cell_idx, self.x_bcs[0, 0].numel())[0])
-        if self.enc is not None:
-            enc = self.d.model.encode_local(self.C)
-            old, new = getattr(self.enc, "first_conv_partial", None), getattr(enc, "first_conv_partial", None)
-            if (old is None) != (new is None) or enc.shape != self.enc.shape or enc.dtype != self.enc.dtype:
-                self.enc, self.graph = enc, None  # another structure than the captured one: capture again on these tensors
-            else:
-                self.enc.copy_(enc)
-                if old is not None:
-                    old[1].copy_(new[1])
+        self._refresh_enc()
         if nonce is not None or trajectory_ids is not None:
             ids = [int(i) & 0xFFFFFFFF for i in self.stream_ids.tolist()] if trajectory_ids is None else list(trajectory_ids)
             nn = int(self.stream_ids[0].item()) >> 32 if nonce is None else nonce
@@ -110,9 +103,26 @@ class GraphSampler:
         return self
 
     @torch.no_grad()
+    def _refresh_enc(self):
+        """encode_local(C) (and the cached conditioning conv hanging off it) again, into the tensors the captured graph
+        reads: after another geometry was bound or the weights changed."""
+        if self.enc is None:
+            return
+        enc = self.d.model.encode_local(self.C)
+        old, new = getattr(self.enc, "first_conv_partial", None), getattr(enc, "first_conv_partial", None)
+        if (old is None) != (new is None) or enc.shape != self.enc.shape or enc.dtype != self.enc.dtype:
+            self.enc, self.graph = enc, None  # another structure than the captured one: capture again on these tensors
+        else:
+            self.enc.copy_(enc)
+            if old is not None:
+                old[1].copy_(new[1])
+
+    @torch.no_grad()
     def _refresh_tables(self):
-        """What the step reads that is a function of the WEIGHTS alone: recomputed into the same tensors after a weight
-        update (the captured graph keeps their addresses)."""
+        """What the step reads that is a function of the WEIGHTS (and the bound geometry) alone: recomputed into the same
+        tensors after a weight update (the captured graph keeps their addresses)."""
+        if getattr(self, "_table_versions", None) is not None:  # not the constructor's call: enc was just made there
+            self._refresh_enc()
         tab = self.d.model.conditioning_table(self.C, self.d.num_timesteps) if COND_TABLE else None
         old = self.c_table
         if tab is not None and old is not None and tab.shape == old.shape and tab.dtype == old.dtype:

@@ -562,6 +562,42 @@ def test_graph_sampler_on_a_grid_whose_planes_are_not_multiples_of_four():
             assert not plain.fused_noise and rel_l2(plain.sample(), out) < 1e-5
 
 
+def test_sampler_refreshes_its_cached_conditioning_conv_after_a_weight_update(monkeypatch):
+    """With the first conv NOT composed with the encoders (TDX_COMPOSE_FIRST_CONV=0) the sampler keeps
+    encode_local(C) and the conditioning half of the first conv (first_conv_partial): both are functions of the weights
+    and must follow a weight update, into the same tensors (the captured graph reads those addresses)."""
+    from turbdiff_amd.models import ddpm as D
+    from turbdiff_amd.sampling import GraphSampler
+
+    monkeypatch.setattr(D, "COMPOSE_FIRST_CONV", False)
+    torch.manual_seed(1)
+    grid = (16, 8, 8)
+    net = D.DenoisingModel(in_features=4, out_features=4, c_local_features=4, c_global_features=0, timesteps=6, dim=32,
+                           u_net_levels=2, norm_type="group")
+    diff = D.GaussianDiffusion(net, timesteps=6, beta_schedule="log-snr-linear", noise_bcs=True).to(dev())
+    net.set_compute_dtype(torch.bfloat16)
+    V = grid[0] * grid[1] * grid[2]
+    x_bcs = torch.randn(2, 4, *grid, generator=torch.Generator().manual_seed(4)).to(dev())
+    C = cond(torch.randn(4, *grid, generator=torch.Generator().manual_seed(5)))
+    cidx = torch.arange(0, V, 3, device=dev())
+    gs = GraphSampler(diff, x_bcs, C, cidx, seed=3)
+    part = getattr(gs.enc, "first_conv_partial", None)
+    assert part is not None, "this configuration should use the cached conditioning conv"
+    held, old_part, old_enc = part[1], part[1].clone(), gs.enc.clone()
+    gs.sample()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.25)
+    after = gs.sample()
+    assert gs.enc.first_conv_partial[1] is held  # same tensor (the captured graph reads its address) ...
+    with torch.no_grad():
+        fresh = net.encode_local(C)
+    # ... with the new weights' contents: equal to a fresh evaluation (bf16 rounding), far from the old ones
+    assert rel_l2(gs.enc.float(), fresh.float()) < 1e-2 and rel_l2(held.float(), fresh.first_conv_partial[1].float()) < 1e-2
+    assert rel_l2(gs.enc.float(), old_enc.float()) > 0.1 and rel_l2(held.float(), old_part.float()) > 0.1
+    assert torch.isfinite(after).all()
+
+
 def test_conditioning_table_row_equals_the_time_mlp(golden):
     """DenoisingModel.conditioning_table: row t is the conditioning vector the model computes for timestep t (the sampler
     looks it up instead of running the time MLP every reverse step); a forward with cond = those rows equals the plain
