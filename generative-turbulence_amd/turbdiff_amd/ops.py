@@ -936,7 +936,9 @@ class _ResnetBlock(torch.autograd.Function):
         if dec is not None:
             # inference only: the block output goes straight through the model's 1x1 decoder (tdx_gn_apply_decode) and is
             # never written; returns the decoded (B, F, X, Y, Z) f32 tensor instead of the block output
-            assert wr is None and enc is None and x2 is None and Cin == Cout and not torch.is_grad_enabled()
+            # (grad mode is always off inside Function.forward: the no-autograd condition is the caller's,
+            # decode_fused_supported -- nothing is saved for a backward pass on this route)
+            assert wr is None and enc is None and x2 is None and Cin == Cout
             wd, bd = dec
             F = wd.shape[0]
             out = torch.empty((B, F, X, Y, Z), dtype=torch.float32, device=dev)
@@ -1077,6 +1079,7 @@ def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, s
     decode(block output) as (B, F, X, Y, Z) f32 (ops.decode's result) without writing the block output
     (decode_fused_supported says when)."""
     wr, br = skip_wb if skip_wb is not None else (None, None)
+    assert decode_wb is None or not torch.is_grad_enabled(), "decode_wb: inference only (the block output is not kept)"
     enc = None
     if skip_encoded is not None:
         assert x1 is skip_encoded.standin and conv1_input is not None and skip_wb is None and x2 is None
