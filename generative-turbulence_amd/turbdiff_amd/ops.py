@@ -917,7 +917,7 @@ class _ResnetBlock(torch.autograd.Function):
             # inference only: conv1 over the leading n_lead channels of x1, continued from the
             # precomputed convolution of the batch-shared tail (tdx_conv3_fwd_partial)
             n_lead, init = partial
-            assert x2 is None and not torch.is_grad_enabled() and tuple(init.shape) == (1, X, Y, Z, Cout)
+            assert x2 is None and tuple(init.shape) == (1, X, Y, Z, Cout)
             h1 = torch.empty((B, X, Y, Z, Cout), dtype=dt, device=dev)
             st1 = torch.empty((B, groups, 2), dtype=torch.float32, device=dev)
             L.call("tdx_conv3_fwd_partial", L.ptr(x1), n_lead, C1, L.ptr(_packed_conv3_cin_slice(w1, 0, n_lead, dt)),
@@ -1080,6 +1080,7 @@ def resnet_block(x1, x2, scale, shift, conv1_wb, norm1_wb, conv2_wb, norm2_wb, s
     (decode_fused_supported says when)."""
     wr, br = skip_wb if skip_wb is not None else (None, None)
     assert decode_wb is None or not torch.is_grad_enabled(), "decode_wb: inference only (the block output is not kept)"
+    assert partial is None or not torch.is_grad_enabled(), "partial: inference only (the backward needs the full conv)"
     enc = None
     if skip_encoded is not None:
         assert x1 is skip_encoded.standin and conv1_input is not None and skip_wb is None and x2 is None
