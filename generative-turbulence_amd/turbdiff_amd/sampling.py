@@ -133,8 +133,14 @@ class GraphSampler:
             self.c_table = tab
         self._table_versions = [(p, p._version) for p in self.d.parameters()]
 
+    def _changed(self, seen) -> bool:
+        """Have the diffusion's parameters changed since `seen` = [(tensor, version)] was recorded -- updated in place
+        (optimiser step, load_state_dict) or replaced by other tensors (another model assigned, .to(device))?"""
+        cur = list(self.d.parameters())
+        return len(cur) != len(seen) or any(p is not q or p._version != v for p, (q, v) in zip(cur, seen))
+
     def _tables_stale(self) -> bool:
-        return any(p._version != v for p, v in self._table_versions)
+        return self._changed(self._table_versions)
 
     # ---- state
     def _randn(self, out):
@@ -202,7 +208,7 @@ class GraphSampler:
         self._versions = [(p, p._version) for p in self.d.parameters()]
 
     def _stale(self) -> bool:
-        return any(p._version != v for p, v in self._versions)
+        return self._changed(self._versions)
 
     @torch.no_grad()
     def run_steps(self, n: int, pbar: bool = False):

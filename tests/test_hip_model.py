@@ -530,6 +530,15 @@ def test_graph_sampler_recaptures_after_a_weight_update(golden):
     stream = gs.noise_stream()
     eager = diff.p_sample_loop(x_bcs, C, cidx, noise_fn=lambda like: next(stream))
     assert rel_l2(after, eager) < 1e-5 and rel_l2(after, before) > 1e-3
+    # a parameter REPLACED by another tensor (no version bump on the old one) is a change too
+    second_graph = gs.graph
+    net = diff.model
+    net.decode[1].weight = torch.nn.Parameter(net.decode[1].weight.detach() * 0.5)
+    swapped = gs.sample()
+    assert gs.graph is not second_graph
+    stream = gs.noise_stream()
+    eager = diff.p_sample_loop(x_bcs, C, cidx, noise_fn=lambda like: next(stream))
+    assert rel_l2(swapped, eager) < 1e-5 and rel_l2(swapped, after) > 1e-3
 
 
 def test_graph_sampler_on_a_grid_whose_planes_are_not_multiples_of_four():
