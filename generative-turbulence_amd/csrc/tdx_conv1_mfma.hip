@@ -166,34 +166,59 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
         }
         __syncthreads();
         constexpr int CHUNKS = PW / 8;  // 16-B chunks per row
+        constexpr int NI = (C1M_ROWS * CHUNKS) / 256;  // row chunks per thread; its chunk column c is the same in all of them
+        const int c = tid % CHUNKS;
+        const int cb = n0 + np * 32 + c * 8;  // first of the thread's 8 output channels
+        if (add) {
+            // all addend loads of the thread go out before the first is used (they were one memory round trip per
+            // chunk), and the GroupNorm coefficients of its 8 channels are formed once per sample instead of per chunk
+            // (a 64-bit division, 8 statistics loads and 16 parameter loads per 16 B: the fused tail ran at half the
+            // bandwidth of the plain addend form, profiles/r11bf16_kernel_stats.csv)
+            Raw8<bf16> braw[NI];
 #pragma unroll
-        for (int i = 0; i < (C1M_ROWS * CHUNKS) / 256; ++i) {
-            const int pc = tid + i * 256;
-            const int vr = pc / CHUNKS, c = pc % CHUNKS;
-            const int64_t rr = row0 + vr;
-            if (rr < rows) {
-                uint4 v = *reinterpret_cast<const uint4*>(smem + (PW == 64 ? sw128(vr, c) : sw64(vr, c)));
-                const int64_t off = rr * Cout + n0 + np * 32 + c * 8;
-                if (add) {
-                    Vec8<bf16> a, b;
-                    a.load(reinterpret_cast<const bf16*>(&v));
-                    b.load(add + off);
-                    if (gn.stats != nullptr) {
-                        const int bs = (int)(rr / gn.V), cb = n0 + np * 32 + c * 8, cpg = Cout / gn.G;
+            for (int i = 0; i < NI; ++i) {
+                const int64_t rr = row0 + (tid + i * 256) / CHUNKS;
+                braw[i].load(add + (rr < rows ? rr : rows - 1) * Cout + cb);
+            }
+            float ka[8], c0[8];
+            int64_t s_end = -1;  // rows below s_end (and not below the sample's first row) use ka / c0 as they are
+            auto coef = [&](int64_t rr) {
+                const int bs = (int)(rr / gn.V), cpg = Cout / gn.G;
+                s_end = ((int64_t)bs + 1) * gn.V;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float2 st = *reinterpret_cast<const float2*>(gn.stats + ((size_t)bs * gn.G + (cb + e) / cpg) * 2);
-                            const float gam = gn.gamma[cb + e];
-                            const float ka = st.y * gam * 1.0f, c0 = gn.beta[cb + e] - st.x * st.y * gam;
-                            b.v[e] = silu_f(__builtin_fmaf(b.v[e], ka, c0));
-                        }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) a.v[e] += b.v[e];
-                    a.store(y + off);
-                } else {
-                    *reinterpret_cast<uint4*>(y + off) = v;
+                for (int e = 0; e < 8; ++e) {
+                    const float2 st = *reinterpret_cast<const float2*>(gn.stats + ((size_t)bs * gn.G + (cb + e) / cpg) * 2);
+                    const float gam = gn.gamma[cb + e];
+                    ka[e] = st.y * gam * 1.0f;
+                    c0[e] = gn.beta[cb + e] - st.x * st.y * gam;
                 }
+            };
+            if (gn.stats != nullptr) coef(row0 + tid / CHUNKS);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int vr = (tid + i * 256) / CHUNKS;
+                const int64_t rr = row0 + vr;
+                if (rr >= rows) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(smem + (PW == 64 ? sw128(vr, c) : sw64(vr, c)));
+                Vec8<bf16> a, b = braw[i].get();
+                a.load(reinterpret_cast<const bf16*>(&v));
+                if (gn.stats != nullptr) {
+                    if (rr >= s_end) coef(rr);  // the workgroup's rows run into the next sample (rows ascend with i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b.v[e] = silu_f(__builtin_fmaf(b.v[e], ka[e], c0[e]));
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a.v[e] += b.v[e];
+                a.store(y + rr * Cout + cb);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int vr = (tid + i * 256) / CHUNKS;
+                const int64_t rr = row0 + vr;
+                if (rr < rows)
+                    *reinterpret_cast<uint4*>(y + rr * Cout + cb) =
+                        *reinterpret_cast<const uint4*>(smem + (PW == 64 ? sw128(vr, c) : sw64(vr, c)));
             }
         }
     }
