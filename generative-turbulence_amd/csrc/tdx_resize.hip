@@ -387,11 +387,16 @@ resize_bwd_generic_kernel(const T* __restrict__ dy, const T* __restrict__ add, T
 static int resize_args_ok(int B, int Xi, int Yi, int Zi, int Xo, int Yo, int Zo, int C) {
     return B > 0 && Xi > 0 && Yi > 0 && Zi > 0 && Xo > 0 && Yo > 0 && Zo > 0 && C > 0;
 }
-static TileGrid make_tiles(int X, int Y, int Z, int C) {
+static TileGrid make_tiles(int X, int Y, int Z, int C, int64_t samples = 0) {
     // ~8 passes of (256 / L) voxels: 256 voxels up to 64 channels, halved for every doubling beyond
     const int L = C >> 3;
     int vox = 256;
     while (vox > 8 && vox * L > 8 * 256) vox >>= 1;
+    // samples > 0 (the adjoint): small tensors get smaller tiles, down to one pass per workgroup, until ~1024 workgroups
+    // exist -- a tile's passes are chains of dependent gathers, and the 48x16x12 / 24x8x6 levels left 576 / 144 / 72
+    // eight-pass workgroups on 256 CUs (100 / 68 / 30 us for 141 / 35 / 8 MB)
+    const int one_pass = 256 / L > 8 ? 256 / L : 8;
+    while (samples > 0 && vox > one_pass && samples * X * Y * Z / vox < 1024) vox >>= 1;
     TileGrid t;
     t.tz = 8; t.ty = 8; t.tx = 4;
     // shrink x first, then y, then z, down to the voxel budget
@@ -407,7 +412,8 @@ extern "C" int tdx_resize_fwd(const void* x, void* y, int B, int Xi, int Yi, int
                               int dtype, void* stream) {
     TDX_CHECK_ARG(x && y && resize_args_ok(B, Xi, Yi, Zi, Xo, Yo, Zo, C));
     if (C % 8 || C / 8 > 256) return TDX_ESHAPE;
-    const TileGrid tg = make_tiles(Xo, Yo, Zo, C);
+    static const bool fine_tiles = !(getenv("TDX_RESIZE_FWD_TILES") && atoi(getenv("TDX_RESIZE_FWD_TILES")) == 0);  // A/B switch
+    const TileGrid tg = make_tiles(Xo, Yo, Zo, C, fine_tiles ? B : 0);
     const int64_t blocks = (int64_t)B * tg.nx * tg.ny * tg.nz;
     static const bool no_pairs = getenv("TDX_RESIZE_PAIRS") && atoi(getenv("TDX_RESIZE_PAIRS")) == 0;  // A/B switch
     const AxisMap mx = make_axis(Xi, Xo), my = make_axis(Yi, Yo), mz = make_axis(Zi, Zo);
@@ -447,7 +453,8 @@ extern "C" int tdx_resize_bwd(const void* dy, const void* add, void* dx, int B, 
                                                       as_stream(stream), (const T*)dy, (const T*)add, (T*)dx, ax, ay, az, C, total));
         return tdx_launch_status();
     }
-    const TileGrid tg = make_tiles(Xi, Yi, Zi, C);
+    static const bool fine_tiles = !(getenv("TDX_RESIZE_BWD_TILES") && atoi(getenv("TDX_RESIZE_BWD_TILES")) == 0);  // A/B switch
+    const TileGrid tg = make_tiles(Xi, Yi, Zi, C, fine_tiles ? B : 0);
     const dim3 grid((unsigned)((int64_t)B * tg.nx * tg.ny * tg.nz));
 #define RS_BWD(KV)                                                                                                     \
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_bwd_kernel<T, KV>), grid, dim3(256), 0, as_stream(stream),     \
