@@ -88,14 +88,28 @@ film_bwd_kernel(FilmBwdTable tab, const float* __restrict__ c, float* __restrict
     }
     const int k = r / C, ch = r - k * C;
     const float* g = tab.g[li] + (int64_t)k * B * C + ch;
+    // loads go out in groups (rolled one-load trips are chains of memory round trips: this kernel is all latency)
     float gsum = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float v = ok ? g[(int64_t)b * C] : 0.f;
-        sg[threadIdx.x * (B + 1) + b] = v;
-        gsum += v;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (ok && b0 + u < B) ? g[(int64_t)min(b0 + u, B - 1) * C] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (b0 + u < B) {
+                sg[threadIdx.x * (B + 1) + b0 + u] = v[u];
+                gsum += v[u];
+            }
     }
     const float* w = tab.w[li] + (int64_t)r * T;
-    for (int t = 0; t < T; ++t) sw[threadIdx.x * (T + 1) + t] = ok ? w[t] : 0.f;
+    for (int t0 = 0; t0 < T; t0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = (ok && t0 + u < T) ? w[min(t0 + u, T - 1)] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (t0 + u < T) sw[threadIdx.x * (T + 1) + t0 + u] = v[u];
+    }
     __syncthreads();
     if (ok) {
         float* dw = tab.dw[li] + (int64_t)r * T;
@@ -120,8 +134,17 @@ film_bwd_kernel(FilmBwdTable tab, const float* __restrict__ c, float* __restrict
 __global__ void film_bwd_finish_kernel(const float* __restrict__ partial, float* __restrict__ dc, int nblocks, int BT) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= BT) return;
+    // eight partials' loads in flight per trip, added in the same order as before (a rolled load -> add loop over the
+    // ~80 blocks was 80 memory round trips in a row: 21 us for 192 outputs)
     float a = 0.f;
-    for (int k = 0; k < nblocks; ++k) a += partial[(int64_t)k * BT + i];
+    for (int k0 = 0; k0 < nblocks; k0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = partial[(int64_t)min(k0 + u, nblocks - 1) * BT + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < nblocks) a += t[u];
+    }
     dc[i] = a;
 }
 
