@@ -317,18 +317,18 @@ def test_p_sample_step(noise_bcs, t):
 @pytest.mark.parametrize("noise_bcs", [True, False])
 @pytest.mark.parametrize("clip", [False, True])
 @pytest.mark.parametrize("t", [0, 1, 7])
-def test_p_sample_step_rng_matches_separate_draws_bitwise(noise_bcs, clip, t):
+@pytest.mark.parametrize("shape", [(3, 4, 6, 5, 4), (1, 4, 2, 2, 1), (2, 4, 40, 33, 28)])
+def test_p_sample_step_rng_matches_separate_draws_bitwise(noise_bcs, clip, t, shape):
     """tdx_p_sample_step_rng == tdx_randn_batched(z); [tdx_randn_batched(z2);] tdx_p_sample_step, bit for bit, and it leaves
     the same RNG offset and t - 1 behind (the contract include/tdx.h states)."""
     from turbdiff_amd import ops, schedules
 
     T, d = 10, dev()
-    shape = (3, 4, 6, 5, 4)
-    V = 120
+    V = shape[2] * shape[3] * shape[4]
     x_t, eps, xb = (rnd(*shape, seed=s).to(d) for s in range(3))
     mask = ops.cell_mask(_mask_idx(V).to(d), V)
     sched = schedules.pack_step_tables(schedules.diffusion_tables("log-snr-linear", T)).to(d)
-    sids = torch.tensor([(5 << 32) | 7, 11, (1 << 32) | 2], dtype=torch.int64, device=d)
+    sids = torch.tensor([(5 << 32) | 7, 11, (1 << 32) | 2][: shape[0]], dtype=torch.int64, device=d)
     seed, off0 = 1234, 4096
 
     off = torch.full((1,), off0, dtype=torch.int64, device=d)
@@ -360,13 +360,15 @@ def test_p_sample_step_rng_refuses_unaligned_planes():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("with_c", [True, False])
-def test_gn_apply_encoded_equals_encode_then_apply_bitwise(dtype, with_c):
+@pytest.mark.parametrize("B,D,grid", [(2, 32, (13, 9, 11)), (1, 32, (1, 1, 1)), (3, 16, (5, 1, 7)), (1, 64, (33, 32, 32)),
+                                      (2, 8, (17, 16, 2))])
+def test_gn_apply_encoded_equals_encode_then_apply_bitwise(dtype, with_c, B, D, grid):
     """include/tdx.h: tdx_gn_apply_encoded == tdx_encode_fwd + tdx_gn_apply(res = its output, act = 1), bit for bit;
-    V chosen so that the kernel runs full trips and a ragged tail."""
+    shapes: one voxel, fewer voxels than a trip, full trips + a ragged tail, many blocks, narrow / wide rows."""
     from turbdiff_amd import _lib as L, ops
 
     d = dev()
-    B, D, G, grid = 2, 32, 8, (13, 9, 11)
+    G = 8
     V = grid[0] * grid[1] * grid[2]
     C = 2 * D if with_c else D
     x = rnd(B, 4, *grid, seed=1).to(d)
@@ -392,12 +394,14 @@ def test_gn_apply_encoded_equals_encode_then_apply_bitwise(dtype, with_c):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("C", [32, 64])
-def test_gn_apply_decode_equals_apply_then_decode_bitwise(dtype, C):
-    """include/tdx.h: tdx_gn_apply_decode == tdx_gn_apply(res, act = 1) + tdx_decode_fwd, bit for bit."""
+@pytest.mark.parametrize("B,grid", [(2, (13, 9, 11)), (1, (1, 1, 1)), (3, (5, 1, 7)), (1, (33, 32, 32))])
+def test_gn_apply_decode_equals_apply_then_decode_bitwise(dtype, C, B, grid):
+    """include/tdx.h: tdx_gn_apply_decode == tdx_gn_apply(res, act = 1) + tdx_decode_fwd, bit for bit; shapes: one voxel,
+    fewer voxels than a trip, full trips + a ragged tail, many blocks."""
     from turbdiff_amd import _lib as L, ops
 
     d = dev()
-    B, G, grid = 2, 8, (13, 9, 11)
+    G = 8
     V = grid[0] * grid[1] * grid[2]
     h2 = rnd(B, *grid, C, seed=1).to(d).to(dtype)
     res = rnd(B, *grid, C, seed=2).to(d).to(dtype)
