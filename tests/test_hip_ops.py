@@ -1175,7 +1175,8 @@ def test_persistent_kernels_on_fewer_cus(case, cus, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,V,C1,C2,Co", [(2, 1000, 64, 0, 128), (3, 777, 64, 64, 32), (1, 256, 32, 0, 32), (6, 4097, 128, 128, 64)])
+@pytest.mark.parametrize("B,V,C1,C2,Co", [(2, 1000, 64, 0, 128), (3, 777, 64, 64, 32), (1, 256, 32, 0, 32), (6, 4097, 128, 128, 64),
+                                          (4, 100, 64, 0, 64), (7, 40, 32, 32, 32)])  # several samples inside one 256-row tile
 def test_conv1_fused_with_groupnorm_tail(B, V, C1, C2, Co):
     """tdx_conv1_fwd_gn -- y = silu(GN(h)) + bias + [x1|x2] @ w, the tail of a ResnetBlock with a projected skip
     (reference ddpm.py:176,188,197) in one pass -- against the two calls it replaces (tdx_conv1_fwd into a temporary,
