@@ -17,8 +17,10 @@ dst = root / "profiles"
 dst.mkdir(exist_ok=True)
 
 def one(pattern):
+    # the newest match: gpurun_out/ on the build host accumulates the files of every collection under the same names'
+    # directory (on the GPU box, where tools/r11_profiles.sh runs this, there is exactly one)
     f = glob.glob(str(src / pattern))
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None
 
 stats = one("stats/*/*kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
