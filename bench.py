@@ -366,6 +366,62 @@ def cfg1_leg(dev, with_cpu):
     return res
 
 
+def cfg5_attention_leg(dev):
+    """BASELINE configs[4]: the bottleneck attention core (reference attention.py:9-15, ddpm.py:295-308; heads = 4,
+    dim_head = 32) at 96x32x24 = 73 728 tokens, B = 1, on the MFMA flash kernels with fp16 and bf16 operands: forward and
+    backward ms by HIP events on the launching stream, algorithmic TFLOP/s (forward 4 N^2 d h; backward 2.5x that:
+    dP, dV, dQ, dK and the recomputed S) against the 2.5 PFLOP/s dense peak, and rel-L2 of 128 sampled query rows against
+    the CPU oracle's SDPA on the same rounded inputs."""
+    from turbdiff_amd import ops
+
+    B, H, D, N = 1, 4, 32, 96 * 32 * 24
+    flops = 4.0 * N * N * D * H * B
+    res = {"workload": "BASELINE configs[4]: attention core, N = 96x32x24 = 73 728 tokens, 4 heads x 32, B = 1",
+           "fwd_flops": flops, "bwd_flops": 2.5 * flops, "peak_tflops": 2500.0,
+           "algorithmic_bytes": 4.0 * N * H * D * 2 * B, "modes": {}}
+    gen = torch.Generator(device=dev).manual_seed(11)
+    base = torch.randn(B, N, 3 * H * D, device=dev, generator=gen)
+    rows = torch.randperm(N, generator=torch.Generator().manual_seed(12))[:128]
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        qkv = base.to(dt)
+        for _ in range(2):
+            out = ops.attention(qkv, H)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 5
+        s.record()
+        for _ in range(n):
+            out = ops.attention(qkv, H)
+        e.record()
+        torch.cuda.synchronize()
+        fwd = s.elapsed_time(e) / n
+        qg = qkv.clone().requires_grad_()
+        o2 = ops.attention(qg, H)
+        go = torch.randn(o2.shape, device=dev, generator=gen).to(dt)
+        for _ in range(2):
+            o2.backward(go, retain_graph=True)
+        s.record()
+        for _ in range(n):
+            o2.backward(go, retain_graph=True)
+        e.record()
+        torch.cuda.synchronize()
+        bwd = s.elapsed_time(e) / n
+        m = {"fwd_ms": fwd, "bwd_ms": bwd, "fwd_tflops": flops / fwd / 1e9, "bwd_tflops": 2.5 * flops / bwd / 1e9,
+             "fwd_frac_of_mfma_peak": flops / fwd / 1e9 / 2500.0, "bwd_frac_of_mfma_peak": 2.5 * flops / bwd / 1e9 / 2500.0,
+             "hbm_frac_fwd": 4.0 * N * H * D * 2 * B / (fwd * 1e-3) / 8e12}
+        try:
+            from oracle import turbdiff_oracle as O  # the checker, on 128 query rows
+
+            q, k, v = qkv.float().cpu().reshape(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+            ref = O.sdpa(q[:, :, rows], k, v)
+            got = out.float().cpu().reshape(B, N, H, D)[:, rows].permute(0, 2, 1, 3)
+            m["rel_l2_vs_oracle_128_rows"] = ((got - ref).norm() / ref.norm()).item()
+        except Exception as ex:  # noqa: BLE001
+            m["rel_l2_vs_oracle_128_rows"] = f"{type(ex).__name__}: {ex}"[:200]
+        res["modes"][name] = m
+        del qkv, qg, o2, go, out
+    return res
+
+
 REAL_GRID = (194, 50, 50)  # the dataset's grid (reference scripts/grid-embedding.py:69)
 
 
@@ -730,6 +786,8 @@ def main():
                 extra["real_grid"]["modes"]["bf16"]["ms_per_step"] / (REAL_GRID[0] * REAL_GRID[1] * REAL_GRID[2])
                 / (out["ms_per_step"] / V)) if args.dtype == "bf16" else None
             leg_done("real_grid_194x50x50")
+            extra["cfg5_attention"] = cfg5_attention_leg(dev)
+            leg_done("cfg5_attention")
     if extra:
         out["extra"] = extra
 

@@ -193,7 +193,9 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
                     c0[e] = gn.beta[cb + e] - st.x * st.y * gam;
                 }
             };
-            if (gn.stats != nullptr) coef(row0 + tid / CHUNKS);
+            // (the last row tile's rows >= `rows` are never stored: clamp, so that no thread forms coefficients from a
+            // sample index == B, one past the (B, G, 2) statistics)
+            if (gn.stats != nullptr) coef(row0 + tid / CHUNKS < rows ? row0 + tid / CHUNKS : rows - 1);
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int vr = (tid + i * 256) / CHUNKS;

@@ -66,12 +66,16 @@ struct RingArgs {
 // Inline assembly, not the builtin: the compiler would order every later ds_read behind the copy with vmcnt(0).
 __device__ __forceinline__ void rg_dma(const void* gsrc, unsigned lds) {
     lds = __builtin_amdgcn_readfirstlane(lds);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
+    unsigned keep;  // M0 is compiler-reserved: saved and restored inside the statement instead of a clobber the compiler does not honour
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
 }
 // the same with a uniform 64-bit base and a 32-bit per-lane byte offset
 __device__ __forceinline__ void rg_dma_off(const void* sbase, unsigned voff, unsigned lds) {
     lds = __builtin_amdgcn_readfirstlane(lds);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory", "m0");
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds) : "memory");
 }
 #define RG_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 __device__ __forceinline__ void rg_barrier() {

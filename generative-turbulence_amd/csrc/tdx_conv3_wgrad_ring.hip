@@ -72,7 +72,9 @@ __device__ __forceinline__ bf16x8 wr_tr_frag(const unsigned char* lo, const unsi
 // one LDS-DMA instruction (inline assembly: see tdx_conv3_ring.hip)
 __device__ __forceinline__ void wr_dma(const void* gsrc, unsigned lds) {
     lds = __builtin_amdgcn_readfirstlane(lds);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds) : "memory", "m0");
+    unsigned keep;  // M0 is compiler-reserved: saved and restored inside the statement (no "m0" clobber)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
 }
 __device__ __forceinline__ void wr_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

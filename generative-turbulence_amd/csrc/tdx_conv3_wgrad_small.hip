@@ -50,7 +50,9 @@ __device__ __forceinline__ bf16x8 ws_tr_frag(const unsigned char* lo, const unsi
 // itself (s_waitcnt vmcnt(0) + barrier before a buffer is read); it issues no other vector-memory loads.
 __device__ __forceinline__ void ws_dma16(const void* gsrc, const unsigned char* lds) {
     const unsigned a = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(a) : "memory", "m0");
+    unsigned keep;  // M0 is compiler-reserved: saved and restored inside the statement (no "m0" clobber)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(a) : "memory");
 }
 
 template <int NT>

@@ -17,7 +17,6 @@ from __future__ import annotations
 
 import math
 import os
-import weakref
 from dataclasses import dataclass
 from functools import partial
 
@@ -569,7 +568,7 @@ def batch_mean(x: torch.Tensor):
 
 
 GRAPH_SAMPLER = os.environ.get("TDX_GRAPH_SAMPLER", "1") != "0"
-_SAMPLERS = weakref.WeakKeyDictionary()  # GaussianDiffusion -> its GraphSampler (kept off the module: not copyable)
+MAX_GRAPH_SAMPLERS = 3  # captured samplers kept per diffusion, least recently used dropped first
 
 
 class GaussianDiffusion(nn.Module):
@@ -600,6 +599,27 @@ class GaussianDiffusion(nn.Module):
             self.register_buffer(name, tab, persistent=False)
         self.register_buffer("step_tables", schedules.pack_step_tables(tables), persistent=False)
         self._mask_cache = None
+        self._graph_samplers = None  # signature -> sampling.GraphSampler (built on first use, see graph_samplers)
+
+    # ---- the captured samplers: owned by the diffusion they sample from, so they die with it
+    def graph_samplers(self):
+        """signature -> GraphSampler, least recently used first.  A plain attribute (not a module / buffer): the
+        samplers point back at this object, an ordinary reference cycle the garbage collector frees together with the
+        captured graphs, their private pool and the scratch arena once the diffusion is dropped.  (A WeakKeyDictionary
+        keyed by the diffusion never let go: its values referenced their own key.)"""
+        cache = self.__dict__.get("_graph_samplers")
+        if cache is None:
+            from collections import OrderedDict
+
+            cache = self.__dict__["_graph_samplers"] = OrderedDict()
+        return cache
+
+    def __getstate__(self):
+        # copy.deepcopy / pickle: neither captured graphs nor the mask cache travel; the copy builds its own
+        state = super().__getstate__()
+        state["_graph_samplers"] = None
+        state["_mask_cache"] = None
+        return state
 
     # ---- helpers
     def domain_mask(self, cell_idx: torch.Tensor, V: int):
@@ -668,13 +688,14 @@ class GaussianDiffusion(nn.Module):
         this is what `DiffusionTrainer.sample`, `tools/eval_ckpt.py` and a `dropin` user get.  Noise comes from the
         counter-based generator, one stream per trajectory; the per-call nonce is drawn from torch's global CPU generator
         (so `torch.manual_seed` / `seed_everything` make the samples reproducible, as they do for the reference's
-        `torch.randn_like`) unless `seed` is given; `trajectory_ids` = global ids of the batch's trajectories when a larger
+        `torch.randn_like`) unless `seed` is given (reduced mod 2^31 - 1: the nonce shares the 64-bit stream id with the
+        trajectory id, seeds that differ by a multiple of 2^31 - 1 give the same noise); `trajectory_ids` = global ids of the batch's trajectories when a larger
         set is sharded over ranks (samples then do not depend on the sharding).  The sampler and its graph are kept per
         input shape and pointed at the new batch / geometry by copies (`GraphSampler.rebind`); a weight update re-captures.
         With `noise_fn(like)` -- injected noise in the reference's drawing order (x_T; then per step t > 0: z, and z' if
         noise_bcs), the golden tests -- or TDX_GRAPH_SAMPLER=0 the loop runs eagerly, one launch sequence per step."""
         if self.learned_variances:
-            raise NotImplementedError("sampling with learned variances is not on the accelerated path")
+            return self._general_sample(x_bcs, C, cell_idx, pbar, start_from, noise_fn)
         if noise_fn is None and GRAPH_SAMPLER and x_bcs.is_cuda and hasattr(self.model, "encode_local"):
             return self._graph_sample(x_bcs, C, cell_idx, pbar, start_from, seed, trajectory_ids)
         return self._eager_sample(x_bcs, C, cell_idx, pbar, start_from, noise_fn)
@@ -685,13 +706,58 @@ class GaussianDiffusion(nn.Module):
         nonce = int(torch.randint(0, 2**31 - 1, (1,)).item()) if seed is None else int(seed) % (2**31 - 1)
         x_bcs = x_bcs.contiguous().float()
         sig = GraphSampler.signature_of(self, x_bcs, C)
-        gs = _SAMPLERS.get(self)
-        if gs is None or gs.signature() != sig:
-            gs = _SAMPLERS[self] = GraphSampler(self, x_bcs, C, cell_idx, seed=0, trajectory_ids=trajectory_ids, nonce=nonce)
+        cache = self.graph_samplers()
+        gs = cache.get(sig)
+        if gs is None:
+            # calls that alternate between a few shapes (a partial last batch, B = 1 next to B = 8, two grids) keep one
+            # captured sampler each; all of them capture on ONE stream, hence share one scratch arena
+            shared = next(iter(cache.values()))._capture_stream if cache else None
+            gs = cache[sig] = GraphSampler(self, x_bcs, C, cell_idx, seed=0, trajectory_ids=trajectory_ids, nonce=nonce,
+                                           capture_stream=shared)
+            while len(cache) > MAX_GRAPH_SAMPLERS:
+                cache.popitem(last=False)
         else:
+            cache.move_to_end(sig)
             gs.rebind(x_bcs, C, cell_idx, nonce=nonce,
                       trajectory_ids=list(range(x_bcs.shape[0])) if trajectory_ids is None else trajectory_ids)
         return gs.sample(start_from, pbar=pbar)
+
+    def _general_sample(self, x_bcs, C, cell_idx, pbar, start_from, noise_fn):
+        """The reference's loop step by step over `p_sample` (ddpm.py:767-816) for what the fused update kernel does not
+        cover: learned variances, where `log_var` is the per-voxel lerp between log beta_t and the posterior log-variance
+        (ddpm.py:732-741).  The unmodified reference cannot finish this loop -- ddpm.py:805 hands the 5-D std to
+        `broadcast_right`, which asks for reshape(-1, -1, -1, -1, -1) (utils.py:11, RuntimeError; recorded in
+        tests/golden/options.npz) -- so this is the arithmetic the loop spells out, with the std used as it is: the
+        U-Net forward runs on the HIP kernels, the elementwise rest on torch ops over the same tensors."""
+        randn = noise_fn if noise_fn is not None else torch.randn_like
+        x_bcs = x_bcs.contiguous().float()
+        B = x_bcs.shape[0]
+        inside = self.domain_mask(cell_idx, x_bcs[0, 0].numel())[0].view(x_bcs.shape[-3:]).bool()
+        times = lambda t: torch.full((B,), t, dtype=torch.long, device=x_bcs.device)
+        if start_from is None:
+            x_t, T = randn(x_bcs), self.num_timesteps
+        else:
+            x_t, T = self.q_sample(x_bcs, times(start_from - 1), randn(x_bcs)), start_from
+        if not self.noise_bcs:
+            x_t = torch.where(inside, x_t, x_bcs)
+        steps = reversed(range(T))
+        if pbar:
+            from tqdm.auto import tqdm
+
+            steps = tqdm(steps, desc="sampling loop time step", total=T, position=1)
+        for t in steps:
+            mean, log_var = self.p_sample(x_t, t, C, cell_idx)
+            if t == 0:
+                x_t = mean
+                continue
+            noise = randn(x_t)
+            if not self.noise_bcs:
+                noise = torch.where(inside, noise, torch.zeros_like(noise))
+            std = (log_var / 2).exp()
+            x_t = mean + (std if std.ndim == noise.ndim else broadcast_right(std, noise)) * noise
+            if self.noise_bcs:
+                x_t = torch.where(inside, x_t, self.q_sample(x_bcs, times(t), randn(x_bcs)))
+        return torch.where(inside, x_t, x_bcs)
 
     def _eager_sample(self, x_bcs, C, cell_idx, pbar, start_from, noise_fn):
         randn = noise_fn if noise_fn is not None else torch.randn_like

@@ -50,6 +50,32 @@ def init_from_env(backend: str | None = None, force: bool = False):
     return rank, world, local
 
 
+CUS_PER_GPU = 256  # MI355X: 8 XCDs x 32 CUs
+
+
+def check_cu_budget(environ=None) -> tuple[int, int]:
+    """The persistent conv kernels (ring forward / data gradient, producer-consumer weight gradient) launch one
+    workgroup per CU on TDX_PERSISTENT_CUS CUs (default: all 256) and each needs a whole CU's LDS; RCCL's all-reduce
+    kernels run one workgroup (= one CU) per channel.  When the two together ask for more CUs than the chip has, a
+    persistent launch that finds CUs taken runs in two rounds (~2x its time) -- or the collective waits for a whole
+    conv launch, and the overlap with backward is gone.  Raises unless TDX_PERSISTENT_CUS + NCCL_MAX_NCHANNELS <= 256
+    (both must be SET for a multi-GPU run: RCCL's default channel count is its own choice).  Returns the two numbers."""
+    import os
+
+    env = os.environ if environ is None else environ
+    cus = int(env.get("TDX_PERSISTENT_CUS", str(CUS_PER_GPU)))
+    ch = env.get("NCCL_MAX_NCHANNELS")
+    if ch is None:
+        raise RuntimeError(
+            "data-parallel training on GPUs: set NCCL_MAX_NCHANNELS (and TDX_PERSISTENT_CUS) so that the persistent conv "
+            f"kernels and RCCL's channels fit the {CUS_PER_GPU} CUs together, e.g. TDX_PERSISTENT_CUS=224 "
+            "NCCL_MAX_NCHANNELS=32 (what bench.py --gpus N sets)")
+    if cus + int(ch) > CUS_PER_GPU:
+        raise RuntimeError(f"TDX_PERSISTENT_CUS ({cus}) + NCCL_MAX_NCHANNELS ({ch}) > {CUS_PER_GPU} CUs: the persistent conv "
+                           "kernels and the all-reduce would queue behind each other instead of overlapping")
+    return cus, int(ch)
+
+
 def _static_ready_order(module: torch.nn.Module, params: list) -> list[int] | None:
     """Indices into `params` in the order their gradients become ready, from the first submodule that
     offers ``grad_ready_order()`` (an iterable of parameters); parameters it does not list go last."""
@@ -106,6 +132,8 @@ class BucketedDataParallel:
         self._wait_events: list = []
         self._bucket_events: list = []                 # timing: per step {bucket: (launch event, wait start, wait end)}
         self._step_launch: dict = {}
+        if self.active and self.world > 1 and self.params and self.params[0].is_cuda and dist.get_backend(group) == "nccl":
+            check_cu_budget()  # RCCL's kernels and the persistent conv kernels share the chip
         if self.active and broadcast:
             with torch.no_grad():
                 for p in self.params:

@@ -34,7 +34,8 @@ class GraphSampler:
     existing graph at another batch / geometry of the same shape by copying into them -- `GaussianDiffusion.
     p_sample_loop` keeps one sampler per input shape and re-uses its graph from call to call."""
 
-    def __init__(self, diffusion, x_bcs, C, cell_idx, seed: int = 0, trajectory_ids=None, use_graph: bool = True, nonce: int = 0):
+    def __init__(self, diffusion, x_bcs, C, cell_idx, seed: int = 0, trajectory_ids=None, use_graph: bool = True, nonce: int = 0,
+                 capture_stream=None):
         self.d = diffusion
         self.x_bcs = x_bcs.detach().float().contiguous().clone()
         self.C = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in C.items()} if isinstance(C, dict) else C
@@ -59,7 +60,8 @@ class GraphSampler:
         self.z2 = None if self.fused_noise or not diffusion.noise_bcs else torch.empty_like(self.x_bcs)
         self.use_graph = use_graph
         self.graph = None
-        self._capture_stream = None  # ONE stream for every capture of this sampler (its scratch arena is per stream)
+        # ONE stream for every capture of this sampler (its scratch arena is per stream); samplers of one diffusion share it
+        self._capture_stream = capture_stream
         with torch.no_grad():
             self.enc = diffusion.model.encode_local(self.C)
         self.c_table = None  # (T, c_dim) conditioning vectors per timestep (DenoisingModel.conditioning_table) or None
@@ -213,6 +215,8 @@ class GraphSampler:
     @torch.no_grad()
     def run_steps(self, n: int, pbar: bool = False):
         n = min(n, self.steps_left)
+        if n <= 0:
+            return self.x_t  # finished trajectory: t is -1, a warm-up / capture step would index the tables out of range
         if self._tables_stale():
             self._refresh_tables()
         if self.use_graph and (self.graph is None or self._stale()):

@@ -268,7 +268,19 @@ class DiffusionTrainer(nn.Module):
 
     def _sample_normalized(self, batch, start_from, noise_fn):
         x, C = self._model_input(batch)
-        return self.model.p_sample_loop(x, C, self._cell_idx(batch), pbar=False, start_from=start_from, noise_fn=noise_fn)
+        kw = {}
+        if noise_fn is None and not self.model.learned_variances:
+            # identically seeded ranks draw the same per-call nonce: the trajectory ids keep their noise streams apart
+            # (rank r samples trajectories r B ... r B + B - 1 of the global set, whatever the sharding)
+            kw["trajectory_ids"] = self._global_trajectory_ids(x.shape[0])
+        return self.model.p_sample_loop(x, C, self._cell_idx(batch), pbar=False, start_from=start_from, noise_fn=noise_fn, **kw)
+
+    @staticmethod
+    def _global_trajectory_ids(B: int):
+        import torch.distributed as dist
+
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        return [rank * B + i for i in range(B)]
 
     @torch.no_grad()
     def validation_step(self, batch, store):

@@ -290,3 +290,40 @@ def p_sample_loop(sd, buf, x_bcs, c_local, cell_idx, noises, *, timesteps, noise
             # BC cells are re-noised at level t (not t-1), ddpm.py:807-811
             x_t = where_cells(cell_idx, x_t, q_sample(buf, x_bcs, tt, next(noises)))
     return where_cells(cell_idx, x_t, x_bcs)  # ddpm.py:814
+
+
+def learned_log_var(buf, t, variance_weights):
+    """ddpm.py:733-741: per-voxel log-variance, lerp(log beta_t, posterior log-variance_t; sigmoid(weights))."""
+    return torch.lerp(_bc(buf["log_betas"][t], variance_weights), _bc(buf["posterior_log_var"][t], variance_weights),
+                      torch.sigmoid(variance_weights))
+
+
+def p_sample_loop_learned_var(sd, buf, x_bcs, c_local, cell_idx, noises, *, timesteps, noise_bcs, norm_type="group",
+                              start_from=None):
+    """p_sample_loop (ddpm.py:767-816) with learned_variances=True: the model emits [eps_hat | variance weights]
+    (ddpm.py:732-741).  The reference's own loop stops with a RuntimeError at ddpm.py:805 (broadcast_right of the 5-D
+    per-voxel std, utils.py:11); this is the loop with the std applied as it is -- pinned against the reference's
+    p_sample (which does run) chained by tests/golden/make_golden.py (`learned_var_noelbo/sample`)."""
+    noises = iter(noises)
+    B = x_bcs.shape[0]
+    times = lambda s: torch.full((B,), s, dtype=torch.long, device=x_bcs.device)
+    if start_from is None:
+        x_t, T = next(noises), timesteps
+    else:
+        x_t, T = q_sample(buf, x_bcs, times(start_from - 1), next(noises)), start_from
+    if not noise_bcs:
+        x_t = where_cells(cell_idx, x_t, x_bcs)
+    for step in reversed(range(T)):
+        tt = times(step)
+        eps_hat, vw = denoiser(sd, x_t, tt, c_local, timesteps=timesteps, norm_type=norm_type).chunk(2, dim=1)
+        _, mean = model_mean(buf, x_t, tt, eps_hat, cell_idx, noise_bcs)
+        if step == 0:
+            x_t = mean
+            break
+        z = next(noises)
+        if not noise_bcs:
+            z = where_cells(cell_idx, z)
+        x_t = mean + (learned_log_var(buf, tt, vw) / 2).exp() * z
+        if noise_bcs:
+            x_t = where_cells(cell_idx, x_t, q_sample(buf, x_bcs, tt, next(noises)))
+    return where_cells(cell_idx, x_t, x_bcs)

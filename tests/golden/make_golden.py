@@ -480,6 +480,43 @@ def main():
             ox[f"{tag}/n_noise"] = np.array(len(noises))
             for i, n in enumerate(noises):
                 ox[f"{tag}/sample_noise/{i}"] = to_np(n)
+        if tag == "learned_var_noelbo":
+            # Sampling with learned variances.  The reference's OWN loop cannot finish: ddpm.py:805 calls
+            # broadcast_right(std, noise) with a 5-D per-voxel std and utils.py:11 then asks for reshape(-1, -1, -1, -1, -1)
+            # (RuntimeError).  Recorded here as a fact; what CAN be pinned is everything model-dependent: the reference's
+            # unmodified p_sample (mean, lerped per-voxel log_var; ddpm.py:732-741,758-765) at every step of a 10-step
+            # loop whose remaining arithmetic (x = mean + exp(log_var / 2) z; BC re-noising with the reference's q_sample;
+            # final where_cells; ddpm.py:796-814) is spelled out below with the reference's helpers.
+            try:
+                model.p_sample_loop(xs, Cs, cs, pbar=False)
+                ox[f"{tag}/sample_raises"] = np.array("")
+            except Exception as e:
+                ox[f"{tag}/sample_raises"] = np.array(type(e).__name__)
+            gl = torch.Generator().manual_seed(4242)
+            drawn = []
+
+            def draw(like):
+                drawn.append(torch.randn(like.shape, generator=gl))
+                return drawn[-1]
+
+            with torch.no_grad():
+                x_t = draw(xs)
+                for step in reversed(range(10)):
+                    mean, log_var = model.p_sample(x_t, step, Cs, cs)
+                    if step in (6, 0):
+                        ox[f"{tag}/p_sample_mean/{step}"] = to_np(mean)
+                        ox[f"{tag}/p_sample_log_var/{step}"] = to_np(log_var)
+                    if step == 0:
+                        x_t = mean
+                        break
+                    x_t = mean + (log_var / 2).exp() * draw(x_t)
+                    tt = torch.full((xs.shape[0],), step, dtype=torch.long)
+                    x_t = where_cells(cs, x_t, model.q_sample(xs, tt, draw(xs)))
+                x_t = where_cells(cs, x_t, xs)
+            ox[f"{tag}/sample"] = to_np(x_t)
+            ox[f"{tag}/n_noise"] = np.array(len(drawn))
+            for i, n in enumerate(drawn):
+                ox[f"{tag}/sample_noise/{i}"] = to_np(n)
     np.savez_compressed(OUT / "options.npz", **ox)
 
     # ------------------------------------------------------------------ state_dict manifest

@@ -352,3 +352,18 @@ def test_philox_reference_matches_random123_known_answers():
     for ctr, key, want in kat:
         got = philox4x32_10(*ctr, *key)
         assert tuple(int(x) for x in got) == want
+
+
+def test_ddp_cu_budget_check():
+    """parallel.check_cu_budget: the persistent conv kernels' CUs plus RCCL's channels must fit the
+    256 CUs; an unset channel count is refused too (RCCL would choose its own)."""
+    from turbdiff_amd.parallel import check_cu_budget
+
+    assert check_cu_budget({"TDX_PERSISTENT_CUS": "224", "NCCL_MAX_NCHANNELS": "32"}) == (224, 32)
+    assert check_cu_budget({"TDX_PERSISTENT_CUS": "192", "NCCL_MAX_NCHANNELS": "16"}) == (192, 16)
+    with pytest.raises(RuntimeError, match="> 256"):
+        check_cu_budget({"TDX_PERSISTENT_CUS": "240", "NCCL_MAX_NCHANNELS": "32"})
+    with pytest.raises(RuntimeError, match="> 256"):
+        check_cu_budget({"NCCL_MAX_NCHANNELS": "8"})  # default: all 256 CUs
+    with pytest.raises(RuntimeError, match="NCCL_MAX_NCHANNELS"):
+        check_cu_budget({"TDX_PERSISTENT_CUS": "224"})

@@ -192,6 +192,29 @@ def test_oracle_norm_type_variants(golden, tag, norm):
     assert rel_l2(eps, g[f"{tag}/eps_hat"]) < 1e-5
 
 
+def test_oracle_learned_variance_sampling(golden):
+    """Learned variances (ddpm.py:732-741): the oracle's per-voxel log-variance and its 10-step loop against the
+    reference's p_sample chained by the generator (the reference's own loop raises -- also recorded)."""
+    g = golden("options")
+    tag = "learned_var_noelbo"
+    assert str(g.z[f"{tag}/sample_raises"]) == "RuntimeError"
+    sd = dict(golden("model_cfg1").sub("sd/"))
+    sd.update(g.sub("learned_var/sd/"))
+    buf = O.schedule_buffers("log-snr-linear", 10)
+    noises = [g[f"{tag}/sample_noise/{i}"] for i in range(int(g[f"{tag}/n_noise"]))]
+    with torch.no_grad():
+        out = O.p_sample_loop_learned_var(sd, buf, g["x"], g["c_local"], g["cell_idx"], noises, timesteps=10, noise_bcs=True)
+        assert rel_l2(out, g[f"{tag}/sample"]) < 1e-5
+        # t = 9 is the first step: x_t = noises[0]; check the log-variance formula on a step we can reach directly
+        tt = torch.full((2,), 9, dtype=torch.long)
+        _, vw = O.denoiser(sd, noises[0], tt, g["c_local"], timesteps=10).chunk(2, dim=1)
+        lv = O.learned_log_var(buf, tt, vw)
+        assert lv.shape == noises[0].shape
+        lo = torch.minimum(O._bc(buf["log_betas"][tt], lv), O._bc(buf["posterior_log_var"][tt], lv))
+        hi = torch.maximum(O._bc(buf["log_betas"][tt], lv), O._bc(buf["posterior_log_var"][tt], lv))
+        assert ((lv >= lo - 1e-6) & (lv <= hi + 1e-6)).all()
+
+
 # --------------------------------------------------------------------------- baseline conv layers (SURVEY §8 f4)
 
 

@@ -114,3 +114,121 @@ def test_shard_trajectories_partition():
             seen += list(shard_trajectories(n, r, world))
         assert seen == list(range(n))
     assert len(shard_trajectories(64, 3, 8)) == 8
+
+
+# --------------------------------------------------------------------------- sharded data feed, world size 2
+
+
+def _unequal_cases():
+    """Two geometries with unequal sample counts (5 and 3 usable time steps): at batch size 2 that is 3 + 2 = 5 batch
+    lists -- an odd number, so the two ranks' shards only have equal length because the sampler wraps around."""
+    import numpy as np
+
+    from turbdiff_amd.data.ofles import OpenFOAMMetadata, Variable
+
+    gen = torch.Generator().manual_seed(0)
+    cases = []
+    for n, counts in ((5, (6, 5, 4)), (3, (5, 5, 5))):
+        inside = torch.zeros(counts, dtype=torch.bool)
+        inside[1:-1, 1:-1, 1:-1] = True
+        cell_idx = inside.flatten().nonzero().flatten()
+        meta = OpenFOAMMetadata(np.array(counts), cell_idx, {"walls": {"idx": torch.tensor([0, 1])}}, {})
+        cases.append((meta, np.arange(n) * 0.1, {Variable.U: torch.randn(n, len(cell_idx), 3, generator=gen),
+                                                 Variable.P: torch.randn(n, len(cell_idx), 1, generator=gen)}))
+    return cases
+
+
+def _feed_worker(rank, world, port, outdir, device):
+    """One rank of a data-parallel epoch: its shard of the batch lists (OpenFOAMSampler(rank, world)), optionally
+    staged to the device (DeviceStager), one all-reduce per batch as the gradient exchange would do -- a rank with
+    fewer batches than its peer would leave the other hanging in the collective (the test's timeout)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "generative-turbulence_amd"))
+    from turbdiff_amd.data.ofles import InMemoryRepository, OpenFOAMDataset, OpenFOAMSampler, OpenFOAMStats, Variable
+    from turbdiff_amd.parallel import init_from_env
+
+    init_from_env("gloo")
+    stats = OpenFOAMStats({"u": {"mean": torch.zeros(3), "std": torch.ones(3)}, "p": {"mean": torch.tensor(0.0), "std": torch.tensor(1.0)}})
+    ds = OpenFOAMDataset(InMemoryRepository(_unequal_cases()), stats, discard_first_seconds=-1.0)
+    log = []
+    for epoch in range(2):
+        s = OpenFOAMSampler(ds, batch_size=2, shuffle=True, rank=rank, world_size=world, seed=5)
+        s.set_epoch(epoch)
+        lists = list(s)
+        feed = (ds[b] for b in lists)
+        if device != "cpu":
+            from turbdiff_amd.data.staging import DeviceStager
+
+            feed = DeviceStager(feed, device)
+        sums = []
+        for b in feed:
+            u = b.data.samples[Variable.U]
+            assert u.device.type == torch.device(device).type
+            v = u.float().sum().reshape(1).cpu()
+            dist.all_reduce(v)  # lock-step: every rank must arrive here the same number of times
+            sums.append((v.item(), tuple(int(c) for c in b.data.metadata.cell_counts) if hasattr(b.data.metadata, "cell_counts") else None))
+        log.append((lists, sums))
+    torch.save(log, f"{outdir}/feed{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_feed(tmp_path):
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "generative-turbulence_amd"))
+    from turbdiff_amd.data.ofles import InMemoryRepository, OpenFOAMDataset, OpenFOAMSampler, OpenFOAMStats, Variable
+
+    logs = [torch.load(tmp_path / f"feed{r}.pt") for r in range(2)]
+    stats = OpenFOAMStats({"u": {"mean": torch.zeros(3), "std": torch.ones(3)}, "p": {"mean": torch.tensor(0.0), "std": torch.tensor(1.0)}})
+    ds = OpenFOAMDataset(InMemoryRepository(_unequal_cases()), stats, discard_first_seconds=-1.0)
+    for epoch in range(2):
+        full = OpenFOAMSampler(ds, batch_size=2, shuffle=True, seed=5)
+        full.set_epoch(epoch)
+        ref = list(full)
+        assert len(ref) == 5  # 3 + 2 batch lists: odd
+        a, b = logs[0][epoch][0], logs[1][epoch][0]
+        assert len(a) == len(b) == 3, "both ranks must see the same number of batches (the odd one wraps around)"
+        merged = [x for pair in zip(a, b) for x in pair]
+        assert merged[:5] == ref and merged[5] in ref
+        # the all-reduced sums: both ranks hold the same value per step = sum over the two ranks' batches
+        for i, ((va, _), (vb, _)) in enumerate(zip(logs[0][epoch][1], logs[1][epoch][1])):
+            want = sum(ds[x].data.samples[Variable.U].float().sum().item() for x in (a[i], b[i]))
+            assert va == vb and abs(va - want) < 1e-3 * max(1.0, abs(want))
+    assert logs[0][0][0] != logs[0][1][0]  # epochs reshuffle
+
+
+@pytest.mark.timeout(120)
+def test_sharded_sampler_feeds_two_ranks_in_lock_step(tmp_path):
+    """OpenFOAMSampler under world size 2 with unequal case counts (an odd number of batch lists):
+    both ranks iterate the same number of single-geometry batches, together they cover the single-process order, and a
+    collective per batch completes."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_feed_worker, args=(r, 2, port, str(tmp_path), "cpu")) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=100)
+        assert p.exitcode == 0
+    _check_feed(tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_sharded_sampler_and_device_stager_two_ranks_one_gpu(tmp_path):
+    """The same epoch with each rank's shard staged through its own DeviceStager (pinned buffers + copy stream) on
+    cuda:0: two processes, one device."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_feed_worker, args=(r, 2, port, str(tmp_path), "cuda:0")) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=280)
+        assert p.exitcode == 0
+    _check_feed(tmp_path)
