@@ -591,6 +591,60 @@ def test_p_sample_loop_eager_switch(golden, monkeypatch):
     assert not diff.graph_samplers() and torch.isfinite(out).all()
 
 
+def test_graph_samplers_die_with_their_diffusion_and_are_kept_per_shape(golden):
+    """(a) a sampled diffusion that is dropped is collected together with its captured sampler (graph, private
+    pool, buffers) -- the former WeakKeyDictionary kept both alive for the whole process; (b) calls that alternate
+    between shapes keep one captured sampler each (LRU of MAX_GRAPH_SAMPLERS) on ONE capture stream, and flipping back
+    does not re-capture; (c) copy.deepcopy of a sampled diffusion works and starts without samplers; (d) run_steps on a
+    finished sampler is a no-op (no capture at t = -1)."""
+    import copy
+    import gc
+    import weakref
+
+    from turbdiff_amd.models import ddpm as D
+
+    g = golden("sample_cfg1")
+    x_bcs, C, cidx = g["x_bcs"].to(dev()), cond(g["c_local"]), g["cell_idx"].to(dev())
+    diff = build_cfg1(golden, noise_bcs=True)
+    diff.p_sample_loop(x_bcs, C, cidx, seed=1)
+    (gs2,) = diff.graph_samplers().values()
+    graph2 = gs2.graph
+    diff.p_sample_loop(x_bcs[:1], C, cidx, seed=1)  # another shape: a second sampler, the first one stays
+    assert len(diff.graph_samplers()) == 2
+    gs1 = list(diff.graph_samplers().values())[-1]
+    assert gs1 is not gs2 and gs1._capture_stream is gs2._capture_stream
+    diff.p_sample_loop(x_bcs, C, cidx, seed=2)      # back to the first shape: same sampler, same graph
+    assert list(diff.graph_samplers().values())[-1] is gs2 and gs2.graph is graph2
+    for k in range(D.MAX_GRAPH_SAMPLERS + 1):        # more shapes than the cache holds: the oldest go
+        xk = x_bcs[:1, :, : x_bcs.shape[2] - 2 * (k + 1)].contiguous()
+        X = xk.shape[2]
+        ck = {key: v[:, :X].contiguous() for key, v in C.items()}
+        m = torch.zeros(xk.shape[-3:], dtype=torch.bool)
+        m[1:-1, 1:-1, 1:-1] = True
+        diff.p_sample_loop(xk, ck, m.flatten().nonzero().flatten().to(dev()), seed=3)
+    assert len(diff.graph_samplers()) == D.MAX_GRAPH_SAMPLERS and gs2 not in diff.graph_samplers().values()
+    # (d)
+    last = list(diff.graph_samplers().values())[-1]
+    assert last.steps_left == 0
+    before = last.x_t.clone()
+    last.graph = None
+    assert last.run_steps(5) is last.x_t and last.graph is None and torch.equal(before, last.x_t)
+    # (c)
+    twin = copy.deepcopy(diff)
+    assert not twin.graph_samplers() and torch.isfinite(twin.p_sample_loop(x_bcs, C, cidx, seed=1)).all()
+    del twin
+    # (a)
+    del gs1, gs2, graph2, last
+    probe = build_cfg1(golden, noise_bcs=True)
+    probe.p_sample_loop(x_bcs, C, cidx, seed=1)
+    sampler = next(iter(probe.graph_samplers().values()))
+    wd, ws, wx = weakref.ref(probe), weakref.ref(sampler), weakref.ref(sampler.x_t)
+    del probe, sampler
+    gc.collect()
+    torch.cuda.synchronize()
+    assert wd() is None and ws() is None and wx() is None, "a dropped diffusion must not be kept alive by its sampler cache"
+
+
 def test_graph_sampler_recaptures_after_a_weight_update(golden):
     """The captured graph has the packed weight operands' addresses baked in.  After the weights change (optimiser
     step, load_state_dict, here an in-place update) the sampler must not replay stale operands: it re-captures, and
