@@ -142,7 +142,7 @@ SCRATCH_SMALL_BYTES = 4096  # streams that only need the zero block at the arena
 SCRATCH_MAX_ARENAS = int(os.environ.get("TDX_SCRATCH_MAX_ARENAS", "6"))
 # entry points that may use the arena (K-split slabs of the small-grid kernels, the zero block of the DMA kernels)
 ARENA_USERS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_fwd_partial", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add",
-               "tdx_conv3_bwd_weight"}
+               "tdx_conv3_bwd_weight", "tdx_attn_fwd"}  # tdx_attn_fwd: partial (O, m, l) of the stream-K schedule
 # bind + launch of an arena user is one critical section: the library keeps ONE arena pointer per process and ctypes
 # releases the GIL during a foreign call, so a second launching thread could otherwise re-bind between the two
 _LAUNCH_LOCK = threading.RLock()

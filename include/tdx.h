@@ -281,7 +281,12 @@ int tdx_resize_bwd(const void* dy, const void* add, void* dx, int B, int Xi, int
 /* ------------------------------------------------------------------ attention ---------- */
 /* F.scaled_dot_product_attention on the to_qkv output (attention.py:9-15, ddpm.py:295-308).
  * qkv [B][N][3*H*D]: channels [0,HD) = q, [HD,2HD) = k, [2HD,3HD) = v, head-major inside
- * each third.  out [B][N][H*D].  lse [B][H][N] f32 (log-sum-exp of the scaled scores). */
+ * each third.  out [B][N][H*D].  lse [B][H][N] f32 (log-sum-exp of the scaled scores).
+ * Long sequences (bf16 / fp16 tensors, N >= 128) run the matrix-core flash kernel; when the launch has more 256-query
+ * blocks than the chip holds at once and not a whole number of rounds (BASELINE configs[4]: 1152 blocks on 512 slots), a
+ * persistent stream-K schedule splits the (query block, key tile) space evenly over 512 workgroups and parks the partial
+ * (O, m, l) of split blocks in the scratch arena (tdx_set_scratch, 35.7 MB behind its zero block; without one, or with
+ * TDX_ATTN_STREAMK=0, one workgroup per block). */
 int tdx_attn_fwd(const void* qkv, void* out, float* lse, int B, int N, int H, int D, int dtype, void* stream);
 int tdx_attn_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, int B, int N, int H,
                  int D, int dtype, void* workspace, void* stream);

@@ -673,6 +673,62 @@ def test_attention_fp16_operands(N, monkeypatch):
     monkeypatch.delenv("TDX_ATTN_IMPL")
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 8e-3), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("N", [1000, 4096 + 64 * 37 + 5])
+def test_attention_growing_scores_and_loose_norm_bound(dtype, tol, N, monkeypatch):
+    """The matrix-core forward's lazy running maximum (round 5): scores that keep GROWING along the key index (every
+    tile outgrows the stale maximum: the raise path runs over and over), an outlier key of huge norm that no query
+    aligns with (the Cauchy-Schwarz bound |q| max|k| is loose by far more than the allowance: the per-tile check must
+    stay on), queries of very different norms in one wave, and a ragged last tile -- against the fp64 oracle on the same
+    rounded inputs; with the norm bound switched off (TDX_ATTN_BOUND=0: always checking) and with the stream-K schedule
+    forced off, bit-identical results are not required, the tolerance is."""
+    from turbdiff_amd import ops
+
+    B, H, D = 2, 4, 32
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, N, H, D, generator=g) * torch.logspace(-1, 0.7, N).reshape(1, N, 1, 1)[:, torch.randperm(N, generator=g)]
+    u = torch.nn.functional.normalize(torch.randn(B, 1, H, D, generator=g), dim=-1)
+    ramp = torch.linspace(-6.0, 6.0, N).reshape(1, N, 1, 1)
+    k = torch.randn(B, N, H, D, generator=g) * 0.3 + u * ramp          # scores grow with the key index for q along +u
+    q = q + 2.0 * u * (torch.rand(B, N, H, 1, generator=g) > 0.5)       # half of the queries look along +u
+    k[:, N // 3] = 40.0 * torch.nn.functional.normalize(torch.randn(B, H, D, generator=g), dim=-1)  # the outlier
+    v = torch.randn(B, N, H, D, generator=g)
+    qkv = torch.cat([t.reshape(B, N, H * D) for t in (q, k, v)], dim=-1).to(dtype)
+    qd, kd, vd = (t.reshape(B, N, H, D).transpose(1, 2).double() for t in qkv.chunk(3, dim=-1))
+    ref = O.sdpa(qd, kd, vd).transpose(1, 2).reshape(B, N, H * D)
+    lse_ref = torch.logsumexp(qd @ kd.transpose(-1, -2) / D**0.5, dim=-1)  # (B, H, N)
+    for env in ({}, {"TDX_ATTN_BOUND": "0"}, {"TDX_ATTN_STREAMK": "0"}):
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        x = qkv.to(dev()).requires_grad_()
+        out = ops.attention(x, H)
+        assert torch.isfinite(out).all()
+        assert rel_l2(out.float().cpu(), ref) < tol, (env, rel_l2(out.float().cpu(), ref))
+        out.backward(torch.ones_like(out))
+        assert torch.isfinite(x.grad).all()
+        # the log-sum-exp the backward pass consumes, straight from the entry point
+        from turbdiff_amd import _lib as L
+
+        xd = qkv.to(dev())
+        o2 = torch.empty(B, N, H * D, dtype=dtype, device=dev())
+        lse = torch.empty(B, H, N, dtype=torch.float32, device=dev())
+        L.call("tdx_attn_fwd", L.ptr(xd), L.ptr(o2), L.ptr(lse), B, N, H, D, L.dtype_code(dtype), L.stream())
+        assert torch.equal(o2, out.detach())
+        # (the kernels round q * log2(e) / sqrt(d) to the operand format once more: a score carries an error of up to
+        # 2^-9 |q| |k| / sqrt(d) with bf16 operands, 2^-12 with fp16 -- |q| |k| / sqrt(d) reaches ~200 here)
+        err = (lse.cpu().double() - lse_ref).abs()
+        ulp = 2.0**-9 if dtype == torch.bfloat16 else 2.0**-12
+        kmax = kd.norm(dim=-1).amax(dim=-1, keepdim=True)                       # (B, H, 1)
+        assert (err <= 2e-2 + ulp * qd.norm(dim=-1) * kmax / D**0.5).all(), (env, err.max())
+        # against the SAME arithmetic in fp64 (q * log2(e) / sqrt(d) rounded to the operand format first) the kernel's
+        # log-sum-exp is exact to fp32 / operand-rounding-of-P noise
+        qs = (qd.float() * (1.4426950408889634 / D**0.5)).to(dtype).double()
+        lse_same = torch.logsumexp((qs @ kd.transpose(-1, -2)) / 1.4426950408889634, dim=-1)
+        assert (lse.cpu().double() - lse_same).abs().max().item() < 1e-2, env
+        for kk in env:
+            monkeypatch.delenv(kk)
+
+
 def test_attention_config5_rows_vs_oracle_fp16():
     """The config-5 size itself (N = 73 728, 4 heads x 32) with fp16 operands: 256 oracle rows at 2e-3."""
     from oracle import turbdiff_oracle as O
