@@ -55,6 +55,7 @@ struct AttnBf16 {
     static __device__ __forceinline__ float unpack_lo(unsigned w) { return __uint_as_float(w << 16); }
     static __device__ __forceinline__ float unpack_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
     static constexpr float lazy = 32.0f;
+    static constexpr float headroom = 0.0f;
 };
 struct AttnF16 {
     typedef f16 T;
@@ -77,6 +78,10 @@ struct AttnF16 {
         return (float)__builtin_bit_cast(h2, w)[1];
     }
     static constexpr float lazy = 15.0f;  // 2^15 < 65504
+    // fp16's allowance is narrow: a segment may START with m up to 2^3 above its first block's maximum when that is what
+    // lets the wave run without the check (probabilities then begin at 2^-3; what fp16 flushes to zero moves from 2^-24
+    // to 2^-21 of the maximum)
+    static constexpr float headroom = 3.0f;
 };
 
 template <typename V8>
@@ -287,6 +292,10 @@ attn_fwd_mfma_kernel(const typename E::T* __restrict__ qkv, typename E::T* __res
             }
             float mx = row_max(s0);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (E::headroom > 0.f) {  // (bound = inf without the key norms: no lift)
+                const float lift = bound - E::lazy + 0.1f - mx;  // what m lacks for the check-free loop
+                if (__builtin_amdgcn_ballot_w64(lift > E::headroom) == 0) mx += fmaxf(lift, 0.f);
+            }
             m = mx;
 #pragma unroll
             for (int i = 0; i < 16; ++i) negm[i] = -mx;
