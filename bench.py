@@ -294,6 +294,68 @@ def timed_train_steps(diff, x, C, md, mode, steps, warmup):
     return 1e3 * (time.perf_counter() - t0) / steps
 
 
+class _Task:
+    """What training.GraphedTrainingStep asks of a task, around a bare GaussianDiffusion and dense inputs."""
+
+    def __init__(self, diff):
+        self.model = diff
+
+    def _model_input(self, b):
+        return b.x, b.C
+
+    def _cell_idx(self, b):
+        return b.cell_idx
+
+    def parameters(self):
+        return self.model.parameters()
+
+
+def host_and_graph_step(diff, x, C, md, mode, steps, warmup):
+    """The same training step eagerly and with forward + backward replayed from ONE captured hipGraph
+    (training.GraphedTrainingStep; clip + RAdam stay eager): ms per step and the HOST's share of it (time to enqueue a
+    step, no device sync inside the timed loop; the device is drained before and after)."""
+    from turbdiff_amd.optim import ClipRAdam
+    from turbdiff_amd.training import GraphedTrainingStep
+
+    set_mode(diff, mode)
+    batch = SimpleNamespace(x=x, C=C, cell_idx=md.cell_idx)
+    res = {}
+    for kind in ("eager", "graph"):
+        diff.zero_grad(set_to_none=True)
+        opt = ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1)
+        gs = GraphedTrainingStep(_Task(diff)) if kind == "graph" else None
+
+        def step():
+            if gs is not None:
+                gs(batch)
+            else:
+                opt.zero_grad(set_to_none=True)
+                loss, _ = diff(x, C, md, None)
+                loss.backward()
+                del loss
+            opt.step()
+
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0, c0 = time.perf_counter(), time.process_time()
+        for _ in range(steps):
+            step()
+        t1, c1 = time.perf_counter(), time.process_time()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        # host_cpu: CPU time of the process (issuing thread + autograd's backward thread: what the host WORKS per step; a
+        # hipGraphLaunch that waits for room in the launch queue spins, so on a device-bound step it counts the wait);
+        # host_enqueue: wall time until the last step is issued
+        res[kind] = {"ms_per_step": 1e3 * (t2 - t0) / steps, "host_enqueue_ms_per_step": 1e3 * (t1 - t0) / steps,
+                     "host_cpu_ms_per_step": 1e3 * (c1 - c0) / steps}
+        del gs, opt
+        diff.zero_grad(set_to_none=True)
+    res["note"] = ("graph = forward + backward as one captured hipGraph per input signature (t and noise drawn inside, weights "
+                   "re-packed inside); clip + RAdam eager in both; host_enqueue = wall time to issue the steps")
+    return res
+
+
 CFG1_GRID = (48, 32, 32)
 
 
@@ -333,6 +395,9 @@ def cfg1_leg(dev, with_cpu):
         loop_s = (time.perf_counter() - t0) / 5
         res["modes"][mode] = {"ms_per_step": ms, "voxels_per_s": v1 / (ms * 1e-3), "sample_loop_ms": 1e3 * loop_s,
                               "ddpm_samples_per_s_T10": 1.0 / loop_s}
+        hg = host_and_graph_step(diff, x, C, md, mode, 20, 5)
+        res["modes"][mode]["captured_step"] = hg
+        res["modes"][mode]["voxels_per_s_captured_step"] = v1 / (hg["graph"]["ms_per_step"] * 1e-3)
     if with_cpu:
         from oracle import turbdiff_oracle as O
 
@@ -703,6 +768,11 @@ def main():
         extra["parity_modes"] = pm
         set_mode(diff, args.dtype)
         leg_done("parity_modes")
+
+    if not args.no_extra and world == 1:
+        # the host's share of the headline step, eager and with forward + backward replayed from one captured graph
+        extra["captured_step"] = host_and_graph_step(diff, x, C, md, args.dtype, 10, 3)
+        leg_done("captured_step")
 
     if not args.no_extra:
         set_mode(diff, args.dtype)

@@ -207,7 +207,9 @@ extern "C" int tdx_p_sample_step(const float* x_t, const float* eps, const float
 // pass 2: scale -> loss.   grad written in pass 1.
 __global__ void __launch_bounds__(256)
 masked_loss_kernel(const float* __restrict__ e, const float* __restrict__ n, const uint8_t* __restrict__ mask, int l1,
-                   double* __restrict__ acc, float* __restrict__ grad, float gscale, int64_t V) {
+                   double* __restrict__ acc, float* __restrict__ grad, float gscale, int64_t V,
+                   const int64_t* __restrict__ n_cells_dev, double samples) {
+    if (n_cells_dev) gscale = (float)(1.0 / (samples * (double)*n_cells_dev));
     const int64_t base = (int64_t)blockIdx.y * V;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float s = 0.f;
@@ -232,7 +234,9 @@ masked_loss_kernel(const float* __restrict__ e, const float* __restrict__ n, con
 // thread at 192 x 64 x 48: 67 us for 170 MB (profiles/r11_batch_scaling.txt); this one streams.
 __global__ void __launch_bounds__(256)
 masked_loss_vec_kernel(const float* __restrict__ e, const float* __restrict__ n, const uint8_t* __restrict__ mask, int l1,
-                       double* __restrict__ acc, float* __restrict__ grad, float gscale, int64_t V) {
+                       double* __restrict__ acc, float* __restrict__ grad, float gscale, int64_t V,
+                       const int64_t* __restrict__ n_cells_dev, double samples) {
+    if (n_cells_dev) gscale = (float)(1.0 / (samples * (double)*n_cells_dev));
     const int64_t base = (int64_t)blockIdx.y * V;
     const int64_t V4 = V >> 2, stride = (int64_t)gridDim.x * blockDim.x;
     float s = 0.f;
@@ -266,28 +270,48 @@ masked_loss_vec_kernel(const float* __restrict__ e, const float* __restrict__ n,
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
 }
-__global__ void masked_loss_finish(const double* acc, float* loss, double inv) { loss[0] = (float)(acc[0] * inv); }
+__global__ void masked_loss_finish(const double* acc, float* loss, double inv, const int64_t* n_cells_dev, double samples) {
+    if (n_cells_dev) inv = 1.0 / (samples * (double)*n_cells_dev);
+    loss[0] = (float)(acc[0] * inv);
+}
 
 extern "C" size_t tdx_masked_loss_workspace_bytes(void) { return 16; }
-extern "C" int tdx_masked_loss(const float* eps_hat, const float* noise, const uint8_t* mask, int64_t n_cells, int l1,
-                               float* loss, float* grad, int B, int F, int64_t V, void* workspace, void* stream) {
-    TDX_CHECK_ARG(eps_hat && noise && mask && loss && workspace && n_cells > 0 && B > 0 && F > 0 && V > 0);
+static int masked_loss_launch(const float* eps_hat, const float* noise, const uint8_t* mask, int64_t n_cells,
+                              const int64_t* n_cells_dev, int l1, float* loss, float* grad, int B, int F, int64_t V,
+                              void* workspace, void* stream) {
     hipError_t err = hipMemsetAsync(workspace, 0, 16, as_stream(stream));
     if (err != hipSuccess) return (int)err;
-    const double inv = 1.0 / ((double)B * F * (double)n_cells);
+    const double samples = (double)B * F;
+    const double inv = n_cells_dev ? 0.0 : 1.0 / (samples * (double)n_cells);
     const bool vec = (V % 4) == 0 && ((uintptr_t)eps_hat % 16) == 0 && ((uintptr_t)noise % 16) == 0 && ((uintptr_t)mask % 4) == 0 &&
                      (grad == nullptr || ((uintptr_t)grad % 16) == 0);
     if (vec) {
         dim3 grid((unsigned)min((int64_t)128, (V / 4 + 511) / 512), B * F);
         hipLaunchKernelGGL(masked_loss_vec_kernel, grid, dim3(256), 0, as_stream(stream), eps_hat, noise, mask, l1,
-                           (double*)workspace, grad, (float)inv, V);
+                           (double*)workspace, grad, (float)inv, V, n_cells_dev, samples);
     } else {
         dim3 grid((unsigned)min((int64_t)64, (V + 255) / 256), B * F);
         hipLaunchKernelGGL(masked_loss_kernel, grid, dim3(256), 0, as_stream(stream), eps_hat, noise, mask, l1,
-                           (double*)workspace, grad, (float)inv, V);
+                           (double*)workspace, grad, (float)inv, V, n_cells_dev, samples);
     }
-    hipLaunchKernelGGL(masked_loss_finish, dim3(1), dim3(1), 0, as_stream(stream), (const double*)workspace, loss, inv);
+    hipLaunchKernelGGL(masked_loss_finish, dim3(1), dim3(1), 0, as_stream(stream), (const double*)workspace, loss, inv,
+                       n_cells_dev, samples);
     return tdx_launch_status();
+}
+
+extern "C" int tdx_masked_loss(const float* eps_hat, const float* noise, const uint8_t* mask, int64_t n_cells, int l1,
+                               float* loss, float* grad, int B, int F, int64_t V, void* workspace, void* stream) {
+    TDX_CHECK_ARG(eps_hat && noise && mask && loss && workspace && n_cells > 0 && B > 0 && F > 0 && V > 0);
+    return masked_loss_launch(eps_hat, noise, mask, n_cells, nullptr, l1, loss, grad, B, F, V, workspace, stream);
+}
+
+// the same with the number of in-domain cells read from device memory at run time (int64 scalar): a captured training
+// step (hipGraph) serves geometries with different cell counts through one graph
+extern "C" int tdx_masked_loss_dyn(const float* eps_hat, const float* noise, const uint8_t* mask,
+                                   const int64_t* n_cells_dev, int l1, float* loss, float* grad, int B, int F, int64_t V,
+                                   void* workspace, void* stream) {
+    TDX_CHECK_ARG(eps_hat && noise && mask && loss && workspace && n_cells_dev && B > 0 && F > 0 && V > 0);
+    return masked_loss_launch(eps_hat, noise, mask, 0, n_cells_dev, l1, loss, grad, B, F, V, workspace, stream);
 }
 
 // ------------------------------------------------------------------ Philox N(0,1) --------

@@ -70,6 +70,7 @@ SIGNATURES = {
     "tdx_p_sample_step": (_i, [_vp] * 7 + [_i, _vp, _i, _i, _vp, _i, _i, _i64, _vp]),
     "tdx_p_sample_step_rng": (_i, [_vp] * 5 + [_i, _vp, _i, _i, _vp, _i, _i, _i64, _u64, _vp, _vp, _vp]),
     "tdx_masked_loss": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i64, _vp, _vp]),
+    "tdx_masked_loss_dyn": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i64, _vp, _vp]),
     "tdx_masked_loss_workspace_bytes": (_sz, []),
     "tdx_grid_embed": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i64, _vp]),
     "tdx_grid_select": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i64, _i64, _vp]),

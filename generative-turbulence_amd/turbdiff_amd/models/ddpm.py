@@ -793,7 +793,14 @@ class GaussianDiffusion(nn.Module):
     def p_losses(self, x_start, t, C, metadata, variables, noise=None):
         x_start = x_start.contiguous().float()
         cell_idx = metadata.cell_idx
-        mask, n_cells = self.domain_mask(cell_idx, x_start[0, 0].numel())
+        dm = getattr(metadata, "domain_mask", None)
+        if dm is not None:
+            # (uint8 [V] mask, int64 device scalar n_cells) in buffers the caller owns: training.GraphedTrainingStep
+            # replays one captured step for every geometry of a grid size by copying into them
+            mask, n_cells = dm
+            assert not (self.learned_variances and self.elbo_weight is not None), "the ELBO term gathers by cell_idx"
+        else:
+            mask, n_cells = self.domain_mask(cell_idx, x_start[0, 0].numel())
         if noise is None:
             noise = torch.randn_like(x_start)
         x_t = ops.q_sample(x_start, noise, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod, t,

@@ -698,8 +698,12 @@ class _MaskedLoss(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=eps_hat.device)
         grad = torch.empty_like(eps_hat) if eps_hat.requires_grad else None
         ws = _ws(L.query("tdx_masked_loss_workspace_bytes"), eps_hat.device)
-        L.call("tdx_masked_loss", L.ptr(eps_hat), L.ptr(noise), L.ptr(mask), n_cells, int(l1), L.ptr(loss), L.ptr(grad),
-               B, F, V, L.ptr(ws), L.stream())
+        if torch.is_tensor(n_cells):  # device int64 scalar, read when the kernels run (captured training step)
+            L.call("tdx_masked_loss_dyn", L.ptr(eps_hat), L.ptr(noise), L.ptr(mask), L.ptr(n_cells), int(l1), L.ptr(loss),
+                   L.ptr(grad), B, F, V, L.ptr(ws), L.stream())
+        else:
+            L.call("tdx_masked_loss", L.ptr(eps_hat), L.ptr(noise), L.ptr(mask), n_cells, int(l1), L.ptr(loss), L.ptr(grad),
+                   B, F, V, L.ptr(ws), L.stream())
         if grad is not None:
             ctx.save_for_backward(grad)
         return loss.reshape(())
@@ -712,7 +716,11 @@ class _MaskedLoss(torch.autograd.Function):
 
 
 def masked_loss(eps_hat, noise, mask, n_cells, l1=False):
-    """mean over batch of the mean error over (features, in-domain cells), ddpm.py:845-852."""
+    """mean over batch of the mean error over (features, in-domain cells), ddpm.py:845-852.  n_cells: the number of
+    in-domain cells as a Python int, or as an int64 device scalar read at run time."""
+    if torch.is_tensor(n_cells):
+        assert n_cells.dtype == torch.int64 and n_cells.numel() == 1 and n_cells.is_cuda
+        return _MaskedLoss.apply(eps_hat, noise, mask, n_cells, l1)
     return _MaskedLoss.apply(eps_hat, noise, mask, int(n_cells), l1)
 
 

@@ -15,6 +15,7 @@ optimizer state_dicts move between the two implementations.
 
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -97,23 +98,42 @@ class ClipRAdam(torch.optim.Optimizer):
             k = plan["turn"] = (plan["turn"] + 1) % 3
             if plan["events"][k] is not None:
                 plan["events"][k].synchronize()
+            params = plan["params"]
+            grads = [p.grad for p in params]
+            if any(g is not None and (g.dtype != torch.float32 or not g.is_contiguous()) for g in grads):
+                for p, g in zip(params, grads):
+                    if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                        p.grad = g.float().contiguous()
+                grads = [p.grad for p in params]
+            # the host's share of a step matters once forward + backward replay from a captured graph: the static columns
+            # (parameter / moment addresses, sizes) are written once per plan, the gradient column as one array, and the
+            # per-parameter step counters (0-dim views into ONE tensor, so state_dict keeps torch's layout) with one add
+            fixed = plan.get("fixed")
+            state = [self.state[p] for p in params]
+            if fixed is None or any(st["exp_avg"] is not a or st["step"] is not v for st, a, v in zip(state, fixed[1], fixed[3])):
+                # first step, or somebody replaced state tensors (load_state_dict): adopt them
+                cols = np.array([[p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()]
+                                 for p, st in zip(params, state)], dtype=np.int64)
+                steps = torch.tensor([float(st["step"]) for st in state], dtype=torch.float32)
+                views = [steps[i] for i in range(len(params))]
+                for st, v in zip(state, views):
+                    st["step"] = v
+                fixed = plan["fixed"] = (cols, [st["exp_avg"] for st in state], steps, views)
             tab = plan["hosts"][k].numpy()
-            for i, p in enumerate(plan["params"]):
-                st = self.state[p]
-                g = p.grad
-                if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
-                    g = p.grad = g.float().contiguous()
-                tab[i, 0] = p.data_ptr()
-                tab[i, 1] = g.data_ptr() if g is not None else 0
-                tab[i, 2] = st["exp_avg"].data_ptr()
-                tab[i, 3] = st["exp_avg_sq"].data_ptr()
-                tab[i, 4] = p.numel()
-                if g is not None:
-                    st["step"] += 1
+            tab[:] = fixed[0]
+            tab[:, 1] = [0 if g is None else g.data_ptr() for g in grads]
+            steps = fixed[2]
+            live_all = all(g is not None for g in grads)
+            if live_all:
+                steps += 1
+            else:
+                for i, g in enumerate(grads):
+                    if g is not None:
+                        steps[i] += 1
             plan["table"].copy_(plan["hosts"][k], non_blocking=True)
             plan["events"][k] = torch.cuda.Event()
             plan["events"][k].record()
-            live = [i for i, p in enumerate(plan["params"]) if p.grad is not None]
+            live = [i for i, g in enumerate(grads) if g is not None]
             if not live:
                 continue
             stream = L.stream()
@@ -128,8 +148,12 @@ class ClipRAdam(torch.optim.Optimizer):
             # received gradients on different numbers of steps (conditional branches, a state_dict loaded from
             # torch.optim.RAdam) are updated in one launch per distinct count, over that count's chunks only
             by_step = {}
-            for i in live:
-                by_step.setdefault(int(self.state[plan["params"][i]]["step"]), []).append(i)
+            counts = steps.tolist()
+            if live_all and counts.count(counts[0]) == len(counts):
+                by_step[int(counts[0])] = live
+            else:
+                for i in live:
+                    by_step.setdefault(int(counts[i]), []).append(i)
             for step_count, members in by_step.items():
                 if len(by_step) == 1:
                     ct, co, n = plan["chunk_tensor"], plan["chunk_off"], plan["nchunks"]

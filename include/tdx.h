@@ -333,6 +333,11 @@ int tdx_p_sample_step_rng(const float* x_t, const float* eps, const float* x_bcs
  * Writes loss[0] and, if grad != NULL, d loss / d eps_hat (zero outside the mask). */
 int tdx_masked_loss(const float* eps_hat, const float* noise, const uint8_t* mask, int64_t n_cells, int l1,
                     float* loss, float* grad, int B, int F, int64_t V, void* workspace, void* stream);
+/* The same with n_cells read from device memory when the kernels run (int64 scalar): what a hipGraph-captured training step
+ * (turbdiff_amd/training.py, GraphedTrainingStep) calls, so that geometries with different in-domain cell counts
+ * (utils.py:13-19 `select_cells` over `cell_idx`, ddpm.py:848) replay one graph. */
+int tdx_masked_loss_dyn(const float* eps_hat, const float* noise, const unsigned char* mask, const int64_t* n_cells_dev,
+                        int l1, float* loss, float* grad, int B, int F, int64_t V, void* workspace, void* stream);
 size_t tdx_masked_loss_workspace_bytes(void);
 
 /* ------------------------------------------------------------------ data ingress / egress */

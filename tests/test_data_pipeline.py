@@ -383,3 +383,91 @@ def test_sample_store_and_reader_over_real_hdf5_files(tmp_path):
         assert torch.equal(da.samples[v], db.samples[v])
     assert torch.equal(da.metadata.cell_idx, db.metadata.cell_idx) and da.metadata.nu == db.metadata.nu
     assert sorted(da.metadata.boundaries) == sorted(db.metadata.boundaries)
+
+
+@pytest.mark.gpu
+def test_graphed_training_step_equals_the_eager_step_and_serves_other_geometries():
+    """forward + backward of DiffusionTrainer.training_step as ONE captured hipGraph
+    (training.GraphedTrainingStep).  (a) With injected timesteps / noise the replayed step gives the eager step's loss
+    and gradients -- every U-Net parameter AND the learned cell-type table, whose gradient leaves the graph through the
+    conditioning tensor and is chained eagerly -- for two geometries of one grid size with different in-domain cell
+    counts through the SAME graph (n_cells is read on the device: tdx_masked_loss_dyn); (b) the default mode
+    (enable_graph_step: t and noise drawn inside the graph) trains: losses differ from replay to replay, parameters move,
+    no re-capture; (c) weights packed inside the graph: after optimiser steps the replay uses the NEW weights."""
+    from turbdiff_amd.data.ofles import BoundaryCondition as BC
+    from turbdiff_amd.training import DiffusionTrainer, GraphedTrainingStep
+
+    gen = torch.Generator().manual_seed(1)
+    counts = (12, 10, 9)
+    idx = torch.arange(12 * 10 * 9).reshape(counts)
+
+    def case(hole):
+        inside = torch.zeros(counts, dtype=torch.bool)
+        inside[1:-1, 1:-1, 1:-1] = True
+        if hole:
+            inside[3:6, 2:5, 2:6] = False
+        cell_idx = inside.flatten().nonzero().flatten()
+        meta = OpenFOAMMetadata(np.array(counts), cell_idx, {"walls": {"idx": idx[:, 0].flatten()}, "inlets": {"idx": idx[0].flatten()}},
+                                {Variable.U: {"inlets": BC(BC.Type.FIXED_VALUE, torch.tensor([1.0, 0.0, 0.0]))}})
+        fields = {Variable.U: torch.randn(4, len(cell_idx), 3, generator=gen), Variable.P: torch.randn(4, len(cell_idx), 1, generator=gen)}
+        return meta, np.arange(4) * 0.1, fields
+
+    stats = OpenFOAMStats({"u": {"mean": torch.zeros(3), "std": torch.ones(3) * 1.5}, "p": {"mean": torch.tensor(0.1), "std": torch.tensor(0.8)}})
+    ds = OpenFOAMDataset(InMemoryRepository([case(False), case(True)]), stats, discard_first_seconds=-1.0)
+    dev = torch.device("cuda:0")
+    to_dev = lambda b: next(iter(__import__("turbdiff_amd.data.staging", fromlist=["DeviceStager"]).DeviceStager([b], dev)))
+    batches = [to_dev(ds[[0, 1]]), to_dev(ds[[4, 5]])]  # one batch per geometry
+    assert batches[0].data.metadata.cell_idx.numel() != batches[1].data.metadata.cell_idx.numel()
+    torch.manual_seed(0)
+    tr = DiffusionTrainer(**{**DiffusionTrainer.SHIPPED_CONFIG, "dim": 8, "timesteps": 10}, u_net_levels=2, normalization_mode="mean-std",
+                          max_train_steps=10, compute_mode="f32").to(dev)
+    table = tr.cell_type_embedding.embedding.weight
+    # (a)
+    gs = GraphedTrainingStep(tr, inject=True)
+    for i, b in enumerate(batches):
+        t = torch.tensor([3, 7], device=dev)
+        noise = torch.randn(2, 4, *counts, generator=torch.Generator().manual_seed(10 + i)).to(dev)
+        tr.zero_grad(set_to_none=True)
+        x, C = tr._model_input(b)
+        from types import SimpleNamespace
+        loss, _ = tr.model.p_losses(x, t, C, SimpleNamespace(cell_idx=b.data.metadata.cell_idx), None, noise=noise)
+        loss.backward()
+        want = {n: p.grad.clone() for n, p in tr.named_parameters() if p.grad is not None}
+        assert "cell_type_embedding.embedding.weight" in want or "conditioning.cell_type_embedding.embedding.weight" in want
+        want_loss = loss.item()
+        del loss, x, C  # no eager autograd graph may be alive when the step is captured (its AccumulateGrad nodes
+        tr.zero_grad(set_to_none=True)  # belong to the stream the eager backward ran on)
+        gs.set_draws(t, noise)
+        got = gs(b)
+        assert len(gs.slots) == 1, "both geometries must replay one graph"
+        assert abs(got.item() - want_loss) < 1e-5 * abs(want_loss)
+        for n, p in tr.named_parameters():
+            if n in want:
+                assert p.grad is not None, n
+                d = (p.grad - want[n]).norm().item()
+                assert d <= 1e-4 * want[n].norm().item() + 1e-9, (i, n, d)
+    assert table.grad is not None and table.grad.abs().sum() > 0
+    # (b), (c)
+    tr.zero_grad(set_to_none=True)
+    tr.enable_graph_step()
+    before = {n: p.detach().clone() for n, p in tr.named_parameters()}
+    torch.manual_seed(5)
+    losses = [tr.fit_step(batches[i % 2]).item() for i in range(6)]
+    assert all(np.isfinite(losses)) and len(set(round(l, 6) for l in losses)) > 1
+    assert len(tr._graph_step.slots) == 1
+    moved = [n for n, p in tr.named_parameters() if not torch.equal(p.detach(), before[n])]
+    # (a conv bias in front of a GroupNorm has a mathematically zero gradient: rounding noise may or may not move it)
+    assert all(".conv.bias" in n for n in set(before) - set(moved)) and len(moved) > 0.9 * len(before), set(before) - set(moved)
+    # the graph packs the weights of the moment: an eager step on the same inputs and draws agrees with a replay after
+    # six optimiser steps
+    gs2 = GraphedTrainingStep(tr, inject=True)
+    t = torch.tensor([1, 9], device=dev)
+    noise = torch.randn(2, 4, *counts, generator=torch.Generator().manual_seed(77)).to(dev)
+    gs2.set_draws(t, noise)
+    gs2(batches[0])               # captures (and replays once) under the current weights
+    tr._opt.step()                # weights change in place
+    got = gs2(batches[0]).item()
+    x, C = tr._model_input(batches[0])
+    with torch.no_grad():
+        want, _ = tr.model.p_losses(x, t, C, SimpleNamespace(cell_idx=batches[0].data.metadata.cell_idx), None, noise=noise)
+    assert abs(got - want.item()) < 1e-5 * abs(want.item()), (got, want.item())
