@@ -350,26 +350,45 @@ class DenoisingModel(nn.Module):
             if hasattr(self, n):
                 yield from reversed(list(getattr(self, n).parameters()))
 
+    def __getstate__(self):
+        # copy.deepcopy / pickle: the cached module lists and pack plans (device buffers, foreign job tables) stay behind
+        state = super().__getstate__()
+        state.pop("_lists", None)
+        return state
+
+    def _static_lists(self):
+        """Module lists the forward needs every call (the module tree does not change after construction): the 3x3x3 and
+        1x1 weights whose operands are prefetched, and the ResnetBlocks in FiLM order."""
+        hit = self.__dict__.get("_lists")
+        if hit is None:
+            conv3, conv1, blocks = [], [], []
+            for m in self.modules():
+                if isinstance(m, Block):
+                    conv3.append(m.conv)
+                elif isinstance(m, ResnetBlock):
+                    blocks.append(m)
+                    if not isinstance(m.conv, nn.Identity):
+                        conv1.append(m.conv)
+                elif isinstance(m, Attention):
+                    conv1 += [m.to_qkv, m.to_out]
+            hit = self.__dict__["_lists"] = (conv3, conv1, blocks, {})
+        return hit
+
     def prefetch_weights(self, skip_first_conv: bool):
         """Packed operands of all 3x3x3 weights and transposed copies of all 1x1 weights the forward is about to
         ask for, refreshed in one launch each (ops.prefetch_weights) instead of one launch per layer on first use."""
-        conv3, conv1 = [], []
-        first = self.u_net.downsampling_blocks[0].block1.conv.weight if skip_first_conv else None
-        for m in self.modules():
-            if isinstance(m, Block) and m.conv.weight is not first:
-                conv3.append(m.conv.weight)
-            elif isinstance(m, ResnetBlock) and not isinstance(m.conv, nn.Identity):
-                conv1.append(m.conv.weight)
-            elif isinstance(m, Attention):
-                conv1 += [m.to_qkv.weight, m.to_out.weight]
-        ops.prefetch_weights(conv3, conv1, self.compute_dtype)
+        conv3, conv1, _, plans = self._static_lists()
+        first = self.u_net.downsampling_blocks[0].block1.conv if skip_first_conv else None
+        key = (bool(skip_first_conv), self.compute_dtype, _lib.pack_code(self.compute_dtype))
+        plans[key] = ops.prefetch_weights([m.weight for m in conv3 if m is not first], [m.weight for m in conv1],
+                                          self.compute_dtype, plans.get(key))
 
     def film_table(self, c):
         """{id(block): (2, B, dim_out) [scale, shift]} for every ResnetBlock, projected from the conditioning vector
         in one launch (the reference projects inside each block, ddpm.py:191-192)."""
         if os.environ.get("TDX_FILM", "1") == "0":
             return None
-        blocks = [m for m in self.modules() if isinstance(m, ResnetBlock)]
+        blocks = self._static_lists()[2]
         films = ops.film_projections(c, [b.project_onto_scale_shift for b in blocks])
         return {id(b): f for b, f in zip(blocks, films)}
 

@@ -281,43 +281,62 @@ def _cache_fresh(key, weight) -> bool:
     return hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr()
 
 
-def prefetch_weights(conv3_weights, conv1_weights, dtype: torch.dtype) -> None:
+class PackPlan:
+    """Packed operands of a FIXED list of 3x3x3 weights and transposed copies of a fixed list of 1x1 weights, kept in
+    buffers the plan owns and refreshed IN PLACE by one launch each when a weight changed (every optimiser step in
+    training; never while sampling).  The job tables are built once: a refresh costs the host a version check per weight
+    and two foreign calls -- the per-step loop that allocated 2 x 22 operand tensors and rebuilt both tables was 0.3 ms
+    of device idle time at the head of every training step (tools/timeline_gaps.py).  `_packed_conv3` / `_conv1_wt`
+    find the operands through the shared cache, as before."""
+
+    def __init__(self, conv3_weights, conv1_weights, dtype: torch.dtype):
+        self.dtype, self.code = dtype, L.pack_code(dtype)
+        self.w3, self.w1 = list(conv3_weights), list(conv1_weights)
+        for w in self.w3 + self.w1:
+            assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous(), "fp32 contiguous device parameters"
+        self.ops3 = [(torch.empty(27 * w.shape[1] * w.shape[0], dtype=dtype, device=w.device),
+                      torch.empty(27 * w.shape[1] * w.shape[0], dtype=dtype, device=w.device)) for w in self.w3]
+        self.ops1 = [torch.empty((w[0].numel(), w.shape[0]), dtype=torch.float32, device=w.device) for w in self.w1]
+        self.tab3 = (L.PackJob * max(len(self.w3), 1))(*[L.PackJob(w.data_ptr(), wf.data_ptr(), wb.data_ptr(), w.shape[1], w.shape[0])
+                                                         for w, (wf, wb) in zip(self.w3, self.ops3)])
+        self.tab1 = (L.TransposeJob * max(len(self.w1), 1))(*[L.TransposeJob(w.data_ptr(), wt.data_ptr(), w.shape[0], w[0].numel())
+                                                              for w, wt in zip(self.w1, self.ops1)])
+        self.ptrs = [w.data_ptr() for w in self.w3 + self.w1]
+        self.seen3, self.seen1 = [None] * len(self.w3), [None] * len(self.w1)
+
+    def valid_for(self, conv3_weights, conv1_weights, dtype) -> bool:
+        """Same parameter tensors at the same addresses, same operand format?"""
+        ws = list(conv3_weights) + list(conv1_weights)
+        return (dtype == self.dtype and L.pack_code(dtype) == self.code and len(ws) == len(self.ptrs)
+                and all(a is b for a, b in zip(ws, self.w3 + self.w1)) and all(w.data_ptr() == p for w, p in zip(ws, self.ptrs)))
+
+    def refresh(self) -> None:
+        if self.w3 and any(w._version != v for w, v in zip(self.w3, self.seen3)):
+            L.call("tdx_conv3_pack_weights", self.tab3, len(self.w3), self.code, L.stream())
+            for i, (w, (wf, wb)) in enumerate(zip(self.w3, self.ops3)):
+                self.seen3[i] = w._version
+                _pack_cache[(id(w), self.dtype, self.code)] = (weakref.ref(w), w._version, w.data_ptr(), wf, wb)
+        if self.w1 and any(w._version != v for w, v in zip(self.w1, self.seen1)):
+            L.call("tdx_transpose_many", self.tab1, len(self.w1), L.stream())
+            for i, (w, wt) in enumerate(zip(self.w1, self.ops1)):
+                self.seen1[i] = w._version
+                _pack_cache[(id(w), "wt")] = (weakref.ref(w), w._version, w.data_ptr(), wt, None)
+
+
+def prefetch_weights(conv3_weights, conv1_weights, dtype: torch.dtype, plan: "PackPlan | None" = None) -> "PackPlan | None":
     """Refresh the packed operands of all given 3x3x3 weights (as _packed_conv3 would, one by one) and the transposed
-    copies of all given 1x1 weights (as _conv1_wt would) in ONE launch each, for those whose cached copy is stale --
-    after an optimiser step that is every weight, and a model forward would otherwise start with ~30 tiny launches.
-    The later _packed_conv3 / _conv1_wt calls then hit the cache."""
+    copies of all given 1x1 weights (as _conv1_wt would) in ONE launch each -- after an optimiser step every weight is
+    stale, and a model forward would otherwise start with ~30 tiny launches.  Returns the PackPlan to pass back in next
+    time (it is rebuilt when the parameter tensors or the operand format changed); the later _packed_conv3 / _conv1_wt
+    calls hit the cache."""
     if os.environ.get("TDX_PREFETCH", "1") == "0":  # A/B switch: every layer packs on first use
-        return
-    code = L.pack_code(dtype)
-    jobs, keep = [], []
-    for w in conv3_weights:
-        key = (id(w), dtype, code)
-        if _cache_fresh(key, w):
-            continue
-        Cout, Cin = w.shape[0], w.shape[1]
-        src = w.detach().contiguous()
-        wf = torch.empty(27 * Cin * Cout, dtype=dtype, device=w.device)
-        wb = torch.empty(27 * Cin * Cout, dtype=dtype, device=w.device)
-        jobs.append(L.PackJob(L.ptr(src), L.ptr(wf), L.ptr(wb), Cin, Cout))
-        keep.append(src)
-        _pack_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), wf, wb)
-    if jobs:
-        L.call("tdx_conv3_pack_weights", (L.PackJob * len(jobs))(*jobs), len(jobs), code, L.stream())
-    jobs = []
-    for w in conv1_weights:
-        key = (id(w), "wt")
-        if _cache_fresh(key, w):
-            continue
-        Cout = w.shape[0]
-        src = w.detach().reshape(Cout, -1).float().contiguous()
-        wt = torch.empty((src.shape[1], Cout), dtype=torch.float32, device=w.device)
-        jobs.append(L.TransposeJob(L.ptr(src), L.ptr(wt), Cout, src.shape[1]))
-        keep.append(src)
-        _pack_cache[key] = (weakref.ref(w), w._version, w.data_ptr(), wt, None)
-    if jobs:
-        L.call("tdx_transpose_many", (L.TransposeJob * len(jobs))(*jobs), len(jobs), L.stream())
+        return None
+    if plan is None or not plan.valid_for(conv3_weights, conv1_weights, dtype):
+        plan = PackPlan(conv3_weights, conv1_weights, dtype)
+    plan.refresh()
     if len(_pack_cache) > 4096:
         _pack_cache.clear()
+    return plan
 
 
 def conv3_partial_supported(x, weight, n_lead: int) -> bool:
@@ -752,18 +771,26 @@ class _FilmProjections(torch.autograd.Function):
         n = len(wb) // 2
         c32 = c.detach().float().contiguous()
         B, T = c32.shape
-        ws = [wb[2 * i].detach().float().contiguous() for i in range(n)]
-        bs = [None if wb[2 * i + 1] is None else wb[2 * i + 1].detach().float().contiguous() for i in range(n)]
-        outs = []
+        # fp32 contiguous parameters are used as they are (no per-layer detach / cast / copy calls: with 11 layers they
+        # were a tenth of a millisecond of host time in front of the first conv of every forward)
+        plain = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+        ws = [plain(wb[2 * i].detach()) for i in range(n)]
+        bs = [None if wb[2 * i + 1] is None else plain(wb[2 * i + 1].detach()) for i in range(n)]
+        halves = [w.shape[0] // 2 for w in ws]
+        flat = torch.empty(2 * B * sum(halves), dtype=torch.float32, device=c.device)  # all layers' (2, B, C_i) outputs
+        outs, off = [], 0
+        for h in halves:
+            outs.append(flat[off : off + 2 * B * h].view(2, B, h))
+            off += 2 * B * h
+        base = flat.data_ptr()
+        off = 0
         for lo in range(0, n, L.FILM_MAX_LAYERS):
             hi = min(n, lo + L.FILM_MAX_LAYERS)
             tab = (L.FilmLayer * (hi - lo))()
             for j, i in enumerate(range(lo, hi)):
-                C2 = ws[i].shape[0]
-                assert ws[i].shape == (C2, T) and C2 % 2 == 0
-                out = torch.empty((2, B, C2 // 2), dtype=torch.float32, device=c.device)
-                tab[j] = L.FilmLayer(L.ptr(ws[i]), L.ptr(bs[i]), L.ptr(out), C2 // 2)
-                outs.append(out)
+                assert ws[i].shape == (2 * halves[i], T)
+                tab[j] = L.FilmLayer(ws[i].data_ptr(), None if bs[i] is None else bs[i].data_ptr(), base + 4 * off, halves[i])
+                off += 2 * B * halves[i]
             L.call("tdx_film_fwd", L.ptr(c32), B, T, tab, hi - lo, L.stream())
         ctx.save_for_backward(c32, *ws)
         ctx.has_bias = [b is not None for b in bs]
