@@ -98,7 +98,10 @@ attn_bwd_dq_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E:
     const float sm_scale = rsqrtf((float)FB_D);
 
     typename E::V8 qf[2][2], gf[2][2];  // Q (pre-scaled) and dO as B operands: col = query r, k = d
-    float lse2[2], dl[2];
+    // -lse log2(e) and -delta of the lane's query, broadcast over the 16 accumulator registers: as the C operands of the
+    // score / dP products they deliver S^T - lse and dP^T - delta straight from the matrix pipe (the kernel is bound by its
+    // vector-ALU work: that was 32 subtractions and 32 zeroing moves of ~110 issue slots per 32 x 32 tile)
+    f32x16 nl[2], nd[2];
     f32x16 dq[2];               // dQ^T[d][q]
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -108,10 +111,9 @@ attn_bwd_dq_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E:
             qf[qt][ks] = fb_row_frag<E>(base + (int64_t)q * ld + h * FB_D + ks * 16 + hh * 8, FB_LOG2E * sm_scale);
             gf[qt][ks] = fb_row_frag<E>(dout + ((int64_t)b * N + q) * (H * FB_D) + h * FB_D + ks * 16 + hh * 8, 1.0f);
         }
-        lse2[qt] = lse[((int64_t)b * H + h) * N + q] * FB_LOG2E;
-        dl[qt] = delta[((int64_t)b * H + h) * N + q];
+        const float ml = -lse[((int64_t)b * H + h) * N + q] * FB_LOG2E, md = -delta[((int64_t)b * H + h) * N + q];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dq[qt][i] = 0.f;
+        for (int i = 0; i < 16; ++i) { dq[qt][i] = 0.f; nl[qt][i] = ml; nd[qt][i] = md; }
     }
 
     const int st_row = tid >> 2, st_c = tid & 3;
@@ -149,18 +151,15 @@ attn_bwd_dq_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E:
             }
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
-                f32x16 st, dp;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
-                st = E::mfma(kf[0], qf[qt][0], st);
+                f32x16 st = E::mfma(kf[0], qf[qt][0], nl[qt]);   // S^T - lse
                 st = E::mfma(kf[1], qf[qt][1], st);
-                dp = E::mfma(vf[0], gf[qt][0], dp);
+                f32x16 dp = E::mfma(vf[0], gf[qt][0], nd[qt]);   // dP^T - delta
                 dp = E::mfma(vf[1], gf[qt][1], dp);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    float p = __builtin_amdgcn_exp2f(st[i] - lse2[qt]);
+                    float p = __builtin_amdgcn_exp2f(st[i]);
                     if (TAIL && k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= N) p = 0.f;  // keys beyond N
-                    st[i] = p * (dp[i] - dl[qt]);  // dS^T
+                    st[i] = p * dp[i];  // dS^T
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) dq[qt] = E::mfma(ktf[s], fb_as_b<E>(st, s), dq[qt]);
@@ -200,8 +199,8 @@ attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E
     unsigned char* sQp = smem + FB_T * 64;      // Q tile, plain rows (Q^T fragments)
     unsigned char* sG = smem + 2 * FB_T * 64;   // dO tile, swizzled (dP = dO V^T)
     unsigned char* sGp = smem + 3 * FB_T * 64;  // dO tile, plain rows (dO^T fragments)
-    float* sL = reinterpret_cast<float*>(smem + 4 * FB_T * 64);  // lse * log2(e) of the tile's queries (+inf beyond N)
-    float* sD = sL + FB_T;                                        // delta
+    float* sL = reinterpret_cast<float*>(smem + 4 * FB_T * 64);  // -lse * log2(e) of the tile's queries (-inf beyond N)
+    float* sD = sL + FB_T;                                        // -delta
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -234,8 +233,8 @@ attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E
         greg = *reinterpret_cast<const uint4*>(dout + ((int64_t)b * N + q) * (H * FB_D) + h * FB_D + st_c * 8);
         if (tid < FB_T) {
             const int qq = i0 + tid;
-            lreg = qq < N ? lse[((int64_t)b * H + h) * N + qq] * FB_LOG2E : INFINITY;  // exp2(s - inf) = 0: no query there
-            dreg = qq < N ? delta[((int64_t)b * H + h) * N + qq] : 0.f;
+            lreg = qq < N ? -lse[((int64_t)b * H + h) * N + qq] * FB_LOG2E : -INFINITY;  // exp2(s - inf) = 0: no query there
+            dreg = qq < N ? -delta[((int64_t)b * H + h) * N + qq] : 0.f;
         }
     };
     const int g = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
@@ -266,8 +265,10 @@ attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E
                 qtf[s] = fb_tr_frag<typename E::V8>(sQp + off, sQp + off + 8 * 64);
                 gtf[s] = fb_tr_frag<typename E::V8>(sGp + off, sGp + off + 8 * 64);
             }
-            // per-register row scalars: register i <-> query row (i & 3) + 8 (i >> 2) + 4 hh of the block
-            float lrow[16], drow[16];
+            // per-register row scalars: register i <-> query row (i & 3) + 8 (i >> 2) + 4 hh of the block.  The sixteen
+            // (negated) values ARE the C operands of the score / dP products: S - lse and dP - delta come out of the
+            // matrix pipe, the vector ALU keeps the exponential, one product and the conversions
+            f32x16 lrow, drow;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float4 l4 = *reinterpret_cast<const float4*>(sL + qb * 32 + 8 * c + 4 * hh);
@@ -277,17 +278,14 @@ attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E
             }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                f32x16 st, dp;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) st[i] = dp[i] = 0.f;
-                st = E::mfma(qa[0], kf[kt][0], st);
+                f32x16 st = E::mfma(qa[0], kf[kt][0], lrow);
                 st = E::mfma(qa[1], kf[kt][1], st);
-                dp = E::mfma(ga[0], vf[kt][0], dp);
+                f32x16 dp = E::mfma(ga[0], vf[kt][0], drow);
                 dp = E::mfma(ga[1], vf[kt][1], dp);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    st[i] = __builtin_amdgcn_exp2f(st[i] - lrow[i]);  // P
-                    dp[i] = st[i] * (dp[i] - drow[i]);                 // dS
+                    st[i] = __builtin_amdgcn_exp2f(st[i]);  // P
+                    dp[i] = st[i] * dp[i];                   // dS
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
