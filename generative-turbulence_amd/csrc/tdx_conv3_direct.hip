@@ -838,9 +838,7 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
         if (dtype != TDX_BF16) return TDX_EDTYPE;
         if (!conv3_wgrad_mfma_supported(C1, C2, Cout)) return TDX_ESHAPE;
         float* slabs = dbw + ((Cout + 63) / 64) * 64;
-        // TDX_WGRAD_MANY_SLABS=0 (A/B switch, read per call): at most 8 slabs, more K splits merge by fp32 atomics (round 3)
-        const char* ms = getenv("TDX_WGRAD_MANY_SLABS");
-        const int cap = (ms && atoi(ms) == 0) ? W3_MAX_SLABS : w3_slab_capacity(Cin, Cout);
+        const int cap = w3_slab_capacity(Cin, Cout);
         int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs, cap, &nslab);
         slab_ptr = slabs;
         if (rc != TDX_OK) return rc;

@@ -259,10 +259,9 @@ int conv3_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const 
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
     static const bool no_thin = getenv("TDX_CONV3_THIN") && atoi(getenv("TDX_CONV3_THIN")) == 0;  // A/B switch
     const int NT = (Cout % 64 == 0) ? 2 : 1;
-    // (8 x 8 x 8 bricks with four M tiles per wave, which pay in the split kernel, are 25-35 % SLOWER here: this
-    // kernel is MFMA-bound with two workgroups per CU already; opt-in with TDX_CONV3_BIG=1 for A/B runs)
-    static const bool want_big = getenv("TDX_CONV3_BIG") && atoi(getenv("TDX_CONV3_BIG")) == 1;
-    const bool big = NT == 1 && want_big && (int64_t)g.B * ceil_div(g.Xo, 8) * ceil_div(g.Yo, 8) * ceil_div(g.Zo, 8) >= 1024;
+    // (8 x 8 x 8 bricks with four M tiles per wave, which pay in the split kernel, measured 25-35 % SLOWER here: this
+    // kernel is MFMA-bound with two workgroups per CU already)
+    const bool big = false;
     BrickRegions main, thin;
     brick_plan(g, zero_pad, !no_thin, main, thin, big ? BRICK_BIG : BRICK_MAIN);
 #define F3_GO(NTV, ZP, TH, PM, REG)                                                                                     \

@@ -45,8 +45,7 @@ int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, cons
     static const bool no_thin = getenv("TDX_CONV3_THIN") && atoi(getenv("TDX_CONV3_THIN")) == 0;  // A/B switch
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     // 32-wide output tiles: 8 x 8 x 8 bricks (four M tiles per wave) where the grid is large enough to fill the chip
-    static const bool no_big = getenv("TDX_CONV3_BIG") && atoi(getenv("TDX_CONV3_BIG")) == 0;  // A/B switch
-    const bool big = NT == 1 && !no_big && (int64_t)g.B * ceil_div(g.Xo, 8) * ceil_div(g.Yo, 8) * ceil_div(g.Zo, 8) >= 1024;
+    const bool big = NT == 1 && (int64_t)g.B * ceil_div(g.Xo, 8) * ceil_div(g.Yo, 8) * ceil_div(g.Zo, 8) >= 1024;
     BrickRegions main, thin;
     brick_plan(g, zero_pad, !no_thin, main, thin, big ? BRICK_BIG : BRICK_MAIN);
     const int64_t lo_offset = (int64_t)27 * (C1 + C2) * Cout;  // elements between the hi and the lo weight image

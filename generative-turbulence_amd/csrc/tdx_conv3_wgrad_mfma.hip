@@ -378,8 +378,7 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
 #endif
     dim3 grid((unsigned)(ntiles * nsplit));
     // slab mode: every (tile, split) pair stores its whole partial tile, so the slabs need no zeroing
-    static const int slab_cap = getenv("TDX_WGRAD_SLABS") ? atoi(getenv("TDX_WGRAD_SLABS")) : 1 << 30;  // A/B switch
-    const bool use_slabs = slabs != nullptr && nsplit <= max_slabs && nsplit <= slab_cap;
+    const bool use_slabs = slabs != nullptr && nsplit <= max_slabs;
     const int64_t slab_stride = use_slabs ? (int64_t)27 * Cin * Cout : 0;
     float* out = use_slabs ? slabs : dwp;
     if (nslab_out) *nslab_out = use_slabs ? nsplit : 0;

@@ -412,13 +412,11 @@ extern "C" int tdx_resize_fwd(const void* x, void* y, int B, int Xi, int Yi, int
                               int dtype, void* stream) {
     TDX_CHECK_ARG(x && y && resize_args_ok(B, Xi, Yi, Zi, Xo, Yo, Zo, C));
     if (C % 8 || C / 8 > 256) return TDX_ESHAPE;
-    static const bool fine_tiles = !(getenv("TDX_RESIZE_FWD_TILES") && atoi(getenv("TDX_RESIZE_FWD_TILES")) == 0);  // A/B switch
-    const TileGrid tg = make_tiles(Xo, Yo, Zo, C, fine_tiles ? B : 0);
+    const TileGrid tg = make_tiles(Xo, Yo, Zo, C, B);
     const int64_t blocks = (int64_t)B * tg.nx * tg.ny * tg.nz;
-    static const bool no_pairs = getenv("TDX_RESIZE_PAIRS") && atoi(getenv("TDX_RESIZE_PAIRS")) == 0;  // A/B switch
     const AxisMap mx = make_axis(Xi, Xo), my = make_axis(Yi, Yo), mz = make_axis(Zi, Zo);
     // measured (tools/micro/resize_bench.py, B = 8): 64 channels 281 -> 256 us, 128 channels 65 -> 69 us: narrow rows only
-    if (!no_pairs && C <= 64 && !((tg.tx | tg.ty | tg.tz) & 1) && Xo > Xi && Yo > Yi && Zo > Zi && pair_window_ok(mx) &&
+    if (C <= 64 && !((tg.tx | tg.ty | tg.tz) & 1) && Xo > Xi && Yo > Yi && Zo > Zi && pair_window_ok(mx) &&
         pair_window_ok(my) && pair_window_ok(mz)) {
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_up_pairs_kernel<T>), dim3((unsigned)blocks), dim3(256), 0,
                                                       as_stream(stream), (const T*)x, (T*)y, mx, my, mz, C, tg));
@@ -453,8 +451,7 @@ extern "C" int tdx_resize_bwd(const void* dy, const void* add, void* dx, int B, 
                                                       as_stream(stream), (const T*)dy, (const T*)add, (T*)dx, ax, ay, az, C, total));
         return tdx_launch_status();
     }
-    static const bool fine_tiles = !(getenv("TDX_RESIZE_BWD_TILES") && atoi(getenv("TDX_RESIZE_BWD_TILES")) == 0);  // A/B switch
-    const TileGrid tg = make_tiles(Xi, Yi, Zi, C, fine_tiles ? B : 0);
+    const TileGrid tg = make_tiles(Xi, Yi, Zi, C, B);
     const dim3 grid((unsigned)((int64_t)B * tg.nx * tg.ny * tg.nz));
 #define RS_BWD(KV)                                                                                                     \
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_bwd_kernel<T, KV>), grid, dim3(256), 0, as_stream(stream),     \

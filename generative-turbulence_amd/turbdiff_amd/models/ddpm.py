@@ -74,18 +74,19 @@ class SinusoidalPosEmb(nn.Module):
 
 
 # one autograd node per ResnetBlock (hand-written backward) instead of one per operator;
-# TDX_FUSE_BLOCKS=0 selects the per-operator composition (same kernels, used as a cross-check)
-import os as _os
+# FUSE_BLOCKS = False selects the per-operator composition (same kernels, used as a cross-check by the tests)
 
-FUSE_BLOCKS = _os.environ.get("TDX_FUSE_BLOCKS", "1") != "0"
-# TDX_COMPOSE_FIRST_CONV=0: the first U-Net conv runs on the 64 encoded channels as written in the reference
-COMPOSE_FIRST_CONV = _os.environ.get("TDX_COMPOSE_FIRST_CONV", "1") != "0"
-# TDX_DEFER_ENCODE=0: the encoder output is written by tdx_encode_fwd and read back by the first block's skip (A/B switch)
-DEFER_ENCODE = _os.environ.get("TDX_DEFER_ENCODE", "1") != "0"
-# TDX_FUSE_DECODE=0: inference writes the last block's output and runs tdx_decode_fwd on it, as training does (A/B switch)
-FUSE_DECODE = _os.environ.get("TDX_FUSE_DECODE", "1") != "0"
-# TDX_CACHE_COND_CONV=0: sampling recomputes the conditioning half of the first conv every step (A/B switch)
-CACHE_COND_CONV = _os.environ.get("TDX_CACHE_COND_CONV", "1") != "0"
+FUSE_BLOCKS = True
+# Module constants, not environment switches (they were, while each route was being compared with its alternative;
+# tests flip them through monkeypatch):
+# COMPOSE_FIRST_CONV = False: the first U-Net conv runs on the 64 encoded channels as written in the reference
+COMPOSE_FIRST_CONV = True
+# DEFER_ENCODE = False: the encoder output is written by tdx_encode_fwd and read back by the first block's skip
+DEFER_ENCODE = True
+# FUSE_DECODE = False: inference writes the last block's output and runs tdx_decode_fwd on it, as training does
+FUSE_DECODE = True
+# CACHE_COND_CONV = False: sampling recomputes the conditioning half of the first conv every step
+CACHE_COND_CONV = True
 
 
 def _norm_groups(norm: nn.GroupNorm) -> int:
@@ -146,10 +147,7 @@ class ResnetBlock(nn.Module):
         films = {id(block): (2, B, dim_out) scale | shift}: the projections of all blocks computed up front in one
         launch (DenoisingModel.film_table); without it the block projects `c` itself."""
         film = films.get(id(self)) if films is not None else None
-        if film is None and os.environ.get("TDX_FILM", "1") == "0":  # A/B switch: the per-block torch ops
-            f = self.project_onto_scale_shift(c)
-            film = torch.stack((f[:, : self.dim_out], f[:, self.dim_out :]))
-        elif film is None:
+        if film is None:
             film = ops.film_projections(c, [self.project_onto_scale_shift])[0]  # (2, B, dim_out): scale, shift
         scale, shift = film[0], film[1]
         identity = isinstance(self.conv, nn.Identity)
@@ -386,8 +384,6 @@ class DenoisingModel(nn.Module):
     def film_table(self, c):
         """{id(block): (2, B, dim_out) [scale, shift]} for every ResnetBlock, projected from the conditioning vector
         in one launch (the reference projects inside each block, ddpm.py:191-192)."""
-        if os.environ.get("TDX_FILM", "1") == "0":
-            return None
         blocks = self._static_lists()[2]
         films = ops.film_projections(c, [b.project_onto_scale_shift for b in blocks])
         return {id(b): f for b, f in zip(blocks, films)}

@@ -329,8 +329,6 @@ def prefetch_weights(conv3_weights, conv1_weights, dtype: torch.dtype, plan: "Pa
     stale, and a model forward would otherwise start with ~30 tiny launches.  Returns the PackPlan to pass back in next
     time (it is rebuilt when the parameter tensors or the operand format changed); the later _packed_conv3 / _conv1_wt
     calls hit the cache."""
-    if os.environ.get("TDX_PREFETCH", "1") == "0":  # A/B switch: every layer packs on first use
-        return None
     if plan is None or not plan.valid_for(conv3_weights, conv1_weights, dtype):
         plan = PackPlan(conv3_weights, conv1_weights, dtype)
     plan.refresh()
@@ -850,9 +848,9 @@ def film_projections(c: torch.Tensor, linears) -> list:
 _SIDE = {}  # device index -> side stream of the weight gradients
 
 
-# TDX_FUSE_SKIP_TAIL=0: the projected skip of a fused ResnetBlock as two launches (1x1 conv into a temporary, then the
-# GroupNorm / SiLU / add pass) instead of tdx_conv1_fwd_gn's one (A/B switch, read at import)
-FUSE_SKIP_TAIL = os.environ.get("TDX_FUSE_SKIP_TAIL", "1") != "0"
+# the projected skip of a fused ResnetBlock runs as tdx_conv1_fwd_gn's ONE launch; False: two (1x1 conv into a temporary,
+# then the GroupNorm / SiLU / add pass) -- a module constant for tests, not an environment switch any more
+FUSE_SKIP_TAIL = True
 WGRAD_STREAM = os.environ.get("TDX_WGRAD_STREAM", "1") != "0"  # read once (bench.py / tests set it before the import)
 
 

@@ -14,18 +14,17 @@ not depend on how trajectories are sharded over GPUs.
 
 from __future__ import annotations
 
-import os
 
 import torch
 
 from . import _lib as L
 from . import ops
 
-# TDX_FUSED_STEP_NOISE=0: draw z / z2 into tensors with tdx_randn_batched and run tdx_p_sample_step on them (the same
-# values; the A/B switch for the in-kernel draw)
-FUSED_STEP_NOISE = os.environ.get("TDX_FUSED_STEP_NOISE", "1") != "0"
-# TDX_COND_TABLE=0: the time MLP runs every reverse step instead of one look-up in a per-timestep table (A/B switch)
-COND_TABLE = os.environ.get("TDX_COND_TABLE", "1") != "0"
+# module constants (tests flip them; they were environment A/B switches while the two routes were being compared):
+# FUSED_STEP_NOISE = False: draw z / z2 into tensors with tdx_randn_batched and run tdx_p_sample_step on them (same values);
+# COND_TABLE = False: the time MLP runs every reverse step instead of one look-up in a per-timestep table
+FUSED_STEP_NOISE = True
+COND_TABLE = True
 
 
 class GraphSampler:

@@ -707,7 +707,7 @@ def test_graph_sampler_on_a_grid_whose_planes_are_not_multiples_of_four():
 
 
 def test_sampler_refreshes_its_cached_conditioning_conv_after_a_weight_update(monkeypatch):
-    """With the first conv NOT composed with the encoders (TDX_COMPOSE_FIRST_CONV=0) the sampler keeps
+    """With the first conv NOT composed with the encoders (models.ddpm.COMPOSE_FIRST_CONV = False) the sampler keeps
     encode_local(C) and the conditioning half of the first conv (first_conv_partial): both are functions of the weights
     and must follow a weight update, into the same tensors (the captured graph reads those addresses)."""
     from turbdiff_amd.models import ddpm as D
@@ -778,7 +778,7 @@ def test_conditioning_table_row_equals_the_time_mlp(golden):
 
 
 def test_unfused_block_composition_matches_golden(golden, monkeypatch):
-    """TDX_FUSE_BLOCKS=0 path (one autograd node per operator) -- same kernels, cross-check of the
+    """models.ddpm.FUSE_BLOCKS = False path (one autograd node per operator) -- same kernels, cross-check of the
     hand-written ResnetBlock backward used by default."""
     import turbdiff_amd.models.ddpm as D
 
@@ -978,7 +978,7 @@ def test_cached_conditioning_conv_matches_plain_forward():
 def test_deferred_encoder_output_is_bit_identical(dtype, monkeypatch):
     """The encoder output feeds only the first block's identity skip once the first conv is composed with the encoders;
     it is then evaluated inside that block's tail kernel (tdx_gn_apply_encoded, ops.encode_deferred) instead of being
-    written and read back.  Same output and same parameter gradients, bit for bit, as with TDX_DEFER_ENCODE=0 -- in the
+    written and read back.  Same output and same parameter gradients, bit for bit, as with models.ddpm.DEFER_ENCODE = False -- in the
     forward (no-grad: what sampling runs) and through the backward (the stand-in tensor carries the skip's gradient to
     the encoders)."""
     from turbdiff_amd import ops as ops_mod
@@ -1023,7 +1023,7 @@ def test_deferred_encoder_output_is_bit_identical(dtype, monkeypatch):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_inference_decodes_inside_the_last_block_bit_identically(dtype, monkeypatch):
     """Without autograd the last ResnetBlock's tail kernel applies the 1x1 decoder itself (tdx_gn_apply_decode): same
-    output, bit for bit, as with TDX_FUSE_DECODE=0; with autograd on, the block output is kept (the decoder's weight
+    output, bit for bit, as with models.ddpm.FUSE_DECODE = False; with autograd on, the block output is kept (the decoder's weight
     gradient needs it) and the fused route is not taken."""
     from turbdiff_amd import _lib as L
     from turbdiff_amd.models import ddpm as D
