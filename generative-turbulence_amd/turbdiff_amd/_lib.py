@@ -173,7 +173,7 @@ def ensure_scratch(device=None) -> None:
         _SCRATCH = OrderedDict()
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
-    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    key = (idx, stream(idx))
     if _ACTIVE == key:
         return
     if SCRATCH_BYTES <= 0:
@@ -275,8 +275,15 @@ def ptr(t: torch.Tensor | None):
     return t.data_ptr()
 
 
-def stream():
-    return torch.cuda.current_stream().cuda_stream
+# the launching stream's handle, ~700 times per training step: torch.cuda.current_stream() builds a Python Stream object
+# per call (2.65 us measured), the raw query returns the same handle in a tenth of that
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def stream(device_index=None):
+    if _raw_stream is None:
+        return torch.cuda.current_stream(device_index).cuda_stream
+    return _raw_stream(torch.cuda.current_device() if device_index is None else device_index)
 
 
 _ERR = {-1: "TDX_EINVAL (bad argument)", -2: "TDX_ESHAPE (unsupported shape)", -3: "TDX_EDTYPE (unsupported dtype)"}

@@ -42,7 +42,7 @@ def _clean_ws(nbytes: int, device, tag=None) -> torch.Tensor:
     # tag: buffers are shared only by calls with the same internal layout; and only by calls issued from the same
     # stream: two streams (two captured graphs, two threads) running the same layer concurrently must not meet in one
     # accumulator buffer
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, int(nbytes), tag)
+    key = (device, L.stream(device.index), int(nbytes), tag)
     buf = _CLEAN.get(key)
     if buf is None:
         buf = _CLEAN[key] = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=device)
