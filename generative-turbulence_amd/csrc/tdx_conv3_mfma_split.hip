@@ -10,14 +10,23 @@
 // model), i.e. inside the 1e-4 parity gate with room to spare.  It is opt-in (TDX_CONV_SPLIT): the default
 // fp32 mode keeps IEEE fp32 products.
 //
-// Structure: as the fp32 MFMA kernel -- a 4 x 8 x 8 brick of output voxels and BN = 32 NT output channels per
-// workgroup, the halo'd brick of a 16-channel slice and the slice's weights of all 27 taps in LDS -- with the
-// split done while staging: activations are loaded as fp32 and written to LDS as a hi and a lo image
-// (each two half-planes of 16-B entries = 8 bf16 channels, z stride padded 10 -> 12: conflict-free
-// ds_read_b128 with affine tap offsets, the layout of the bf16 kernel); weights arrive pre-split from
-// tdx_conv3_pack_weight_split ([2][K/16][27][N][16] bf16).  157 KB of LDS for NT = 2: one workgroup per CU,
-// one wave per SIMD, so the fragments of tap t+1 are read into a second register set while tap t issues
-// its 6 NT MFMAs, and the next slice's global loads are in flight during the whole MFMA phase.
+// Structure: a 4 x 8 x 8 brick of output voxels (8 x 8 x 8 for 32-wide tiles on large grids) and BN = 32 NT output channels
+// per workgroup; the halo'd brick of an 8-CHANNEL slice and the slice's weights of all taps in LDS, split while staging:
+// activations are loaded as fp32 and written as a hi and a lo image (16-B entries = 8 bf16 channels of a voxel, z stride
+// padded 10 -> 12); weights arrive pre-split from tdx_conv3_pack_weight_split ([2][K/16][27][N][16] bf16, read in 8-channel
+// halves).  An MFMA K step of 16 is 8 channels x 2 TAPS: lanes 0-31 of a fragment hold tap 2 j, lanes 32-63 tap 2 j + 1
+// (14 steps, the 28th tap meets zero weight rows), the arrangement of tdx_conv3_ring.hip.  That halves the LDS image against
+// the round-4 form (16-channel slices, 157 KB): 80.6 KB for NT = 2, so TWO workgroups share a CU and one's staging, barriers
+// and epilogue run beside the other's MFMAs; <= 256 registers per lane (236; the per-piece source offsets are rebuilt from a
+// lane constant + uniform terms every slice instead of being kept).  The fragments of step j + 1 are read into a second
+// register set while step j issues its 6 NT MFMAs, and the next slice's global loads are in flight during the MFMA phase.
+//
+// Where its time goes (profiles/r12_split_staging_ablation.txt; 128 -> 128 channels at 96 x 32 x 24 x 6): the matrix pipe is
+// busy 64 % of the cycles at 1.61 GHz (round 4's form: 51 % at 1.77; the chip lowers the clock as the pipe fills: with
+// staging and epilogue removed, 90 % at 1.56 GHz is the ceiling).  What is left is the global LOADS of the staging, not its
+// LDS stores or the split arithmetic: dropping the loads of the activations gains 8 % (32-wide tiles on 8 x 8 x 8 bricks:
+// 18 %), those of the weights 15 % (11 %); dropping only the stores, nothing.  An 8-channel slice uses 32 B of every
+// 128-B line of an NDHWC fp32 tensor, and every workgroup re-reads the slice's 57 KB of weights from L2.
 #include "tdx_conv3_mfma_split_kernel.h"
 
 bool conv3_mfma_split_supported(int C1, int C2, int Cout) {

@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define SP_KC 16
 
 
+
 template <int BN>
 __device__ __forceinline__ int outs_addr(int v, int c) {
     return v * (BN * 4) + ((c ^ (v & (BN / 4 - 1))) << 4);
@@ -33,8 +34,33 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// LDS image of one 8-channel slice: activations [part = hi, lo][halo voxel, z stride 12][8 ch] (16-B entries), weights
+// [part][tap pair j = 0..13][n][tap 2 j, 2 j + 1][8 ch]: an MFMA K step of 16 = 8 channels x 2 taps, lanes 0-31 hold tap 2 j
+// and lanes 32-63 tap 2 j + 1 of both operands (tap 27 = zero weight rows).
+template <int SHAPE, int BN> struct SplitLds {
+    static constexpr int APLANE = Brick<SHAPE>::ENTRIES * 16 + 64;
+    static constexpr int BPLANE = 28 * BN * 16 + 64;
+    static constexpr int STAGE = 2 * APLANE + 2 * BPLANE;
+    static constexpr int OUT = Brick<SHAPE>::NVOX * BN * 4 + (256 / (BN / 4)) * BN * 8;  // output tile + moment partials
+    static constexpr int BYTES = STAGE > OUT ? STAGE : OUT;
+};
+
+// 4 fp32 -> 4 bf16 hi and 4 bf16 lo
+__device__ __forceinline__ void split4(const float4& a, uint2& hi, uint2& lo) {
+    const float v[4] = {a.x, a.y, a.z, a.w};
+    unsigned h[2], l[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        h[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+        const float r0 = v[2 * i] - __uint_as_float(h[i] << 16), r1 = v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u);
+        l[i] = pack_bf16x2(r0, r1);
+    }
+    hi = make_uint2(h[0], h[1]);
+    lo = make_uint2(l[0], l[1]);
+}
+
 template <int NT, bool ZERO_PAD, int SHAPE, bool PERM>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(256, 2)
 conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2,
                         const bf16* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, BrickRegions R,
                         int Cout, int64_t lo_offset, double* __restrict__ gn_acc, float* __restrict__ d1, int D1,
@@ -44,12 +70,11 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     constexpr int BN = NT * 32;
     constexpr int HY = BR::HY, HZ = BR::HZ, SZ = BR::SZ;
     constexpr int NHALO = BR::NHALO;
-    constexpr int APLANE = BR::ENTRIES * 16 + 64;   // one half-plane of one part
-    constexpr int A_BYTES = 4 * APLANE;             // [part][half]
-    constexpr int B_PLANE = 27 * BN * 16 + 64;
+    constexpr int APLANE = SplitLds<SHAPE, BN>::APLANE;
+    constexpr int B_PLANE = SplitLds<SHAPE, BN>::BPLANE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sA = smem;
-    unsigned char* sB = smem + A_BYTES;
+    unsigned char* sB = smem + 2 * APLANE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -60,76 +85,86 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     const int n0 = blockIdx.y * BN;
     const int Cin = C1 + C2;
 
-    // ---- staging plan of the halo brick: pieces (voxel, half) of 8 fp32 channels
+    // ---- staging plan of the halo brick: one piece = 4 of the 8 fp32 channels of a halo voxel; a lane pair covers the voxel's
+    // 32 B, so one load instruction touches 32 cache lines, not 64 (the vector-memory path, not the LDS stores, is what this
+    // staging costs: profiles/r12_split_staging_ablation.txt)
     constexpr int A_PIECES = NHALO * 2;
     constexpr int A_PER_THREAD = (A_PIECES + 255) / 256;
-    int a_src[A_PER_THREAD], a_dst[A_PER_THREAD];
+    int a_src[A_PER_THREAD], a_dst[A_PER_THREAD];  // source byte offset / (4 Cs) * 4 + 16 q, LDS byte
 #pragma unroll
     for (int i = 0; i < A_PER_THREAD; ++i) {
         const int p = tid + i * 256;
         a_dst[i] = -1;
         a_src[i] = -1;
         if (p < A_PIECES) {
-            const int hv = p >> 1, half = p & 1;
+            const int hv = p >> 1, q = p & 1;
             const int hx = hv / (HY * HZ), rem = hv - hx * (HY * HZ);
             const int hy = rem / HZ, hz = rem - hy * HZ;
-            a_dst[i] = half * APLANE + ((hx * HY + hy) * SZ + hz) * 16;
+            a_dst[i] = ((hx * HY + hy) * SZ + hz) * 16 + q * 8;
             const int src = brick_halo_source<ZERO_PAD, PERM>(g, o, hx, hy, hz);
-            if (src >= 0) a_src[i] = src * 2 + half;
+            if (src >= 0) a_src[i] = src * 2 + q;
         }
     }
     const int64_t batch_vox = (int64_t)b * g.Ei[0] * g.Ei[1] * g.Ei[2];
 
-    // ---- weight staging: pieces (part, row = tap * BN + n, half) of 16 B; packed [part][K/16][27][Cout][16]
-    constexpr int B_ROWS = 27 * BN;
-    constexpr int B_PIECES = B_ROWS * 4;
-    constexpr int B_PER_THREAD = (B_PIECES + 255) / 256;
+    // ---- weight staging: piece p = tid + 256 i -> (m = p / (2 BN): part m & 1, tap pair m >> 1; n = (p % (2 BN)) >> 1;
+    // tap parity p & 1), 16 B = 8 channels; source = the packed [part][K/16][27][Cout][16] images, read in halves.
+    // tid / (2 BN) is wave-uniform and i moves m by an even step: the part and the thread's byte offset are fixed, the tap pair
+    // of piece i is uniform -- addresses are (uniform base) + (32-bit lane offset), nothing is kept per piece.
+    constexpr int B_PIECES = 56 * BN;
+    constexpr int B_PER_THREAD = B_PIECES / 256;
+    constexpr int B_MSTEP = 256 / (2 * BN);
+    static_assert(B_PIECES % 256 == 0 && B_MSTEP % 2 == 0, "weight pieces per thread");
+    const int b_m0 = __builtin_amdgcn_readfirstlane(tid / (2 * BN));
+    const int b_par = tid & 1;
+    const unsigned b_lane = (unsigned)((((b_m0 & 1) * lo_offset) + (int64_t)(n0 + ((tid % (2 * BN)) >> 1)) * SP_KC) * 2);
+    const unsigned b_dst = (b_m0 & 1) * B_PLANE + ((b_m0 >> 1) * 2 * BN + (tid % (2 * BN))) * 16;
 
-    float4 areg[A_PER_THREAD][2];
+    float4 areg[A_PER_THREAD];
     uint4 breg[B_PER_THREAD];
-    auto load_slice = [&](int c) {
-        const int k0 = c * SP_KC;
+    auto load_slice = [&](int s) {
+        const int k0 = s * 8;
         const float* xs;
         int Cs, kk;
         if (k0 < C1) { xs = x1; Cs = C1; kk = k0; } else { xs = x2; Cs = C2; kk = k0 - C1; }
-        xs += batch_vox * Cs + kk;
+        const char* xb = reinterpret_cast<const char*>(xs + batch_vox * Cs + kk);
 #pragma unroll
         for (int i = 0; i < A_PER_THREAD; ++i) {
-            areg[i][0] = areg[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a_src[i] >= 0) {
-                const float4* src = reinterpret_cast<const float4*>(xs + (int64_t)(a_src[i] >> 1) * Cs + (a_src[i] & 1) * 8);
-                areg[i][0] = src[0];
-                areg[i][1] = src[1];
-            }
+            areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_src[i] >= 0)
+                areg[i] = *reinterpret_cast<const float4*>(xb + (size_t)((unsigned)(a_src[i] >> 1) * (unsigned)Cs * 4u + (a_src[i] & 1) * 16u));
         }
-        const bf16* wc = wp + (int64_t)c * 27 * Cout * SP_KC;
+        const char* wc = reinterpret_cast<const char*>(wp + (int64_t)(s >> 1) * 27 * Cout * SP_KC + (s & 1) * 8);
 #pragma unroll
         for (int i = 0; i < B_PER_THREAD; ++i) {
-            const int p = tid + i * 256;
-            breg[i] = make_uint4(0, 0, 0, 0);
-            if (p < B_PIECES) {
-                const int half = p & 1, row = (p >> 1) % B_ROWS, part = (p >> 1) / B_ROWS;
-                const int tap = row / BN, n = row - tap * BN;
-                breg[i] = *reinterpret_cast<const uint4*>(wc + part * lo_offset + ((int64_t)tap * Cout + n0 + n) * SP_KC + half * 8);
-            }
+            const int tap0 = 2 * ((b_m0 >> 1) + i * (B_MSTEP / 2));  // uniform
+            const int t1 = tap0 + 1 < 27 ? tap0 + 1 : 26;
+            const int g0 = PERM ? brick_tap(g, tap0 / 9 - 1, (tap0 / 3) % 3 - 1, tap0 % 3 - 1) : tap0;
+            const int g1 = PERM ? brick_tap(g, t1 / 9 - 1, (t1 / 3) % 3 - 1, t1 % 3 - 1) : t1;
+            const unsigned off = b_lane + (unsigned)((b_par ? g1 : g0) * Cout * (SP_KC * 2));
+            breg[i] = *reinterpret_cast<const uint4*>(wc + (size_t)off);  // tap 27 reads tap 26's row; zeroed when stored
         }
     };
     auto store_slice = [&]() {
 #pragma unroll
         for (int i = 0; i < A_PER_THREAD; ++i)
             if (a_dst[i] >= 0) {
-                uint4 hi, lo;
-                split8(areg[i][0], areg[i][1], hi, lo);
-                *reinterpret_cast<uint4*>(sA + a_dst[i]) = hi;
-                *reinterpret_cast<uint4*>(sA + 2 * APLANE + a_dst[i]) = lo;
+                uint2 hi, lo;
+                split4(areg[i], hi, lo);
+                *reinterpret_cast<uint2*>(sA + a_dst[i]) = hi;
+                *reinterpret_cast<uint2*>(sA + APLANE + a_dst[i]) = lo;
             }
 #pragma unroll
-        for (int i = 0; i < B_PER_THREAD; ++i) {
-            const int p = tid + i * 256;
-            if (p < B_PIECES) {
-                const int half = p & 1, row = (p >> 1) % B_ROWS, part = (p >> 1) / B_ROWS;
-                *reinterpret_cast<uint4*>(sB + (part * 2 + half) * B_PLANE + row * 16) = breg[i];
+        for (int i = 0; i < B_PER_THREAD; ++i)
+        {
+            // (zeroing the register right behind its load would make the compiler wait for every load in turn)
+            // only a thread's last piece can be the 28th tap (pair 13, odd lane)
+            uint4 v = breg[i];
+            if (i == B_PER_THREAD - 1) {
+                const unsigned keep = (2 * ((b_m0 >> 1) + i * (B_MSTEP / 2)) + 1 >= 27 && b_par) ? 0u : 0xffffffffu;
+                v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
             }
+            *reinterpret_cast<uint4*>(sB + b_dst + i * (B_MSTEP / 2) * (2 * BN * 16)) = v;
         }
     };
 
@@ -139,12 +174,9 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     for (int mt = 0; mt < MT; ++mt) {
         int lx, ly, lz;
         BR::lane_voxel(wave, mt, r, lx, ly, lz);
-        a_h[mt] = hh * APLANE + (((lx + 1) * HY + (ly + 1)) * SZ + (lz + 1)) * 16;
+        a_h[mt] = (((lx + 1) * HY + (ly + 1)) * SZ + (lz + 1)) * 16;
     }
-    int tap_row[27];  // weight-image row of every local tap (uniform; immediates when the axes are not permuted)
-#pragma unroll
-    for (int t = 0; t < 27; ++t) tap_row[t] = (PERM ? brick_tap(g, t / 9 - 1, (t / 3) % 3 - 1, t % 3 - 1) : t) * (BN * 16);
-    const int b_off = hh * B_PLANE + r * 16;
+    const int b_off = r * 32 + hh * 16;
 
     f32x16 acc[NT][MT];
 #pragma unroll
@@ -155,23 +187,26 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
             for (int i = 0; i < 16; ++i) acc[nt][mt][i] = 0.f;
 
     struct Frags { bf16x8 xh[MT], xl[MT], wh[NT], wl[NT]; };
-    auto read_frags = [&](int tap, Frags& f) {
-        const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
-        const int toff = ((ex * HY + ey) * SZ + ez) * 16;
+    // K step j: taps 2 j (lanes 0-31) and 2 j + 1 (lanes 32-63; the 28th tap reads tap 26's voxel against zero weights)
+    auto tap_off = [&](int tap) {
+        const int t = tap < 27 ? tap : 26;
+        return (((t / 9 - 1) * HY + ((t / 3) % 3 - 1)) * SZ + (t % 3 - 1)) * 16;
+    };
+    auto read_frags = [&](int j, Frags& f) {
+        const int toff = hh ? tap_off(2 * j + 1) : tap_off(2 * j);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             f.xh[mt] = *reinterpret_cast<const bf16x8*>(sA + a_h[mt] + toff);
-            f.xl[mt] = *reinterpret_cast<const bf16x8*>(sA + 2 * APLANE + a_h[mt] + toff);
+            f.xl[mt] = *reinterpret_cast<const bf16x8*>(sA + APLANE + a_h[mt] + toff);
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            f.wh[nt] = *reinterpret_cast<const bf16x8*>(sB + b_off + tap_row[tap] + nt * 512);
-            f.wl[nt] = *reinterpret_cast<const bf16x8*>(sB + 2 * B_PLANE + b_off + tap_row[tap] + nt * 512);
+            f.wh[nt] = *reinterpret_cast<const bf16x8*>(sB + b_off + j * (2 * BN * 16) + nt * 1024);
+            f.wl[nt] = *reinterpret_cast<const bf16x8*>(sB + B_PLANE + b_off + j * (2 * BN * 16) + nt * 1024);
         }
     };
-    // term-major order: with one wave per SIMD nothing hides the ~12-cycle stall of an MFMA that accumulates
-    // onto the result of the MFMA right before it (tools/micro/mfma_peak: 1785 vs 2437 TFLOP/s), so consecutive
-    // MFMAs go to different accumulators (2 NT apart)
+    // term-major order: consecutive MFMAs go to different accumulators (tools/micro/mfma_peak: back-to-back MFMAs onto one
+    // accumulator stall ~12 cycles each)
     auto mfmas = [&](const Frags& f) {
 #pragma unroll
         for (int term = 0; term < 3; ++term)
@@ -183,27 +218,25 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
                                                                          term == 1 ? f.xl[mt] : f.xh[mt], acc[nt][mt], 0, 0, 0);
     };
 
-    const int nchunks = Cin / SP_KC;
+    const int nslices = Cin / 8;
     load_slice(0);
-    for (int c = 0; c < nchunks; ++c) {
+    for (int s = 0; s < nslices; ++s) {
         __syncthreads();
         store_slice();
         __syncthreads();
-        if (c + 1 < nchunks) load_slice(c + 1);
+        if (s + 1 < nslices) load_slice(s + 1);
         Frags f0, f1;
         read_frags(0, f0);
 #pragma unroll
-        for (int tap = 0; tap < 27; tap += 2) {
-            if (tap + 1 < 27) read_frags(tap + 1, f1);
+        for (int j = 0; j < 14; j += 2) {
+            read_frags(j + 1, f1);
             mfmas(f0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 2 * NT, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NT, 0);
-            if (tap + 1 < 27) {
-                if (tap + 2 < 27) read_frags(tap + 2, f0);
-                mfmas(f1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 2 * NT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NT, 0);
-            }
+            if (j + 2 < 14) read_frags(j + 2, f0);
+            mfmas(f1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT + 2 * NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NT, 0);
         }
     }
 
@@ -296,7 +329,7 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
 template <int NTV, bool ZP, int TH, bool PM>
 static int split_go(SPLIT_GO_ARGS) {
     constexpr int BNV = NTV * 32;
-    const size_t lds = (size_t)4 * (Brick<TH>::ENTRIES * 16 + 64) + (size_t)4 * (27 * BNV * 16 + 64);
+    const size_t lds = SplitLds<TH, BNV>::BYTES;
     auto kern = conv3_mfma_split_kernel<NTV, ZP, TH, PM>;
     static bool attr_set = false;
     if (!attr_set) {
