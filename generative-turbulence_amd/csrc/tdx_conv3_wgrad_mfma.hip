@@ -339,7 +339,7 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
         int rs = conv3_wgrad_small_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st, slabs, max_slabs, nslab_out);
         if (rs != TDX_ESHAPE) return rs;
 #ifndef W3_STAMPS
-        // fine levels, 64-wide tiles: the producer / consumer form (8 computing + 4 loader waves)
+        // fine levels: the producer / consumer form (8 computing + 4 loader waves)
         rs = conv3_wgrad_ring_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st, slabs, max_slabs, nslab_out);
         if (rs != TDX_ESHAPE) return rs;
 #endif

@@ -1,5 +1,6 @@
-// bf16 MFMA weight gradient of the replicate-padded 3x3x3 convolution for 64-wide output tiles, producer / consumer
-// form (gfx950): 8 computing waves + 4 loader waves per workgroup, one workgroup per CU.
+// bf16 MFMA weight gradient of the replicate-padded 3x3x3 convolution, producer / consumer form (gfx950): 8 computing
+// waves + 4 loader waves per workgroup, one workgroup per CU.  Output tiles 64 wide (NTN = 2; described below) or 32 wide
+// (NTN = 1, Cout % 64 != 0: the level-0 layers of the benchmark model).
 //
 //   dW[tap][ci][co] = sum_v x[clamp(v + tap)][ci] * dy[v][co]
 //
@@ -22,8 +23,14 @@
 //     all-ones x fragment with the dy fragment of N tile 0 / 1: every row of that tile is sum_v dy[v][co].
 //
 // Zero rows (dy rows of voxels outside a ragged brick; the missing channels of a half-filled last ci tile) are copied
-// from the zero block at the head of the scratch arena (tdx_set_scratch).  Cout % 64 == 0 only; everything else stays on
-// tdx_conv3_wgrad_mfma.hip.  Same per-workgroup sums in the same order as the brick kernel (K steps in brick order).
+// from the zero block at the head of the scratch arena (tdx_set_scratch).  Same per-workgroup sums in the same order as
+// the brick kernel (K steps in brick order).
+//
+// NTN = 1 (round 5): the 32 x 32 x 27-tap tile is 27 accumulator tiles, 4 / 4 / 4 / 3 / 3 / 3 / 3 / 3 taps per computing wave
+// (4 + 3 MFMAs per SIMD and K step), wave 7's spare slot sums the bias gradient; one dy plane per buffer.  Every x fragment
+// feeds ONE MFMA here, so a K step reads 10 fragments per wave for 3-4 MFMAs (LDS array ~70 % busy at full MFMA rate): it
+// gains less than the 64-wide form did: 32 -> 32 at 192 x 64 x 48 x 6: 0.255 -> 0.218 ms, 128 -> 32: 0.90 -> 0.82 ms,
+// training step -0.22 ms (TDX_WGRAD_RING=2 restores the brick kernel for these layers).
 #include "tdx_common.h"
 #include "tdx_conv3.h"
 #include <stdlib.h>
@@ -47,10 +54,12 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 #define WR_XBUF (WR_XPIECES * 1024)
 #define WR_XPW ((WR_XPIECES + 3) / 4)                  // 10 per loader wave
 #define WR_GPLANE (WR_NVOX * 64)                       // one 32-channel dy plane: 16 pieces
-#define WR_GBUF (2 * WR_GPLANE)
-#define WR_GPW 8                                       // dy pieces per loader wave
 #define WR_CW 8                                        // computing waves
-#define WR_SLOTS 7                                     // accumulator tiles per computing wave
+// NTN = N tiles of 32 output channels per workgroup (2: 64-wide, 1: 32-wide): dy planes per buffer, dy pieces per loader
+// wave, accumulator tiles per computing wave
+#define WR_GBUF(NTN) ((NTN) * WR_GPLANE)
+#define WR_GPW(NTN) (4 * (NTN))
+#define WR_SLOTS(NTN) ((NTN) == 2 ? 7 : 4)
 
 struct WgradRingView {
     int B;
@@ -82,20 +91,22 @@ __device__ __forceinline__ void wr_barrier() {
     asm volatile("" ::: "memory");
 }
 
+template <int NTN>
 __global__ void __launch_bounds__(768, 3)
 conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2, const bf16* __restrict__ dy,
                         float* __restrict__ dwp, float* __restrict__ dbias, WgradRingView gv, int Cout, int nsplit, int n_ci_tiles,
                         int64_t slab_stride, const void* __restrict__ zeros) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* sX = smem;                        // [2][WR_XBUF]
-    unsigned char* sG = smem + 2 * WR_XBUF;           // [2][WR_GBUF]
+    unsigned char* sG = smem + 2 * WR_XBUF;           // [2][WR_GBUF(NTN)]
+    constexpr int GBUF = WR_GBUF(NTN), GPW = WR_GPW(NTN), SLOTS = WR_SLOTS(NTN);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = C1 + C2;
     const int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
-    const int ci0 = (tile % n_ci_tiles) * 32, co0 = (tile / n_ci_tiles) * 64;
+    const int ci0 = (tile % n_ci_tiles) * 32, co0 = (tile / n_ci_tiles) * (32 * NTN);
     const int nbricks = gv.B * gv.nb[0] * gv.nb[1] * gv.nb[2];
 
     if (wave >= WR_CW) {
@@ -115,8 +126,8 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
             const int hy = rem / WR_HZ, hz = rem - hy * WR_HZ;
             xh[i] = hx | (hy << 8) | (hz << 16) | (q4 << 24) | ((cbase + q4 * 8 < Cs) ? (1 << 30) : 0);
         }
-        // dy piece j of this wave: gp = lw * 8 + j -> plane gp / 16, chunks e = (gp % 16) * 64 + lane = (voxel e >> 2, quarter e & 3)
-        const int g_plane = (lw * WR_GPW) / 16, g_p0 = (lw * WR_GPW) % 16;
+        // dy piece j of this wave: gp = lw * GPW + j -> plane gp / 16, chunks e = (gp % 16) * 64 + lane = (voxel e >> 2, quarter e & 3)
+        const int g_plane = (lw * GPW) / 16, g_p0 = (lw * GPW) % 16;
         const int g_e0 = g_p0 * 64 + lane;
         auto issue = [&](int brick, int buf) {
             int bb = brick;
@@ -133,13 +144,13 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                 wr_dma(src, lds0 + buf * WR_XBUF + min(lw * WR_XPW + i, WR_XPIECES - 1) * 1024);
             }
 #pragma unroll
-            for (int j = 0; j < WR_GPW; ++j) {
+            for (int j = 0; j < GPW; ++j) {
                 const int e = g_e0 + 64 * j, v = e >> 2, c4 = e & 3;
                 const int vx = bx * WR_BX + (v >> 6), vy = by * WR_BY + ((v >> 3) & 7), vz = bz * WR_BZ + (v & 7);
                 const bool ok = vx < gv.E[0] && vy < gv.E[1] && vz < gv.E[2];
                 const int64_t vox = (int64_t)bb * gv.batch + vx * gv.s[0] + vy * gv.s[1] + vz * gv.s[2];
                 const bf16* src = ok ? dy + vox * Cout + co0 + g_plane * 32 + c4 * 8 : reinterpret_cast<const bf16*>(zeros);
-                wr_dma(src, lds0 + 2 * WR_XBUF + buf * WR_GBUF + g_plane * WR_GPLANE + (g_p0 + j) * 1024);
+                wr_dma(src, lds0 + 2 * WR_XBUF + buf * GBUF + g_plane * WR_GPLANE + (g_p0 + j) * 1024);
             }
         };
         int brick = split, it = 0;
@@ -154,10 +165,13 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
     }
 
     // =============================================================== computing waves
-    // wave w owns the (tap, N tile) pairs T = first .. first + cnt - 1 (T = 2 tap + nt), spanning taps a .. a + 3
-    const int first = wave < 7 ? 7 * wave : 48, cnt = wave < 6 ? 7 : 6;
-    const int a0 = first >> 1;
-    const bool odd = (first & 1) != 0;  // slot 0 is N tile 1 of tap a; else slots (0, 1) are tap a
+    // NTN = 2: wave w owns the (tap, N tile) pairs T = first .. first + cnt - 1 (T = 2 tap + nt), spanning taps a .. a + 3.
+    // NTN = 1: T = tap; waves 0-2 own 4 taps, waves 3-7 own 3 (27 = 3 x 4 + 5 x 3), wave 7's fourth slot sums the bias
+    // gradient: 4 + 3 MFMAs per SIMD and K step whichever two computing waves share it.
+    const int first = NTN == 2 ? (wave < 7 ? 7 * wave : 48) : (wave < 3 ? 4 * wave : 12 + 3 * (wave - 3));
+    const int cnt = NTN == 2 ? (wave < 6 ? 7 : 6) : (wave < 3 ? 4 : 3);
+    const int a0 = NTN == 2 ? first >> 1 : first;
+    const bool odd = NTN == 2 && (first & 1) != 0;  // slot 0 is N tile 1 of tap a; else slots (0, 1) are tap a
 
     // fragment lane geometry (tdx_conv3_wgrad_mfma.hip): a K step is 16 voxels; lane group g of 16 lanes reads voxel rows
     // 8 kh + q and + 4, columns 16 (g & 1) + 4 p .. + 3
@@ -173,26 +187,28 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
     }
     const int b_row = (8 * kh + q) * 64 + col_off;
 
-    f32x16 acc[WR_SLOTS];
+    f32x16 acc[SLOTS];
 #pragma unroll
-    for (int i = 0; i < WR_SLOTS; ++i)
+    for (int i = 0; i < SLOTS; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    const bool bias_slot = cnt == 6;         // waves 6, 7: slot 6 multiplies ones with dy N tile (wave - 6)
+    // the bias gradient comes from a slot a wave does not need for a tap: it multiplies ones with a dy N tile
+    const bool bias_slot = NTN == 2 ? cnt == 6 : wave == 7;   // NTN = 2: waves 6, 7 (N tile wave - 6); NTN = 1: wave 7
     bf16x8 ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
-    // The brick loop, specialised at compile time on the parity of the wave's first pair (which slots share an x fragment).
-    // The K-step loop stays ROLLED, two steps per trip (dy fragment sets by step parity): fully unrolled, the scheduler
-    // hoists the fragment reads far ahead and spills hundreds of registers.
+    // The brick loop, specialised at compile time (NTN = 2: on the parity of the wave's first pair = which slots share an x
+    // fragment; NTN = 1: on whether the wave's fourth slot is in use).  The K-step loop stays ROLLED, two steps per trip (dy
+    // fragment sets by step parity): fully unrolled, the scheduler hoists the fragment reads far ahead and spills hundreds
+    // of registers.
     auto run = [&](auto odd_c) {
-        constexpr bool ODD = decltype(odd_c)::value;
+        constexpr bool ODD = decltype(odd_c)::value;  // NTN = 1: "the fourth slot is used"
         int it = 0;
         for (int brick = split; brick < nbricks; brick += nsplit, ++it) {
             wr_barrier();  // brick `it` is in LDS (the loaders waited for it), everybody is done with brick it - 1
             const unsigned char* bX = sX + (it & 1) * WR_XBUF;
-            const unsigned char* bG = sG + (it & 1) * WR_GBUF + b_row;
+            const unsigned char* bG = sG + (it & 1) * GBUF + b_row;
             auto step_off = [&](int s) { return ((s >> 2) * WR_HY + 2 * (s & 3)) * WR_HZ * 64; };
             auto read_a = [&](int s, int t) {
                 const unsigned char* ap = bX + a_off[t] + step_off(s);
@@ -202,53 +218,70 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                 const unsigned char* bp = bG + nt * WR_GPLANE + s * (16 * 64);
                 return wr_tr_frag(bp, bp + 4 * 64);
             };
-            bf16x8 A[4], Bq[2][2];
+            bf16x8 A[4], Bq[2][NTN];
 #pragma unroll
             for (int t = 0; t < 4; ++t) A[t] = read_a(0, t);
-            Bq[0][0] = read_b(0, 0); Bq[0][1] = read_b(0, 1);
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt) Bq[0][nt] = read_b(0, nt);
 
-            // one K step: 7 MFMAs; the x fragment of tap t for the next step is read right behind the last MFMA that uses
-            // the current one; the dy fragments of the next step go to the other parity set.  (Past the last step the
-            // "next" reads fetch step 15 again: valid LDS, never used.)
+            // one K step: the x fragment of tap t for the next step is read right behind the last MFMA that uses the
+            // current one; the dy fragments of the next step go to the other parity set.  (Past the last step the "next"
+            // reads fetch step 15 again: valid LDS, never used.)
             auto step = [&](int s, int cur) {
                 const int sn = min(s + 1, WR_NSTEPS - 1), nx = cur ^ 1;
-                Bq[nx][0] = read_b(sn, 0); Bq[nx][1] = read_b(sn, 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                // slot 6's operands: the wave's last pair, or the bias column sums (waves 6, 7)
-                const bf16x8 a6 = bias_slot ? ones : A[3];
-                const bf16x8 b6 = bias_slot ? (wave == 7 ? Bq[cur][1] : Bq[cur][0]) : (ODD ? Bq[cur][1] : Bq[cur][0]);
-                if (!ODD) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bq[cur][0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bq[cur][1], acc[1], 0, 0, 0);
-                    A[0] = read_a(sn, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][0], acc[2], 0, 0, 0);
-                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][1], acc[3], 0, 0, 0);
-                    A[1] = read_a(sn, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][0], acc[4], 0, 0, 0);
-                    acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][1], acc[5], 0, 0, 0);
-                    A[2] = read_a(sn, 2);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a6, b6, acc[6], 0, 0, 0);
-                    A[3] = read_a(sn, 3);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int nt = 0; nt < NTN; ++nt) Bq[nx][nt] = read_b(sn, nt);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * NTN, 0);
+                if constexpr (NTN == 2) {
+                    // slot 6's operands: the wave's last pair, or the bias column sums (waves 6, 7)
+                    const bf16x8 a6 = bias_slot ? ones : A[3];
+                    const bf16x8 b6 = bias_slot ? (wave == 7 ? Bq[cur][1] : Bq[cur][0]) : (ODD ? Bq[cur][1] : Bq[cur][0]);
+                    if (!ODD) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bq[cur][0], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bq[cur][1], acc[1], 0, 0, 0);
+                        A[0] = read_a(sn, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][0], acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][1], acc[3], 0, 0, 0);
+                        A[1] = read_a(sn, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][0], acc[4], 0, 0, 0);
+                        acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][1], acc[5], 0, 0, 0);
+                        A[2] = read_a(sn, 2);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a6, b6, acc[6], 0, 0, 0);
+                        A[3] = read_a(sn, 3);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    } else {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bq[cur][1], acc[0], 0, 0, 0);
+                        A[0] = read_a(sn, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][0], acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][1], acc[2], 0, 0, 0);
+                        A[1] = read_a(sn, 1);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][0], acc[3], 0, 0, 0);
+                        acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][1], acc[4], 0, 0, 0);
+                        A[2] = read_a(sn, 2);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[3], Bq[cur][0], acc[5], 0, 0, 0);
+                        acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a6, b6, acc[6], 0, 0, 0);
+                        A[3] = read_a(sn, 3);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
                 } else {
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bq[cur][1], acc[0], 0, 0, 0);
-                    A[0] = read_a(sn, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][0], acc[1], 0, 0, 0);
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][1], acc[2], 0, 0, 0);
-                    A[1] = read_a(sn, 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][0], acc[3], 0, 0, 0);
-                    acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][1], acc[4], 0, 0, 0);
-                    A[2] = read_a(sn, 2);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[3], Bq[cur][0], acc[5], 0, 0, 0);
-                    acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a6, b6, acc[6], 0, 0, 0);
-                    A[3] = read_a(sn, 3);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    // one slot per tap: every x fragment feeds one MFMA and is re-read for the next step right behind it
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[t], Bq[cur][0], acc[t], 0, 0, 0);
+                        A[t] = read_a(sn, t);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                    if (ODD) {  // the fourth tap (waves 0-2) or the bias column sums (wave 7)
+                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bias_slot ? ones : A[3], Bq[cur][0], acc[3], 0, 0, 0);
+                        A[3] = read_a(sn, 3);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
                 }
             };
 #pragma unroll 1
@@ -258,15 +291,15 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
             }
         }
     };
-    if (odd) run(std::true_type{}); else run(std::false_type{});
+    if (NTN == 2 ? odd : (cnt == 4 || bias_slot)) run(std::true_type{}); else run(std::false_type{});
 
     // ---- merge: D[row = ci][col = co]; lane holds col (lane & 31), rows (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
-    for (int i = 0; i < WR_SLOTS; ++i) {
+    for (int i = 0; i < SLOTS; ++i) {
         const int T = first + i;
         if (i < cnt) {
-            const int ltap = T >> 1, nt = T & 1;  // tap in local axes -> tap of the weight tensor
+            const int ltap = T / NTN, nt = T % NTN;  // tap in local axes -> tap of the weight tensor
             const int tap = (ltap / 9) * gv.ws[0] + ((ltap / 3) % 3) * gv.ws[1] + (ltap % 3) * gv.ws[2];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -276,9 +309,9 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                 if (slab_stride) dst[(int64_t)split * slab_stride] = acc[i][e];
                 else atomicAdd(dst, acc[i][e]);
             }
-        } else if (dbias != nullptr && ci0 == 0 && hh == 0) {
-            // the all-ones slot of waves 6 / 7: every row of the tile is the column sum of dy's N tile 0 / 1
-            atomicAdd(&dbias[co0 + (wave - 6) * 32 + r], acc[i][0]);
+        } else if (bias_slot && i == SLOTS - 1 && dbias != nullptr && ci0 == 0 && hh == 0) {
+            // the all-ones slot: every row of the tile is the column sum of a dy N tile (NTN = 2: tile wave - 6)
+            atomicAdd(&dbias[co0 + (NTN == 2 ? (wave - 6) * 32 : 0) + r], acc[i][0]);
         }
     }
 }
@@ -286,7 +319,7 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
 bool conv3_wgrad_ring_supported(int C1, int C2, int Cout) {
     const char* env = getenv("TDX_WGRAD_RING");  // A/B switch, read per call: 0 = off
     if (env && atoi(env) == 0) return false;
-    return conv3_wgrad_mfma_supported(C1, C2, Cout) && (Cout % 64) == 0 && tdx_scratch_ptr() != nullptr && tdx_scratch_bytes() >= 16;
+    return conv3_wgrad_mfma_supported(C1, C2, Cout) && (Cout % 32) == 0 && tdx_scratch_ptr() != nullptr && tdx_scratch_bytes() >= 16;
 }
 
 // same contract as conv3_wgrad_mfma_launch; TDX_ESHAPE = not a case for this kernel
@@ -311,7 +344,12 @@ int conv3_wgrad_ring_launch(const void* x1, int C1, const void* x2, int C2, cons
         g.E[k] = E[a]; g.s[k] = gs[a]; g.ws[k] = gw[a]; g.nb[k] = ceil_div(E[a], bdim[k]);
     }
     const int nbricks = B * g.nb[0] * g.nb[1] * g.nb[2];
-    const int n_ci = (Cin + 31) / 32, n_co = Cout / 64;
+    const int NTN = (Cout % 64) == 0 ? 2 : 1;
+    {
+        const char* env = getenv("TDX_WGRAD_RING");  // A/B switch: 2 = 64-wide tiles only (round 4's rule)
+        if (NTN == 1 && env && atoi(env) == 2) return TDX_ESHAPE;
+    }
+    const int n_ci = (Cin + 31) / 32, n_co = Cout / (32 * NTN);
     const int ntiles = n_ci * n_co;
     const int cus = tdx_persistent_cus();
     int nsplit = cus >= 256 ? (256 + ntiles - 1) / ntiles : std::max(cus / ntiles, 1);  // one workgroup per CU (at most `cus`)
@@ -319,18 +357,23 @@ int conv3_wgrad_ring_launch(const void* x1, int C1, const void* x2, int C2, cons
     if (nsplit < 1) nsplit = 1;
     // a workgroup should walk several bricks, or the double buffering has nothing to overlap
     if (nbricks < 4 * nsplit) return TDX_ESHAPE;
-    const size_t lds = (size_t)2 * WR_XBUF + (size_t)2 * WR_GBUF;
+    const size_t lds = (size_t)2 * WR_XBUF + (size_t)2 * WR_GBUF(NTN);
     const bool use_slabs = slabs != nullptr && nsplit <= max_slabs;
     const int64_t slab_stride = use_slabs ? (int64_t)27 * Cin * Cout : 0;
     float* out = use_slabs ? slabs : dwp;
     if (nslab_out) *nslab_out = use_slabs ? nsplit : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3_wgrad_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool attr_set[2] = {false, false};
+    const void* kern = NTN == 2 ? (const void*)conv3_wgrad_ring_kernel<2> : (const void*)conv3_wgrad_ring_kernel<1>;
+    if (!attr_set[NTN - 1]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set[NTN - 1] = true;
     }
-    hipLaunchKernelGGL(conv3_wgrad_ring_kernel, dim3((unsigned)(ntiles * nsplit)), dim3(768), lds, st, (const bf16*)x1, C1,
-                       (const bf16*)x2, C2, (const bf16*)dy, out, dbias, g, Cout, nsplit, n_ci, slab_stride, tdx_scratch_ptr());
+    if (NTN == 2)
+        hipLaunchKernelGGL(conv3_wgrad_ring_kernel<2>, dim3((unsigned)(ntiles * nsplit)), dim3(768), lds, st, (const bf16*)x1, C1,
+                           (const bf16*)x2, C2, (const bf16*)dy, out, dbias, g, Cout, nsplit, n_ci, slab_stride, tdx_scratch_ptr());
+    else
+        hipLaunchKernelGGL(conv3_wgrad_ring_kernel<1>, dim3((unsigned)(ntiles * nsplit)), dim3(768), lds, st, (const bf16*)x1, C1,
+                           (const bf16*)x2, C2, (const bf16*)dy, out, dbias, g, Cout, nsplit, n_ci, slab_stride, tdx_scratch_ptr());
     return tdx_launch_status();
 }
