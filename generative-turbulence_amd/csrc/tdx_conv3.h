@@ -86,6 +86,11 @@ bool conv3_wgrad_mfma_split_supported(int C1, int C2, int Cout);
 int conv3_wgrad_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
                                   int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs,
                                   int* nslab_out);
+// producer / consumer form of the split-precision weight gradient (tdx_conv3_wgrad_split_ring.hip: 8 computing + 4 loader
+// waves, 2 x 8 x 8 bricks); same contract, TDX_ESHAPE = not a case for it
+int conv3_wgrad_split_ring_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
+                                  int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs,
+                                  int* nslab_out);
 bool conv3_wgrad_mfma_f32_supported(int C1, int C2, int Cout);
 int conv3_wgrad_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp,
                                 float* dbias, int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs,

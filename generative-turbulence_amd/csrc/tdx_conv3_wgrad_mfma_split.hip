@@ -276,6 +276,10 @@ conv3_wgrad_mfma_split_kernel(const float* __restrict__ x1, int C1, const float*
 int conv3_wgrad_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
                                   int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs,
                                   int* nslab_out) {
+    {   // grids that give every workgroup several bricks: the producer / consumer form
+        const int rs = conv3_wgrad_split_ring_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st, slabs, max_slabs, nslab_out);
+        if (rs != TDX_ESHAPE) return rs;
+    }
     const int Cin = C1 + C2;
     const int E[3] = {X, Y, Z}, gs[3] = {Y * Z, Z, 1}, gw[3] = {9, 3, 1};
     const int cand[3][3] = {{0, 1, 2}, {1, 0, 2}, {2, 0, 1}};
