@@ -300,7 +300,8 @@ int conv3_wgrad_split_ring_launch(const void* x1, int C1, const void* x2, int C2
     const int nbricks = B * g.nb[0] * g.nb[1] * g.nb[2];
     const int n_ci = (Cin + 31) / 32, n_co = Cout / 32;
     const int ntiles = n_ci * n_co;
-    int nsplit = (256 + ntiles - 1) / ntiles;  // one workgroup per CU
+    const int cus = tdx_persistent_cus();
+    int nsplit = cus >= 256 ? (256 + ntiles - 1) / ntiles : std::max(cus / ntiles, 1);  // one workgroup per CU (at most `cus`)
     if (nsplit > nbricks) nsplit = nbricks;
     if (nsplit < 1) nsplit = 1;
     // a workgroup should walk several bricks, or the double buffering has nothing to overlap

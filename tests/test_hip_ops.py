@@ -1474,10 +1474,12 @@ def test_conv1_weight_gradient_in_parameter_layout(dt, C1, C2, Cout):
     # inputs, a half-filled last ci tile (C1 = 16), several co tiles, few and many bricks per workgroup, level-0 size
     (2, 64, 0, 64, (32, 32, 16)), (1, 32, 32, 64, (48, 32, 24)), (2, 16, 0, 64, (32, 16, 16)), (1, 64, 0, 128, (20, 18, 13)),
     (3, 32, 0, 64, (9, 17, 10)), (1, 64, 0, 64, (96, 32, 24)), (2, 64, 0, 64, (192, 64, 48)), (6, 128, 0, 256, (48, 16, 12)),
+    # 32-wide output tiles (round 5): level-0 size, four ci tiles, ragged bricks + two inputs + three co tiles, half-filled ci tile
+    (2, 32, 0, 32, (192, 64, 48)), (1, 128, 0, 32, (96, 32, 24)), (3, 32, 32, 96, (50, 33, 20)), (4, 16, 0, 32, (64, 64, 32)),
 ])
 def test_conv3_weight_gradient_producer_consumer_kernel_vs_brick_kernel(case, monkeypatch):
     """The producer / consumer weight-gradient kernel (tdx_conv3_wgrad_ring.hip: 8 computing + 4 loader waves) against the
-    brick kernel it replaces for 64-wide output tiles (TDX_WGRAD_RING = 1 / 0): the same per-workgroup partial sums,
+    brick kernel it replaces, 64- and 32-wide output tiles (TDX_WGRAD_RING = 1 / 0): the same per-workgroup partial sums,
     merged by fp32 atomics or slabs in a different order -> 2e-6; the bias gradient comes from an all-ones MFMA slot
     instead of the staging registers; the workspace is left zero; and the fp64 sums on the small cases.  Twice: the
     second call catches stale LDS / late copies."""
@@ -1509,12 +1511,64 @@ def test_conv3_weight_gradient_producer_consumer_kernel_vs_brick_kernel(case, mo
         ring = run(1)
         assert torch.isfinite(ring[0]).all() and torch.isfinite(ring[1]).all()
         assert rel_l2(ring[0], brick[0]) < 2e-6 and rel_l2(ring[1], brick[1]) < 2e-6, (case, rep)
-    if B * X * Y * Z <= 20000:
+    if B * X * Y * Z <= 20000 or Co == 96:
         xr = torch.cat([x1] + ([x2] if C2 else []), dim=-1).double().cpu().permute(0, 4, 1, 2, 3)
         w = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
         bz = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
         O.conv3_replicate(xr, w, bz).backward(gy.double().cpu().permute(0, 4, 1, 2, 3))
         assert rel_l2(ring[0].cpu(), w.grad) < 1e-5 and rel_l2(ring[1].cpu(), bz.grad) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # B, C1, C2, Cout, grid: level-0 size; several ci and co tiles; ragged bricks, two inputs; a half-filled ci tile (C1 = 16);
+    # too few bricks per workgroup (the call stays on the single-role kernel: both runs are that kernel)
+    (2, 32, 0, 32, (96, 64, 48)), (1, 128, 0, 64, (96, 32, 24)), (3, 32, 32, 96, (50, 33, 20)), (4, 16, 0, 32, (64, 64, 32)),
+    (1, 64, 0, 64, (20, 18, 13)),
+])
+def test_conv3_split_weight_gradient_producer_consumer_kernel(case, monkeypatch):
+    """The producer / consumer split-precision weight gradient (tdx_conv3_wgrad_split_ring.hip: 2 x 8 x 8 bricks, loader waves
+    split fp32 -> bf16 hi + lo) against the single-role kernel (TDX_WGRAD_SPLIT_RING = 1 / 0; other brick shape and K split,
+    so other partial sums: 1e-5) and against the fp64 sums (three bf16 products per fp32 product: 3e-5); the bias gradient comes
+    from ones x (dy_hi + dy_lo) instead of the fp32 registers.  On 8 workgroups (TDX_PERSISTENT_CUS) as well; twice: the second
+    call catches stale LDS."""
+    from turbdiff_amd import _lib as L
+
+    B, C1, C2, Co, (X, Y, Z) = case
+    d = dev()
+    Ci = C1 + C2
+    g = torch.Generator(device=d).manual_seed(17)
+    rn = lambda *s: torch.randn(*s, device=d, generator=g)
+    x1, x2 = rn(B, X, Y, Z, C1), (rn(B, X, Y, Z, C2) if C2 else None)
+    gy = rn(B, X, Y, Z, Co)
+    st = L.stream()
+    L.ensure_scratch(d)
+    ws = torch.zeros(L.query("tdx_conv3_bwd_weight_workspace_bytes", Ci, Co, L.CONV_SPLIT), dtype=torch.uint8, device=d)
+
+    def run(ring, cus=None):
+        monkeypatch.setenv("TDX_WGRAD_SPLIT_RING", str(ring))
+        if cus is None:
+            monkeypatch.delenv("TDX_PERSISTENT_CUS", raising=False)
+        else:
+            monkeypatch.setenv("TDX_PERSISTENT_CUS", str(cus))
+        dw, db = torch.empty(Co, Ci, 3, 3, 3, device=d), torch.empty(Co, device=d)
+        L.call("tdx_conv3_bwd_weight", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(gy), L.ptr(dw), L.ptr(db), B, X, Y, Z, Co, L.F32,
+               L.CONV_SPLIT | L.WS_CLEAN, L.ptr(ws), st)
+        torch.cuda.synchronize()
+        assert int(ws[: (27 * Ci * Co + Co) * 4].count_nonzero()) == 0
+        return dw, db
+
+    single = run(0)
+    for rep, cus in enumerate((None, None, 8)):
+        ring = run(1, cus)
+        assert torch.isfinite(ring[0]).all() and torch.isfinite(ring[1]).all()
+        assert rel_l2(ring[0], single[0]) < 1e-5 and rel_l2(ring[1], single[1]) < 1e-5, (case, rep)
+    if B * X * Y * Z <= 100000:
+        xr = torch.cat([x1] + ([x2] if C2 else []), dim=-1).double().cpu().permute(0, 4, 1, 2, 3)
+        w = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+        bz = torch.zeros(Co, dtype=torch.float64, requires_grad=True)
+        O.conv3_replicate(xr, w, bz).backward(gy.double().cpu().permute(0, 4, 1, 2, 3))
+        assert rel_l2(ring[0].cpu(), w.grad) < 3e-5 and rel_l2(ring[1].cpu(), bz.grad) < 3e-5
 
 
 @pytest.mark.gpu
