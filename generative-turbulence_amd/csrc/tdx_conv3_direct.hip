@@ -65,12 +65,15 @@ __device__ __forceinline__ void conv3_pack_tile(const float* __restrict__ w, bf1
         if (wf) {  // row = co, k = ci
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = t[row][(half * 8 + q) * 27 + tap];
-            put(wf, ((((int64_t)(ci0 >> 4) * 27 + tap) * Cout + co0 + row) << 4) + half * 8, v);
+            // bf16: [ci/16][tap][co][16 ci]; split images: [ci/8][tap][co][8 ci] (8-channel slices are what their kernels stage)
+            put(wf, SPLIT ? (((int64_t)((ci0 >> 3) + half) * 27 + tap) * Cout + co0 + row) << 3
+                          : ((((int64_t)(ci0 >> 4) * 27 + tap) * Cout + co0 + row) << 4) + half * 8, v);
         }
         if (wb) {  // row = ci, k = co
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = t[half * 8 + q][row * 27 + tap];
-            put(wb, ((((int64_t)(co0 >> 4) * 27 + (26 - tap)) * Cin + ci0 + row) << 4) + half * 8, v);
+            put(wb, SPLIT ? (((int64_t)((co0 >> 3) + half) * 27 + (26 - tap)) * Cin + ci0 + row) << 3
+                          : ((((int64_t)(co0 >> 4) * 27 + (26 - tap)) * Cin + ci0 + row) << 4) + half * 8, v);
         }
     }
 }
@@ -102,8 +105,8 @@ conv3_pack_tiled_many_kernel(PackTable tab) {
     conv3_pack_tile<SPLIT>(tab.w[j], tab.wf[j], tab.wb[j], tab.Cin[j], tab.Cout[j], (tile % ncx) * 16, (tile / ncx) * 16, t);
 }
 
-// split-precision operands (tdx_conv3_mfma_split.hip): hi = bf16(v), lo = bf16(v - hi), two MFMA-layout images
-// [2][K/16][27][N][16] bf16 in a buffer of the fp32 operand's size
+// split-precision operands (tdx_conv3_mfma_split.hip): hi = bf16(v), lo = bf16(v - hi), two images [2][K/8][27][N][8] bf16
+// in a buffer of the fp32 operand's size
 __global__ void conv3_pack_split_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wb, int Cin,
                                         int Cout) {
     const int64_t n = (int64_t)Cout * Cin * 27;
@@ -115,12 +118,12 @@ __global__ void conv3_pack_split_kernel(const float* __restrict__ w, bf16* __res
         const bf16 hi = __float2bfloat16(v);
         const bf16 lo = __float2bfloat16(v - __bfloat162float(hi));
         if (wf) {
-            const int64_t j = wp_index(16, tap, ci, co, Cin, Cout);
+            const int64_t j = wp_index(8, tap, ci, co, Cin, Cout);
             wf[j] = hi;
             wf[n + j] = lo;
         }
         if (wb) {
-            const int64_t j = wp_index(16, 26 - tap, co, ci, Cout, Cin);
+            const int64_t j = wp_index(8, 26 - tap, co, ci, Cout, Cin);
             wb[j] = hi;
             wb[n + j] = lo;
         }

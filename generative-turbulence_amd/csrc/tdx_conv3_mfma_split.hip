@@ -13,8 +13,8 @@
 // Structure: a 4 x 8 x 8 brick of output voxels (8 x 8 x 8 for 32-wide tiles on large grids) and BN = 32 NT output channels
 // per workgroup; the halo'd brick of an 8-CHANNEL slice and the slice's weights of all taps in LDS, split while staging:
 // activations are loaded as fp32 and written as a hi and a lo image (16-B entries = 8 bf16 channels of a voxel, z stride
-// padded 10 -> 12); weights arrive pre-split from tdx_conv3_pack_weight_split ([2][K/16][27][N][16] bf16, read in 8-channel
-// halves).  An MFMA K step of 16 is 8 channels x 2 TAPS: lanes 0-31 of a fragment hold tap 2 j, lanes 32-63 tap 2 j + 1
+// padded 10 -> 12); weights arrive pre-split from tdx_conv3_pack_weight(TDX_F32_SPLIT) ([2][K/8][27][N][8] bf16: a slice's
+// tap row is contiguous).  An MFMA K step of 16 is 8 channels x 2 TAPS: lanes 0-31 of a fragment hold tap 2 j, lanes 32-63 tap 2 j + 1
 // (14 steps, the 28th tap meets zero weight rows), the arrangement of tdx_conv3_ring.hip.  That halves the LDS image against
 // the round-4 form (16-channel slices, 157 KB): 80.6 KB for NT = 2, so TWO workgroups share a CU and one's staging, barriers
 // and epilogue run beside the other's MFMAs; <= 256 registers per lane (236; the per-piece source offsets are rebuilt from a

@@ -108,7 +108,8 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     const int64_t batch_vox = (int64_t)b * g.Ei[0] * g.Ei[1] * g.Ei[2];
 
     // ---- weight staging: piece p = tid + 256 i -> (m = p / (2 BN): part m & 1, tap pair m >> 1; n = (p % (2 BN)) >> 1;
-    // tap parity p & 1), 16 B = 8 channels; source = the packed [part][K/16][27][Cout][16] images, read in halves.
+    // tap parity p & 1), 16 B = 8 channels; source = the packed [part][K/8][27][Cout][8] images: a slice's tap row is 16 B x
+    // Cout contiguous (the [K/16][27][N][16] layout of round 4 made every piece half of a 32-B row: 2x the lines).
     // tid / (2 BN) is wave-uniform and i moves m by an even step: the part and the thread's byte offset are fixed, the tap pair
     // of piece i is uniform -- addresses are (uniform base) + (32-bit lane offset), nothing is kept per piece.
     constexpr int B_PIECES = 56 * BN;
@@ -117,7 +118,7 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
     static_assert(B_PIECES % 256 == 0 && B_MSTEP % 2 == 0, "weight pieces per thread");
     const int b_m0 = __builtin_amdgcn_readfirstlane(tid / (2 * BN));
     const int b_par = tid & 1;
-    const unsigned b_lane = (unsigned)((((b_m0 & 1) * lo_offset) + (int64_t)(n0 + ((tid % (2 * BN)) >> 1)) * SP_KC) * 2);
+    const unsigned b_lane = (unsigned)((((b_m0 & 1) * lo_offset) + (int64_t)(n0 + ((tid % (2 * BN)) >> 1)) * 8) * 2);
     const unsigned b_dst = (b_m0 & 1) * B_PLANE + ((b_m0 >> 1) * 2 * BN + (tid % (2 * BN))) * 16;
 
     float4 areg[A_PER_THREAD];
@@ -134,14 +135,14 @@ conv3_mfma_split_kernel(const float* __restrict__ x1, int C1, const float* __res
             if (a_src[i] >= 0)
                 areg[i] = *reinterpret_cast<const float4*>(xb + (size_t)((unsigned)(a_src[i] >> 1) * (unsigned)Cs * 4u + (a_src[i] & 1) * 16u));
         }
-        const char* wc = reinterpret_cast<const char*>(wp + (int64_t)(s >> 1) * 27 * Cout * SP_KC + (s & 1) * 8);
+        const char* wc = reinterpret_cast<const char*>(wp + (int64_t)s * 27 * Cout * 8);
 #pragma unroll
         for (int i = 0; i < B_PER_THREAD; ++i) {
             const int tap0 = 2 * ((b_m0 >> 1) + i * (B_MSTEP / 2));  // uniform
             const int t1 = tap0 + 1 < 27 ? tap0 + 1 : 26;
             const int g0 = PERM ? brick_tap(g, tap0 / 9 - 1, (tap0 / 3) % 3 - 1, tap0 % 3 - 1) : tap0;
             const int g1 = PERM ? brick_tap(g, t1 / 9 - 1, (t1 / 3) % 3 - 1, t1 % 3 - 1) : t1;
-            const unsigned off = b_lane + (unsigned)((b_par ? g1 : g0) * Cout * (SP_KC * 2));
+            const unsigned off = b_lane + (unsigned)((b_par ? g1 : g0) * Cout * 16);
             breg[i] = *reinterpret_cast<const uint4*>(wc + (size_t)off);  // tap 27 reads tap 26's row; zeroed when stored
         }
     };

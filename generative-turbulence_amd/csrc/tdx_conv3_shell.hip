@@ -161,7 +161,9 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
             const int q = p % Q, row = (p / Q) % B_ROWS, part = (p / Q) / B_ROWS;
             const int t9 = row / BN, n = row - t9 * BN;
             const int tap = (e0 + 1) * g.ws[0] + (t9 / 3) * g.ws[1] + (t9 % 3) * g.ws[2];
-            b_goff[i] = (((q >> 1) * 27 + tap) * N + n0 + n) * KC + (q & 1) * (KC / 2);
+            // bf16 / fp32: [K/KC][27][N][KC], read in halves; split images: [K/8][27][N][8], half q = slice q
+            b_goff[i] = MODE == SH_SPLIT ? ((q * 27 + tap) * N + n0 + n) * (KC / 2)
+                                         : (((q >> 1) * 27 + tap) * N + n0 + n) * KC + (q & 1) * (KC / 2);
             b_dst[i] = (part * Q + q) * B_PLANE + row * 16;
             if (part) b_goff[i] = -2 - b_goff[i];  // lo image: flagged by sign, offset added at load time
         }

@@ -29,8 +29,8 @@ struct SmallGeom {
 
 // SPLIT = false: bf16 tensors.  SPLIT = true: fp32 tensors with split-precision products (every operand as bf16 hi + lo,
 // x w ~ xh wh + xl wh + xh wl, as tdx_conv3_mfma_split.hip): the image is staged as raw fp32 (four 16-B quarter planes of
-// 4 channels) and split into hi / lo when a fragment is read; the weights arrive pre-split ([2 parts][K/16][27][N][16]
-// bf16, lo_offset elements apart).  fp32 images and two weight parts do not fit twice: that mode is single-buffered.
+// 4 channels) and split into hi / lo when a fragment is read; the weights arrive pre-split ([2 parts][K/8][27][N][8] bf16,
+// lo_offset elements apart).  fp32 images and two weight parts do not fit twice: that mode is single-buffered.
 // Round 4: FOUR LOADER WAVES beside the four computing waves (512 threads; one computing + one loader wave per SIMD).  An
 // LDS-DMA instruction blocks its issuing wave for ~150 cycles (profiles/r10_ring_stamps.txt); a slice is 16-23 of them per
 // wave against 27 x MTW MFMAs of 32 cycles, and with ONE wave per SIMD nothing else could issue meanwhile: the matrix pipe
@@ -121,7 +121,8 @@ conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict_
                 const int part = q / 28, half = (q % 28) / 14, row = (q % 14) * 64 + lane;  // row = tap * 32 + n
                 const int rr = min(row, 27 * SM_BN - 1);
                 const int tap = rr >> 5, n = rr & 31;
-                const bf16* src = wp + part * lo_offset + ((int64_t)(c * 27 + tap) * g.N + n0 + n) * SM_KC + half * 8;
+                const bf16* src = SPLIT ? wp + part * lo_offset + ((int64_t)((c * 2 + half) * 27 + tap) * g.N + n0 + n) * 8
+                                        : wp + ((int64_t)(c * 27 + tap) * g.N + n0 + n) * SM_KC + half * 8;
                 unsigned char* dst = sW + ((buf * WPARTS + part) * 2 + half) * (W_HALF + 512) + (q % 14) * 1024;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);

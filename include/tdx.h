@@ -88,8 +88,8 @@ int tdx_cast(const void* x, void* y, int64_t n, int dtype_in, int dtype_out, voi
  * each 27*Cin*Cout elements of `dtype`; either may be NULL.  The element order is an
  * implementation detail shared by pack and the consumers, a function of (dtype, K, N) only:
  * [K/16][27][N][16] for the bf16 MFMA kernels (K % 16 == 0, N % 32 == 0), [K/8][27][N][8] for the fp32 MFMA
- * kernels (K % 8 == 0, N % 32 == 0), else [27][K][N]; dtype = TDX_F32_SPLIT: two bf16 images (hi, lo) of the
- * bf16 MFMA layout in the fp32 operand's buffer where K % 16 == 0 and N % 32 == 0, else the fp32 layouts. */
+ * kernels (K % 8 == 0, N % 32 == 0), else [27][K][N]; dtype = TDX_F32_SPLIT: two bf16 images (hi, lo), each
+ * [K/8][27][N][8], in the fp32 operand's buffer where K % 16 == 0 and N % 32 == 0, else the fp32 layouts. */
 int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream);
 /* The same for n weights (`jobs`: HOST array; wf and wb both required): the weights whose two operands use the
  * MFMA layouts are packed by one launch per 32 jobs -- after an optimiser step a training step re-packs all its
