@@ -69,7 +69,7 @@ bool conv3_small_applies(int C1, int C2, int B, int X, int Y, int Z, int N, bool
 // TDX_ESHAPE = not a small-grid case
 int conv3_wgrad_small_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias, int B,
                              int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out);
-// producer / consumer weight gradient for 64-wide output tiles (tdx_conv3_wgrad_ring.hip, bf16: 8 computing + 4 loader
+// producer / consumer weight gradient, 64- and 32-wide output tiles (tdx_conv3_wgrad_ring.hip, bf16: 8 computing + 4 loader
 // waves per workgroup); same contract as conv3_wgrad_mfma_launch, TDX_ESHAPE = not a case for it
 int conv3_wgrad_ring_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias, int B, int X,
                             int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out);
