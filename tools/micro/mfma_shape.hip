@@ -64,6 +64,49 @@ __global__ void __launch_bounds__(512, 2) k16(float* out, const uint4* src, int 
     if (s == 12345.678f) out[0] = s;
 }
 
+// 32x32x16 with an MT x NT wave tile (MT x 32 voxels by NT x 32 channels), WAVES waves per workgroup, one workgroup per CU:
+// LDS bytes per MFMA = (MT + NT) / (MT NT) KiB -- 1 for 2 x 2, 0.75 for 4 x 2, 0.5 for 4 x 4
+template <int MT, int NT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 1) ktile(float* out, const uint4* src, int iters) {
+    __shared__ uint4 sm[4096];
+    for (int i = threadIdx.x; i < 4096; i += 64 * WAVES) sm[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x16 acc[MT][NT];
+    for (auto& a : acc) for (auto& b : a) for (int i = 0; i < 16; ++i) b[i] = 0.f;
+    bf16x8 A[MT], B[NT];
+    int off = (wave * 64 + lane) & 4095;
+    for (int it = 0; it < iters; ++it) {
+        off = (off + 257) & 4095;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) A[j] = __builtin_bit_cast(bf16x8, sm[(off + 64 * j) & 4095]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) B[j] = __builtin_bit_cast(bf16x8, sm[(off + 2048 + 64 * j) & 4095]);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], B[n], acc[m][n], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (auto& a : acc) for (auto& b : a) for (int i = 0; i < 16; ++i) s += b[i];
+    if (s == 12345.678f) out[0] = s;
+}
+template <int MT, int NT, int WAVES>
+static void run_tile(const char* name, const uint4* src, int iters) {
+    float* out; (void)hipMalloc(&out, 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto kern = ktile<MT, NT, WAVES>;
+    for (int r = 0; r < 30; ++r) hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WAVES), 0, 0, out, src, iters);
+    (void)hipEventRecord(e0);
+    const int reps = 50;
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(kern, dim3(256), dim3(64 * WAVES), 0, 0, out, src, iters);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 2.0 * (32.0 * MT) * (32.0 * NT) * 16 * iters * WAVES * 256.0 * reps;
+    printf("%-44s %8.3f ms/launch  %7.1f TFLOP/s\n", name, ms / reps, flops / ms / 1e9);
+    (void)hipFree(out);
+}
+
 template <typename K>
 static void run(const char* name, K kern, const uint4* src, int iters) {
     float* out; (void)hipMalloc(&out, 4);
@@ -90,6 +133,11 @@ int main() {
         run("16x16x32, operands in registers", k16<false>, src, 4000);
         run("32x32x16, operands re-read from LDS", k32<true>, src, 4000);
         run("16x16x32, operands re-read from LDS", k16<true>, src, 4000);
+        run_tile<2, 2, 8>("32x32x16 LDS-fed, 64x64 tile, 8 waves", src, 8000);
+        run_tile<2, 2, 4>("32x32x16 LDS-fed, 64x64 tile, 4 waves", src, 16000);
+        run_tile<4, 2, 4>("32x32x16 LDS-fed, 128x64 tile, 4 waves", src, 8000);
+        run_tile<4, 2, 8>("32x32x16 LDS-fed, 128x64 tile, 8 waves", src, 4000);
+        run_tile<4, 4, 4>("32x32x16 LDS-fed, 128x128 tile, 4 waves", src, 4000);
     }
     return 0;
 }
