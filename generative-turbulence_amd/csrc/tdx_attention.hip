@@ -198,11 +198,6 @@ extern "C" int tdx_attn_fwd(const void* qkv, void* out, float* lse, int B, int N
         if ((dtype == TDX_BF16 || dtype == TDX_F16) && !force_vector && attn_mfma_supported(N, D))
             return attn_fwd_mfma_launch(qkv, out, lse, B, N, H, dtype, as_stream(stream));
     }
-    if (dtype == TDX_F16) {  // fp16 tensors: short sequences run the row-wise kernels
-        dim3 grid16(ceil_div(N, 64), B * H);
-        hipLaunchKernelGGL((attn_fwd_kernel<f16, 32>), grid16, dim3(64), 0, as_stream(stream), (const f16*)qkv, (f16*)out, lse, N, H);
-        return tdx_launch_status();
-    }
     dim3 grid(ceil_div(N, 64), B * H);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_fwd_kernel<T, 32>), grid, dim3(64), 0, as_stream(stream),
                                                   (const T*)qkv, (T*)out, lse, N, H));
@@ -235,16 +230,6 @@ extern "C" int tdx_attn_bwd(const void* qkv, const void* out, const float* lse, 
                                (const f16*)dout, delta, N, H, total);
             return attn_bwd_mfma_launch(qkv, dout, lse, delta, dqkv, B, N, H, dtype, st);
         }
-    }
-    if (dtype == TDX_F16) {
-        typedef f16 T;
-        hipLaunchKernelGGL((attn_delta_kernel<T, 32>), dim3(ceil_div(total, 256)), dim3(256), 0, st, (const T*)out,
-                           (const T*)dout, delta, N, H, total);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, 32>), grid, dim3(64), 0, st, (const T*)qkv, (const T*)dout, lse,
-                           delta, (T*)dqkv, N, H);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, 32>), grid, dim3(64), 0, st, (const T*)qkv, (const T*)dout, lse,
-                           delta, (T*)dqkv, N, H);
-        return tdx_launch_status();
     }
     TDX_DISPATCH_DTYPE(dtype, {
         hipLaunchKernelGGL((attn_delta_kernel<T, 32>), dim3(ceil_div(total, 256)), dim3(256), 0, st, (const T*)out,

@@ -6,7 +6,7 @@
 #include "../../include/tdx.h"
 
 typedef __hip_bfloat16 bf16;
-typedef _Float16 f16;  // fp16 tensors: accepted by the attention entry points only (TDX_F16)
+typedef _Float16 f16;  // fp16 tensors (TDX_F16): IEEE half storage + fp16 MFMA operands, fp32 accumulation / statistics
 
 #define TDX_CHECK_ARG(cond) \
     do {                    \
@@ -149,6 +149,69 @@ struct Raw8<bf16> {
     }
 };
 
+template <>
+struct Raw8<f16> {
+    uint4 u;
+    __device__ __forceinline__ void load(const f16* p) { u = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ Vec8<f16> get() const {
+        typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+        const h8 h = __builtin_bit_cast(h8, u);
+        Vec8<f16> r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = (float)h[i];
+        return r;
+    }
+};
+
+// ---- the two 16-bit formats of the matrix-core kernels.  Those kernels move operands as raw 16-bit words (LDS-DMA, 16-B
+// register pieces, `bf16x8` fragments); what depends on the format is the MFMA opcode, the rounding of fp32 results to 16
+// bits, the widening of stored words, and the constant 1.0 of the bias-gradient slots.  HF = false: bfloat16 (TDX_BF16),
+// HF = true: IEEE half (TDX_F16; same matrix-pipe cycles on gfx950, 11 instead of 8 significand bits -- the arithmetic of
+// the reference's TF32 GPU runs, train.py:144-156).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <bool HF>
+struct H16;
+template <>
+struct H16<false> {
+    typedef bf16 T;
+    static constexpr int code = TDX_BF16;
+    static __device__ __forceinline__ f32x16_t mfma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+    static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }
+    static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+    static __device__ __forceinline__ bf16x8_t ones() {
+        const uint4 u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        return __builtin_bit_cast(bf16x8_t, u);
+    }
+};
+template <>
+struct H16<true> {
+    typedef f16 T;
+    static constexpr int code = TDX_F16;
+    static __device__ __forceinline__ f32x16_t mfma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+    static __device__ __forceinline__ float lo(unsigned w) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        return (float)__builtin_bit_cast(h2, w)[0];
+    }
+    static __device__ __forceinline__ float hi(unsigned w) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        return (float)__builtin_bit_cast(h2, w)[1];
+    }
+    static __device__ __forceinline__ bf16x8_t ones() {
+        const uint4 u = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+        return __builtin_bit_cast(bf16x8_t, u);
+    }
+};
+static inline bool tdx_is_h16(int dtype) { return dtype == TDX_BF16 || dtype == TDX_F16; }
+
 // ---- wave / block reductions (wave = 64 lanes) -----------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -195,8 +258,23 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n) {
         } else if ((dtype) == TDX_BF16) {              \
             typedef bf16 T;                            \
             __VA_ARGS__;                               \
+        } else if ((dtype) == TDX_F16) {               \
+            typedef f16 T;                             \
+            __VA_ARGS__;                               \
         } else                                         \
             return TDX_EDTYPE;                         \
+    } while (0)
+
+// 16-bit format dispatch for the matrix-core launchers: runs the statement with `constexpr bool HF`
+#define TDX_DISPATCH_H16(f16, ...)          \
+    do {                                    \
+        if (f16) {                          \
+            constexpr bool HF = true;       \
+            __VA_ARGS__;                    \
+        } else {                            \
+            constexpr bool HF = false;      \
+            __VA_ARGS__;                    \
+        }                                   \
     } while (0)
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -12,10 +12,10 @@ bool conv1_mfma_supported(int C1, int C2, int Cout);
 int conv1_mfma_fwd_launch(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
                           const void* add, void* y, int64_t rows, int Cout, hipStream_t st, const float* gn_stats = nullptr,
                           const float* gn_gamma = nullptr, const float* gn_beta = nullptr, int gn_groups = 1,
-                          int64_t gn_voxels = 1);
+                          int64_t gn_voxels = 1, bool hf = false);
 bool conv1_wgrad_mfma_supported(int Cin, int Cout);
 int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
-                            int64_t rows, bool transposed, hipStream_t st);
+                            int64_t rows, bool transposed, hipStream_t st, bool hf = false);
 // fp32 MFMA versions (tdx_conv1_mfma_f32.hip)
 bool conv1_mfma_f32_supported(int C1, int C2, int Cout, const float* w, int ldw);
 int conv1_mfma_f32_fwd_launch(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
@@ -106,8 +106,9 @@ extern "C" int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, con
                              void* stream) {
     TDX_CHECK_ARG(x1 && w && y && rows > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && ldw >= Cout);
     TDX_CHECK_ARG(C2 == 0 || x2);
-    if (dtype == TDX_BF16 && !conv1_force_direct() && conv1_mfma_supported(C1, C2, Cout))
-        return conv1_mfma_fwd_launch(x1, C1, x2, C2, w, ldw, bias, add, y, rows, Cout, as_stream(stream));
+    if (tdx_is_h16(dtype) && !conv1_force_direct() && conv1_mfma_supported(C1, C2, Cout))
+        return conv1_mfma_fwd_launch(x1, C1, x2, C2, w, ldw, bias, add, y, rows, Cout, as_stream(stream), nullptr, nullptr, nullptr, 1,
+                                     1, dtype == TDX_F16);
     if (dtype == TDX_F32 && !conv1_force_direct() && conv1_mfma_f32_supported(C1, C2, Cout, w, ldw))
         return conv1_mfma_f32_fwd_launch(x1, C1, x2, C2, w, ldw, bias, add, y, rows, Cout, as_stream(stream));
     dim3 grid(ceil_div(rows, C1_BM), ceil_div(Cout, C1_BN));
@@ -117,17 +118,17 @@ extern "C" int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, con
     return tdx_launch_status();
 }
 
-// y = silu(GroupNorm(h)) + bias + [x1|x2] @ w: the tail of a ResnetBlock with a projected skip in one pass (bf16 tensors on
+// y = silu(GroupNorm(h)) + bias + [x1|x2] @ w: the tail of a ResnetBlock with a projected skip in one pass (bf16 / fp16 tensors on
 // the matrix-core kernel; TDX_ESHAPE / TDX_EDTYPE otherwise: the caller then runs tdx_conv1_fwd + tdx_gn_apply).
 extern "C" int tdx_conv1_fwd_gn(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
                                 const void* h, const float* stats, const float* gamma, const float* beta, int groups,
                                 void* y, int B, int64_t V, int Cout, int dtype, void* stream) {
     TDX_CHECK_ARG(x1 && w && y && h && stats && gamma && beta && B > 0 && V > 0 && C1 > 0 && C2 >= 0 && Cout > 0 && ldw >= Cout);
     TDX_CHECK_ARG((C2 == 0 || x2) && groups > 0 && (Cout % groups) == 0);
-    if (dtype != TDX_BF16) return TDX_EDTYPE;
+    if (!tdx_is_h16(dtype)) return TDX_EDTYPE;
     if (conv1_force_direct() || !conv1_mfma_supported(C1, C2, Cout)) return TDX_ESHAPE;
     return conv1_mfma_fwd_launch(x1, C1, x2, C2, w, ldw, bias, h, y, (int64_t)B * V, Cout, as_stream(stream), stats, gamma,
-                                 beta, groups, V);
+                                 beta, groups, V, dtype == TDX_F16);
 }
 
 // dw[ci][co] = sum_r x[r,ci] dy[r,co]; each block reduces a chunk of rows for one
@@ -204,8 +205,8 @@ static int conv1_bwd_weight_impl(const void* x, int Cin, const void* dy, int Cou
             if (e != hipSuccess) return (int)e;
         }
     }
-    if (dtype == TDX_BF16 && !conv1_force_direct() && conv1_wgrad_mfma_supported(Cin, Cout))
-        return conv1_wgrad_mfma_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st);
+    if (tdx_is_h16(dtype) && !conv1_force_direct() && conv1_wgrad_mfma_supported(Cin, Cout))
+        return conv1_wgrad_mfma_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st, dtype == TDX_F16);
     if (dtype == TDX_F32 && !conv1_force_direct() && conv1_wgrad_mfma_f32_supported(Cin, Cout))
         return conv1_wgrad_mfma_f32_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st);
     dim3 grid(ceil_div(rows, C1W_ROWS), ceil_div(Cin, C1_BM), ceil_div(Cout, C1_BN));

@@ -50,11 +50,15 @@ struct Conv1GnAdd {
     int64_t V;            // voxels per sample (rows = B V)
 };
 
-template <int NT>
+// HF: format of the 16-bit tensors (H16<HF>: bf16 or fp16 words behind the bf16-typed pointers); the fp32 weights are
+// rounded to it while staging
+template <int NT, bool HF>
 __global__ void __launch_bounds__(256)
 conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                       const float* __restrict__ w, int ldw, const float* __restrict__ bias,
                       const bf16* __restrict__ add, bf16* __restrict__ y, int64_t rows, int Cout, Conv1GnAdd gn) {
+    typedef H16<HF> H;
+    typedef typename H::T HT;
     constexpr int BN = 32 * NT;
     // LDS: staging (x slice 16 KB + w slice BN*64 B) and the output tile [256][64] bf16 (32 KB)
     // share one region
@@ -99,8 +103,7 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
                 unsigned u[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    u[j] = (unsigned)f32_to_bf16_bits(wp[(size_t)(2 * j) * ldw]) |
-                           ((unsigned)f32_to_bf16_bits(wp[(size_t)(2 * j + 1) * ldw]) << 16);
+                    u[j] = H::pack2(wp[(size_t)(2 * j) * ldw], wp[(size_t)(2 * j + 1) * ldw]);
                 breg[i] = make_uint4(u[0], u[1], u[2], u[3]);
             }
         }
@@ -129,7 +132,7 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = H16<HF>::mfma(wf[nt], xf[mt], acc[nt][mt]);
         }
     }
 
@@ -153,10 +156,8 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
 #pragma unroll
                         for (int e = 0; e < 4; ++e) bv[e] = bias[n0 + np * 32 + ch + e];
                     }
-                    const unsigned lo = (unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j] + bv[0]) |
-                                        ((unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 1] + bv[1]) << 16);
-                    const unsigned hi = (unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 2] + bv[2]) |
-                                        ((unsigned)f32_to_bf16_bits(acc[nt][mt][4 * j + 3] + bv[3]) << 16);
+                    const unsigned lo = H::pack2(acc[nt][mt][4 * j] + bv[0], acc[nt][mt][4 * j + 1] + bv[1]);
+                    const unsigned hi = H::pack2(acc[nt][mt][4 * j + 2] + bv[2], acc[nt][mt][4 * j + 3] + bv[3]);
                     int a;
                     if (PW == 64) a = sw128(vr, ch >> 3) + (ch & 7) * 2;
                     else a = sw64(vr, ch >> 3) + (ch & 7) * 2;
@@ -174,11 +175,11 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
             // chunk), and the GroupNorm coefficients of its 8 channels are formed once per sample instead of per chunk
             // (a 64-bit division, 8 statistics loads and 16 parameter loads per 16 B: the fused tail ran at half the
             // bandwidth of the plain addend form, profiles/r11bf16_kernel_stats.csv)
-            Raw8<bf16> braw[NI];
+            Raw8<HT> braw[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int64_t rr = row0 + (tid + i * 256) / CHUNKS;
-                braw[i].load(add + (rr < rows ? rr : rows - 1) * Cout + cb);
+                braw[i].load(reinterpret_cast<const HT*>(add + (rr < rows ? rr : rows - 1) * Cout + cb));
             }
             float ka[8], c0[8];
             int64_t s_end = -1;  // rows below s_end (and not below the sample's first row) use ka / c0 as they are
@@ -202,8 +203,8 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
                 const int64_t rr = row0 + vr;
                 if (rr >= rows) continue;
                 const uint4 v = *reinterpret_cast<const uint4*>(smem + (PW == 64 ? sw128(vr, c) : sw64(vr, c)));
-                Vec8<bf16> a, b = braw[i].get();
-                a.load(reinterpret_cast<const bf16*>(&v));
+                Vec8<HT> a, b = braw[i].get();
+                a.load(reinterpret_cast<const HT*>(&v));
                 if (gn.stats != nullptr) {
                     if (rr >= s_end) coef(rr);  // the workgroup's rows run into the next sample (rows ascend with i)
 #pragma unroll
@@ -211,7 +212,7 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) a.v[e] += b.v[e];
-                a.store(y + rr * Cout + cb);
+                a.store(reinterpret_cast<HT*>(y + rr * Cout + cb));
             }
         } else {
 #pragma unroll
@@ -228,14 +229,15 @@ conv1_mfma_fwd_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restric
 
 int conv1_mfma_fwd_launch(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
                           const void* add, void* y, int64_t rows, int Cout, hipStream_t st, const float* gn_stats,
-                          const float* gn_gamma, const float* gn_beta, int gn_groups, int64_t gn_voxels) {
+                          const float* gn_gamma, const float* gn_beta, int gn_groups, int64_t gn_voxels, bool hf) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;  // NT = 4 needs 270 registers: 1 wave/SIMD, too few loads in flight
     dim3 grid(ceil_div(rows, C1M_ROWS), Cout / (32 * NT));
     const Conv1GnAdd gn = {gn_stats, gn_gamma, gn_beta, gn_groups, gn_voxels};
-#define C1M_LAUNCH(NTV)                                                                                             \
-    hipLaunchKernelGGL((conv1_mfma_fwd_kernel<NTV>), grid, dim3(256), 0, st, (const bf16*)x1, C1, (const bf16*)x2, \
+#define C1M_LAUNCH(NTV, HFV)                                                                                             \
+    hipLaunchKernelGGL((conv1_mfma_fwd_kernel<NTV, HFV>), grid, dim3(256), 0, st, (const bf16*)x1, C1, (const bf16*)x2, \
                        C2, w, ldw, bias, (const bf16*)add, (bf16*)y, rows, Cout, gn)
-    if (NT == 2) C1M_LAUNCH(2); else C1M_LAUNCH(1);
+    if (NT == 2) { if (hf) C1M_LAUNCH(2, true); else C1M_LAUNCH(2, false); }
+    else { if (hf) C1M_LAUNCH(1, true); else C1M_LAUNCH(1, false); }
 #undef C1M_LAUNCH
     return tdx_launch_status();
 }
@@ -254,7 +256,7 @@ bool conv1_wgrad_mfma_supported(int Cin, int Cout) { return (Cin % 32) == 0 && (
 
 // TR: the result is stored as dw[co][ci] (nn.Conv3d's own layout, row stride ldw): the MFMA is issued with its
 // operands swapped, so that a lane owns one ci and the 32 lanes of a half-wave still write one 128-B run.
-template <int MT, int NT, bool TR>  // tile = (32 MT) ci x (32 NT) co
+template <int MT, int NT, bool TR, bool HF>  // tile = (32 MT) ci x (32 NT) co; HF: operand format
 __global__ void __launch_bounds__(256)
 conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restrict__ dy, int Cout,
                         float* __restrict__ dw, int ldw, float* __restrict__ dbias, int64_t rows, int nsplit,
@@ -321,8 +323,8 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
                 const unsigned wds[4] = {gr[i].x, gr[i].y, gr[i].z, gr[i].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    bs[2 * e] += __uint_as_float(wds[e] << 16);
-                    bs[2 * e + 1] += __uint_as_float(wds[e] & 0xffff0000u);
+                    bs[2 * e] += H16<HF>::lo(wds[e]);
+                    bs[2 * e + 1] += H16<HF>::hi(wds[e]);
                 }
             }
         }
@@ -347,8 +349,8 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
-                    acc[m][n] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfv[n], af[m], acc[m][n], 0, 0, 0)
-                                   : __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfv[n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = TR ? H16<HF>::mfma(bfv[n], af[m], acc[m][n])
+                                   : H16<HF>::mfma(af[m], bfv[n], acc[m][n]);
         }
     }
     // ---- merge.  Each wave holds a private (32 MT) x (32 NT) tile: the four are summed through LDS first (fixed order), so
@@ -398,7 +400,7 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
 }
 
 int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
-                            int64_t rows, bool transposed, hipStream_t st) {
+                            int64_t rows, bool transposed, hipStream_t st, bool hf) {
     const int MT = (Cin % 64 == 0) ? 2 : 1, NT = (Cout % 64 == 0) ? 2 : 1;
     const int n_ci = Cin / (32 * MT), n_co = Cout / (32 * NT);
     const int ntiles = n_ci * n_co;
@@ -409,9 +411,15 @@ int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, fl
     if (nsplit > nchunks) nsplit = (int)nchunks;
     if (nsplit < 1) nsplit = 1;
     dim3 grid((unsigned)(ntiles * nsplit));
-#define C1W_LAUNCH(M, N, T)                                                                                          \
-    hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<M, N, T>), grid, dim3(256), 0, st, (const bf16*)x, Cin, (const bf16*)dy, \
-                       Cout, dw, ldw, dbias, rows, nsplit, n_ci)
+#define C1W_LAUNCH(M, N, T)                                                                                                 \
+    do {                                                                                                                    \
+        if (hf)                                                                                                            \
+            hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<M, N, T, true>), grid, dim3(256), 0, st, (const bf16*)x, Cin,       \
+                               (const bf16*)dy, Cout, dw, ldw, dbias, rows, nsplit, n_ci);                                  \
+        else                                                                                                                \
+            hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<M, N, T, false>), grid, dim3(256), 0, st, (const bf16*)x, Cin,      \
+                               (const bf16*)dy, Cout, dw, ldw, dbias, rows, nsplit, n_ci);                                  \
+    } while (0)
 #define C1W_PICK(T)                           \
     if (MT == 2 && NT == 2) C1W_LAUNCH(2, 2, T); \
     else if (MT == 2) C1W_LAUNCH(2, 1, T);       \

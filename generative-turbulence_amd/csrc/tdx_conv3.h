@@ -21,10 +21,10 @@ struct Conv3Geom {
 bool conv3_mfma_supported(int C1, int C2, int Cout);
 bool conv3_mfma_f32_supported(int C1, int C2, int Cout);
 static inline int conv3_layout_kc(int dtype, int K, int N) {
-    if (dtype == 1) return conv3_mfma_supported(K, 0, N) ? 16 : 0;
+    if (dtype == 1 || dtype == 3) return conv3_mfma_supported(K, 0, N) ? 16 : 0;  // TDX_BF16, TDX_F16: one layout
     return conv3_mfma_f32_supported(K, 0, N) ? 8 : 0;
 }
-static inline bool conv3_uses_mfma_layout(int dtype, int K, int N) { return dtype == 1 && conv3_mfma_supported(K, 0, N); }
+static inline bool conv3_uses_mfma_layout(int dtype, int K, int N) { return (dtype == 1 || dtype == 3) && conv3_mfma_supported(K, 0, N); }
 // split-precision (bf16 hi + lo) MFMA forward / zero-padded data gradient for fp32 tensors (tdx_conv3_mfma_split.hip)
 bool conv3_mfma_split_supported(int C1, int C2, int Cout);
 int conv3_mfma_split_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
@@ -45,7 +45,10 @@ struct Conv3Ext {
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                       const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr,
                       void* d1 = nullptr, int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr,
-                      const void* a2 = nullptr, const Conv3Ext* ext = nullptr, const int* slabs_beyond = nullptr);
+                      const void* a2 = nullptr, const Conv3Ext* ext = nullptr, const int* slabs_beyond = nullptr,
+                      bool hf = false);
+// hf (here and in the launchers below): the tensors and the packed operand are IEEE half instead of bfloat16 (TDX_F16):
+// same kernels, same layouts, v_mfma_f32_32x32x16_f16 and half rounding of the results (H16<HF>, tdx_common.h)
 // slabs_beyond = {mx, my, mz}: another kernel has computed the region [0, mx) x [0, my) x [0, mz) of the output; launch
 // only the thin-brick kernel on the remainder slabs beyond it (1-2 voxels thick per axis).
 
@@ -56,23 +59,24 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
 bool conv3_ring_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z);
 int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y, int B, int X,
                       int Y, int Z, int Cout, bool zero_pad, hipStream_t st, double* gn_acc = nullptr, void* d1 = nullptr,
-                      int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr, const void* a2 = nullptr);
+                      int D1 = 0, void* d2 = nullptr, const void* a1 = nullptr, const void* a2 = nullptr, bool hf = false);
 
 // small-grid conv (tdx_conv3_small.hip; bf16 tensors, or fp32 tensors with split-precision products when split): forward
 // or data gradient (then x1 = dy, result split over out1 / out2 with addends, halo fold included); TDX_ESHAPE = not a
 // small-grid case, take the brick kernels.  Needs the scratch arena.
 int conv3_small_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* out1, int D1,
                        void* out2, const void* add1, const void* add2, int B, int X, int Y, int Z, int N, bool data_gradient,
-                       bool split, hipStream_t st);
+                       bool split, hipStream_t st, bool hf = false);
 bool conv3_small_applies(int C1, int C2, int B, int X, int Y, int Z, int N, bool data_gradient, bool split);
 // packed-K weight gradient for small grids (tdx_conv3_wgrad_small.hip, bf16); same contract as conv3_wgrad_mfma_launch,
 // TDX_ESHAPE = not a small-grid case
 int conv3_wgrad_small_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias, int B,
-                             int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out);
+                             int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out,
+                             bool hf = false);
 // producer / consumer weight gradient, 64- and 32-wide output tiles (tdx_conv3_wgrad_ring.hip, bf16: 8 computing + 4 loader
 // waves per workgroup); same contract as conv3_wgrad_mfma_launch, TDX_ESHAPE = not a case for it
 int conv3_wgrad_ring_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias, int B, int X,
-                            int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out);
+                            int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out, bool hf = false);
 // CUs the persistent one-workgroup-per-CU kernels (ring conv, producer / consumer weight gradient) may occupy:
 // TDX_PERSISTENT_CUS in the environment (read per call), a multiple of 8 in [8, 256], default 256.  A data-parallel run
 // sets it below 256 to leave CUs to RCCL's kernels.
@@ -100,10 +104,10 @@ int conv3_wgrad_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, 
 // caller how many slabs to add up (0: the result was accumulated into dwp)
 int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
                             int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs = nullptr,
-                            int max_slabs = 0, int* nslab_out = nullptr);
+                            int max_slabs = 0, int* nslab_out = nullptr, bool hf = false);
 
 // halo-shell term of the data gradient, added onto dx with atomics (tdx_conv3_shell.hip); mode 0 bf16, 1 fp32 MFMA,
-// 2 split-precision; wb = the packed data-gradient operand for (K -> N) in that mode's layout
+// 2 split-precision, 3 fp16; wb = the packed data-gradient operand for (K -> N) in that mode's layout
 // sbuf: conv3_shell_buffer_bytes() of scratch, used when TDX_SHELL_DETERMINISTIC=1 (positions stored, then folded in a
 // fixed order by a second kernel, instead of atomics on edge / corner voxels); nullptr: always the atomics route
 size_t conv3_shell_buffer_bytes(int B, int X, int Y, int Z, int N);

@@ -36,11 +36,16 @@ __global__ void conv3_pack_kernel(const float* __restrict__ w, T* __restrict__ w
 // Tiled pack for the case that both operands use the MFMA layout: a workgroup owns a 16 (co) x 16 (ci) tile, reads
 // its 16 runs of 16*27 contiguous floats, and writes, per tap, one 512-B run of wf ([ci/16][tap][co][16 ci]) and one
 // of wb ([co/16][26-tap][ci][16 co]); per tap 16 rows x 2 halves of 8 packed values (one 16-B store each): 32 threads
-// per tap, 8 taps per pass.  SPLIT: fp32 tensors' split-precision operands, a hi and a lo image (hi = bf16(v),
-// lo = bf16(v - hi)) 27 Cin Cout elements apart.
-template <bool SPLIT>
+// per tap, 8 taps per pass.  FMT = PACK_SPLIT: fp32 tensors' split-precision operands, a hi and a lo image (hi = bf16(v),
+// lo = bf16(v - hi)) 27 Cin Cout elements apart; PACK_F16: the bf16 layout with IEEE half elements.
+#define PACK_BF16 0
+#define PACK_SPLIT 1
+#define PACK_F16 2
+template <int FMT>
 __device__ __forceinline__ void conv3_pack_tile(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wb,
                                                 int Cin, int Cout, int ci0, int co0, float (*t)[16 * 27 + 1]) {
+    constexpr bool SPLIT = FMT == PACK_SPLIT;
+    typedef H16<FMT == PACK_F16> H;
     const int tid = threadIdx.x;
     const int64_t n = (int64_t)Cout * Cin * 27;
     for (int i = tid; i < 16 * 432; i += 256) {
@@ -53,7 +58,7 @@ __device__ __forceinline__ void conv3_pack_tile(const float* __restrict__ w, bf1
         unsigned h[4], l[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            h[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
+            h[q] = H::pack2(v[2 * q], v[2 * q + 1]);
             if (SPLIT)
                 l[q] = pack_bf16x2(v[2 * q] - __uint_as_float(h[q] << 16), v[2 * q + 1] - __uint_as_float(h[q] & 0xffff0000u));
         }
@@ -78,11 +83,11 @@ __device__ __forceinline__ void conv3_pack_tile(const float* __restrict__ w, bf1
     }
 }
 
-template <bool SPLIT>
+template <int FMT>
 __global__ void __launch_bounds__(256)
 conv3_pack_tiled_kernel(const float* __restrict__ w, bf16* __restrict__ wf, bf16* __restrict__ wb, int Cin, int Cout) {
     __shared__ float t[16][16 * 27 + 1];  // [co][ci*27 + tap]
-    conv3_pack_tile<SPLIT>(w, wf, wb, Cin, Cout, blockIdx.x * 16, blockIdx.y * 16, t);
+    conv3_pack_tile<FMT>(w, wf, wb, Cin, Cout, blockIdx.x * 16, blockIdx.y * 16, t);
 }
 
 // the same over several weights in one launch (tdx_conv3_pack_weights): block -> (job, tile)
@@ -95,14 +100,14 @@ struct PackTable {
     int first[PACK_MAX_JOBS + 1];  // first block of job i
     int n;
 };
-template <bool SPLIT>
+template <int FMT>
 __global__ void __launch_bounds__(256)
 conv3_pack_tiled_many_kernel(PackTable tab) {
     __shared__ float t[16][16 * 27 + 1];
     int j = 0;
     while (j + 1 < tab.n && (int)blockIdx.x >= tab.first[j + 1]) ++j;
     const int tile = blockIdx.x - tab.first[j], ncx = tab.Cin[j] / 16;
-    conv3_pack_tile<SPLIT>(tab.w[j], tab.wf[j], tab.wb[j], tab.Cin[j], tab.Cout[j], (tile % ncx) * 16, (tile / ncx) * 16, t);
+    conv3_pack_tile<FMT>(tab.w[j], tab.wf[j], tab.wb[j], tab.Cin[j], tab.Cout[j], (tile % ncx) * 16, (tile / ncx) * 16, t);
 }
 
 // split-precision operands (tdx_conv3_mfma_split.hip): hi = bf16(v), lo = bf16(v - hi), two images [2][K/8][27][N][8] bf16
@@ -139,7 +144,7 @@ extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin
         void* sf = (wf && conv3_mfma_split_supported(Cin, 0, Cout)) ? wf : nullptr;
         void* sb = (wb && conv3_mfma_split_supported(Cout, 0, Cin)) ? wb : nullptr;
         if (sf && sb) {
-            hipLaunchKernelGGL(conv3_pack_tiled_kernel<true>, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
+            hipLaunchKernelGGL(conv3_pack_tiled_kernel<PACK_SPLIT>, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
                                (bf16*)sf, (bf16*)sb, Cin, Cout);
         } else if (sf || sb) {
             int grid = (int)min((int64_t)1024, (n + 255) / 256);
@@ -152,9 +157,13 @@ extern "C" int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin
         return tdx_launch_status();
     }
     const int lf = conv3_layout_kc(dtype, Cin, Cout), lb = conv3_layout_kc(dtype, Cout, Cin);
-    if (dtype == TDX_BF16 && (lf || !wf) && (lb || !wb) && (Cin % 16) == 0 && (Cout % 16) == 0) {
-        hipLaunchKernelGGL(conv3_pack_tiled_kernel<false>, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
-                           (bf16*)wf, (bf16*)wb, Cin, Cout);
+    if (tdx_is_h16(dtype) && (lf || !wf) && (lb || !wb) && (Cin % 16) == 0 && (Cout % 16) == 0) {
+        if (dtype == TDX_F16)
+            hipLaunchKernelGGL(conv3_pack_tiled_kernel<PACK_F16>, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
+                               (bf16*)wf, (bf16*)wb, Cin, Cout);
+        else
+            hipLaunchKernelGGL(conv3_pack_tiled_kernel<PACK_BF16>, dim3(Cin / 16, Cout / 16), dim3(256), 0, as_stream(stream), w,
+                               (bf16*)wf, (bf16*)wb, Cin, Cout);
         return tdx_launch_status();
     }
     int grid = (int)min((int64_t)1024, (n + 255) / 256);
@@ -175,9 +184,11 @@ extern "C" int tdx_conv3_pack_weights(const TdxPackJob* jobs, int n, int dtype, 
     auto flush = [&]() -> int {
         if (tab.n == 0) return TDX_OK;
         if (split)
-            hipLaunchKernelGGL(conv3_pack_tiled_many_kernel<true>, dim3(tab.first[tab.n]), dim3(256), 0, as_stream(stream), tab);
+            hipLaunchKernelGGL(conv3_pack_tiled_many_kernel<PACK_SPLIT>, dim3(tab.first[tab.n]), dim3(256), 0, as_stream(stream), tab);
+        else if (dtype == TDX_F16)
+            hipLaunchKernelGGL(conv3_pack_tiled_many_kernel<PACK_F16>, dim3(tab.first[tab.n]), dim3(256), 0, as_stream(stream), tab);
         else
-            hipLaunchKernelGGL(conv3_pack_tiled_many_kernel<false>, dim3(tab.first[tab.n]), dim3(256), 0, as_stream(stream), tab);
+            hipLaunchKernelGGL(conv3_pack_tiled_many_kernel<PACK_BF16>, dim3(tab.first[tab.n]), dim3(256), 0, as_stream(stream), tab);
         tab.n = 0;
         return tdx_launch_status();
     };
@@ -188,7 +199,7 @@ extern "C" int tdx_conv3_pack_weights(const TdxPackJob* jobs, int n, int dtype, 
         if (split)
             tiled = tiled && conv3_mfma_split_supported(j.Cin, 0, j.Cout) && conv3_mfma_split_supported(j.Cout, 0, j.Cin);
         else
-            tiled = tiled && dtype == TDX_BF16 && conv3_layout_kc(dtype, j.Cin, j.Cout) && conv3_layout_kc(dtype, j.Cout, j.Cin);
+            tiled = tiled && tdx_is_h16(dtype) && conv3_layout_kc(dtype, j.Cin, j.Cout) && conv3_layout_kc(dtype, j.Cout, j.Cin);
         if (!tiled) {
             int rc = tdx_conv3_pack_weight(j.w, j.wf, j.wb, j.Cin, j.Cout, dtype, stream);
             if (rc != TDX_OK) return rc;
@@ -593,8 +604,9 @@ extern "C" int tdx_set_scratch(void* ptr, size_t bytes) {
 }
 
 // ------------------------------------------------------------------ entry points ---------
+// the matrix-core kernels of the 16-bit formats (bf16 and fp16 tensors share them: H16<HF>, tdx_common.h)
 static bool mfma_ok(int dtype, int Cin1, int Cin2, int Cout) {
-    return dtype == TDX_BF16 && conv3_mfma_supported(Cin1, Cin2, Cout);
+    return tdx_is_h16(dtype) && conv3_mfma_supported(Cin1, Cin2, Cout);
 }
 
 extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, const void* wf, const float* bias,
@@ -616,14 +628,17 @@ extern "C" int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, con
     if (use_mfma) {
         if (!mfma_ok(dtype, C1, C2, Cout)) return TDX_ESHAPE;
         // deep U-Net levels: the small-grid kernel (packed M tiles, split K); TDX_ESHAPE = not such a case
+        const bool hf = dtype == TDX_F16;
         int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false,
-                                    false, as_stream(stream));
+                                    false, as_stream(stream), hf);
         if (rs != TDX_ESHAPE) return rs;
         // the two finest levels: persistent LDS-DMA ring kernel (same products, fp32 sums in another order: equal to the brick
         // kernel up to ~1 bf16 ulp on a few % of the elements, tdx_conv3_ring.hip)
-        rs = conv3_ring_launch(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, false, as_stream(stream));
+        rs = conv3_ring_launch(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, false, as_stream(stream), nullptr, nullptr, 0,
+                               nullptr, nullptr, nullptr, hf);
         if (rs != TDX_ESHAPE) return rs;
-        return conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream));
+        return conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, as_stream(stream), nullptr, nullptr, 0, nullptr,
+                                 nullptr, nullptr, nullptr, nullptr, hf);
     }
     return conv3_direct_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, dtype, false, as_stream(stream));
 }
@@ -650,7 +665,8 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     const bool clean = (impl & TDX_WS_CLEAN) != 0;
     impl &= 0xff;
     const bool use_mfma =
-        dtype == TDX_BF16 && (impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout)));
+        tdx_is_h16(dtype) && (impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout)));
+    const bool hf = dtype == TDX_F16;
     const bool f32_split = dtype == TDX_F32 && impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(C1 + C2, 0, Cout);
     const bool f32_mfma = dtype == TDX_F32 && !f32_split && impl != TDX_CONV_DIRECT && conv3_mfma_f32_supported(C1, C2, Cout);
     if (f32_split || f32_mfma) {  // fp32 tensors: the MFMA kernels accumulate the moments in their store loop too
@@ -677,10 +693,10 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
         if (rc != TDX_OK) return rc;
         return tdx_gn_stats(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, stream);
     }
-    if (!mfma_ok(dtype, C1, C2, Cout)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
+    if (!mfma_ok(dtype, C1, C2, Cout)) return tdx_is_h16(dtype) ? TDX_ESHAPE : TDX_EDTYPE;
     hipStream_t st = as_stream(stream);
     {   // deep U-Net levels: small-grid conv, then the statistics pass over its (tiny) result
-        int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false, false, st);
+        int rs = conv3_small_launch(x1, C1, x2, C2, wf, bias, y, Cout, nullptr, nullptr, nullptr, B, X, Y, Z, Cout, false, false, st, hf);
         if (rs == TDX_OK) return gn_stats_launch(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, clean, st);
         if (rs != TDX_ESHAPE) return rs;
     }
@@ -690,8 +706,10 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
         if (e != hipSuccess) return (int)e;
     }
     Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
-    int rc = conv3_ring_launch(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, false, st, acc);
-    if (rc == TDX_ESHAPE) rc = conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, st, acc);
+    int rc = conv3_ring_launch(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, false, st, acc, nullptr, 0, nullptr, nullptr, nullptr, hf);
+    if (rc == TDX_ESHAPE)
+        rc = conv3_mfma_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, st, acc, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, hf);
     if (rc != TDX_OK) return rc;
     return gn_finalize_launch(acc, stats, B, Cout, G, (int64_t)X * Y * Z, eps, TDX_GN_REPLICAS, st);
 }
@@ -705,7 +723,7 @@ extern "C" int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void
     TDX_CHECK_ARG(x1 && wf && y && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && Cout > 0 && ld1 >= C1 && (ld1 % 8) == 0);
     TDX_CHECK_ARG(stats == nullptr || (gn_workspace && G > 0 && (Cout % G) == 0));
     const bool clean = (impl & TDX_WS_CLEAN) != 0;
-    if (!mfma_ok(dtype, C1, 0, Cout)) return dtype == TDX_BF16 ? TDX_ESHAPE : TDX_EDTYPE;
+    if (!mfma_ok(dtype, C1, 0, Cout)) return tdx_is_h16(dtype) ? TDX_ESHAPE : TDX_EDTYPE;
     hipStream_t st = as_stream(stream);
     double* acc = stats ? (double*)gn_workspace : nullptr;
     if (acc && !clean) {
@@ -715,7 +733,7 @@ extern "C" int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void
     Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
     Conv3Ext ext = {ld1, 0, init, init_shared != 0};
     int rc = conv3_mfma_launch(x1, C1, nullptr, 0, wf, bias, y, g, Cout, false, st, acc, nullptr, 0, nullptr, nullptr, nullptr,
-                               &ext);
+                               &ext, nullptr, dtype == TDX_F16);
     if (rc != TDX_OK || !stats) return rc;
     return gn_finalize_launch(acc, stats, B, Cout, G, (int64_t)X * Y * Z, eps, TDX_GN_REPLICAS, st);
 }
@@ -725,7 +743,7 @@ extern "C" size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z,
     // call takes also depends on Cout, so the size is the same for all; the MFMA paths use it only for the position buffer
     // of the deterministic halo-shell route
     (void)impl;
-    const size_t padded = (size_t)B * (X + 2) * (Y + 2) * (Z + 2) * Cin * (dtype == TDX_BF16 ? 2 : 4);
+    const size_t padded = (size_t)B * (X + 2) * (Y + 2) * (Z + 2) * Cin * (tdx_is_h16(dtype) ? 2 : 4);
     const size_t shell = conv3_shell_buffer_bytes(B, X, Y, Z, Cin);  // TDX_SHELL_DETERMINISTIC=1: one fp32 row per shell position
     return (padded > shell ? padded : shell) + 256;
 }
@@ -742,18 +760,21 @@ static int conv3_bwd_data_impl(const void* dy, const void* wb, void* dx1, int C1
     if ((C1 % 8) || (C2 % 8) || (Cout % 8)) return TDX_ESHAPE;
     hipStream_t st = as_stream(stream);
     const Conv3Geom g0 = {B, X, Y, Z, X, Y, Z, 0};
-    const bool use_mfma = dtype == TDX_BF16 && (impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, Cout, 0, Cin)));
+    const bool use_mfma = tdx_is_h16(dtype) && (impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, Cout, 0, Cin)));
+    const bool hf = dtype == TDX_F16;
     int rc;
     if (use_mfma) {
         if (!mfma_ok(dtype, Cout, 0, Cin)) return TDX_ESHAPE;
         // deep U-Net levels: adjoint on the padded grid by the small-grid kernel, halo fold in its reduce pass
-        rc = conv3_small_launch(dy, Cout, nullptr, 0, wb, nullptr, dx1, C1, dx2, add1, add2, B, X, Y, Z, Cin, true, false, st);
+        rc = conv3_small_launch(dy, Cout, nullptr, 0, wb, nullptr, dx1, C1, dx2, add1, add2, B, X, Y, Z, Cin, true, false, st, hf);
         if (rc != TDX_ESHAPE) return rc;
-        rc = conv3_ring_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, B, X, Y, Z, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2);
+        rc = conv3_ring_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, B, X, Y, Z, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2,
+                               hf);
         if (rc == TDX_ESHAPE)
-            rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2);
+            rc = conv3_mfma_launch(dy, Cout, nullptr, 0, wb, nullptr, nullptr, g0, Cin, true, st, nullptr, dx1, C1, dx2, add1, add2,
+                                   nullptr, nullptr, hf);
         if (rc != TDX_OK) return rc;
-        return conv3_shell_launch(dy, wb, dx1, C1, dx2, B, X, Y, Z, Cout, Cin, 0, st, workspace);
+        return conv3_shell_launch(dy, wb, dx1, C1, dx2, B, X, Y, Z, Cout, Cin, hf ? 3 : 0, st, workspace);
     } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT &&
                ((impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin)) || conv3_mfma_f32_supported(Cout, 0, Cin))) {
         const bool split = impl == TDX_CONV_SPLIT && conv3_mfma_split_supported(Cout, 0, Cin);
@@ -821,7 +842,7 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
         hipError_t e = hipMemsetAsync(dwp, 0, ((size_t)27 * Cin * Cout + Cout) * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
-    const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && dtype == TDX_BF16 &&
+    const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && tdx_is_h16(dtype) &&
                                                      conv3_wgrad_mfma_supported(C1, C2, Cout));
     int nslab = 0;
     const float* slab_ptr = nullptr;
@@ -838,11 +859,12 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
         slab_ptr = slabs;
         if (rc != TDX_OK) return rc;
     } else if (use_mfma) {
-        if (dtype != TDX_BF16) return TDX_EDTYPE;
+        if (!tdx_is_h16(dtype)) return TDX_EDTYPE;
         if (!conv3_wgrad_mfma_supported(C1, C2, Cout)) return TDX_ESHAPE;
         float* slabs = dbw + ((Cout + 63) / 64) * 64;
         const int cap = w3_slab_capacity(Cin, Cout);
-        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs, cap, &nslab);
+        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs, cap, &nslab,
+                                         dtype == TDX_F16);
         slab_ptr = slabs;
         if (rc != TDX_OK) return rc;
         if (nslab > W3_MAX_SLABS) {

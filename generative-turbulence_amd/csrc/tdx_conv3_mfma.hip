@@ -86,12 +86,15 @@ __device__ __forceinline__ int out_addr(int v, int c) {
 
 // EXT: strided inputs (ConvView::ld1/ld2) and the `init` tensor of tdx_conv3_fwd_partial; a separate
 // instantiation so that the hot kernels carry none of it (it cost the 32-channel layers 7-19 %)
-template <int NT, bool XT, bool ZERO_PAD, bool PERM, bool EXT>
+// HF: the operand format (H16<HF>: bf16 or fp16 words behind the bf16-typed pointers)
+template <int NT, bool XT, bool ZERO_PAD, bool PERM, bool EXT, bool HF>
 __global__ void __launch_bounds__(256, 2)
 conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                   const bf16* __restrict__ wp, const float* __restrict__ bias, bf16* __restrict__ y, ConvViews gs,
                   int Cout, double* __restrict__ gn_acc, bf16* __restrict__ d1, int D1, bf16* __restrict__ d2,
                   const bf16* __restrict__ a1, const bf16* __restrict__ a2, const bf16* __restrict__ init) {
+    typedef H16<HF> H;
+    typedef typename H::T HT;
     constexpr int BN = NT * 32;
     constexpr int BX = XT ? 2 : 4, BY = XT ? 16 : 8, BZ = 8;
     constexpr int HX = BX + 2, HY = BY + 2, HZ = BZ + 2;
@@ -240,7 +243,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[tap & 1][nt], xf[tap & 1][mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = H::mfma(wf[tap & 1][nt], xf[tap & 1][mt], acc[nt][mt]);
             // pin the interleave: one fragment read of tap+1 behind each MFMA of tap
             if (tap + 1 < 27) {
 #pragma unroll
@@ -272,8 +275,8 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int v = (wx * BY + wy0 + 4 * mt + (r & 3)) * 8 + (r >> 2);
-                const unsigned lo = pack_bf16x2(acc[nt][mt][4 * j] + bv[0], acc[nt][mt][4 * j + 1] + bv[1]);
-                const unsigned hi = pack_bf16x2(acc[nt][mt][4 * j + 2] + bv[2], acc[nt][mt][4 * j + 3] + bv[3]);
+                const unsigned lo = H::pack2(acc[nt][mt][4 * j] + bv[0], acc[nt][mt][4 * j + 1] + bv[1]);
+                const unsigned hi = H::pack2(acc[nt][mt][4 * j + 2] + bv[2], acc[nt][mt][4 * j + 3] + bv[3]);
                 *reinterpret_cast<uint2*>(sO + out_addr<BN>(v, ch >> 3) + (ch & 7) * 2) = make_uint2(lo, hi);
             }
         }
@@ -307,12 +310,12 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
                     bf16* dst = lo ? d1 + u * D1 + n : d2 + u * (Cout - D1) + (n - D1);
                     const bf16* asrc = lo ? (a1 ? a1 + u * D1 + n : nullptr) : (a2 ? a2 + u * (Cout - D1) + (n - D1) : nullptr);
                     if (asrc) {
-                        Vec8<bf16> va, vb;
-                        va.load(reinterpret_cast<const bf16*>(&val));
-                        vb.load(asrc);
+                        Vec8<HT> va, vb;
+                        va.load(reinterpret_cast<const HT*>(&val));
+                        vb.load(reinterpret_cast<const HT*>(asrc));
 #pragma unroll
                         for (int e = 0; e < 8; ++e) va.v[e] += vb.v[e];
-                        va.store(dst);
+                        va.store(reinterpret_cast<HT*>(dst));
                     } else {
                         *reinterpret_cast<uint4*>(dst) = val;
                     }
@@ -325,12 +328,12 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
                     // continue from a precomputed partial convolution ([B or 1][voxels][Cout] bf16), added in
                     // the coalesced store loop; the statistics below see the sum
                     const int64_t iv = (int64_t)b * g.init_batch + c0 * g.so[0] + c1 * g.so[1] + c2 * g.so[2];
-                    Vec8<bf16> va, vb;
-                    va.load(reinterpret_cast<const bf16*>(&val));
-                    vb.load(init + iv * Cout + n0 + cidx * 8);
+                    Vec8<HT> va, vb;
+                    va.load(reinterpret_cast<const HT*>(&val));
+                    vb.load(reinterpret_cast<const HT*>(init + iv * Cout + n0 + cidx * 8));
 #pragma unroll
                     for (int e = 0; e < 8; ++e) va.v[e] += vb.v[e];
-                    va.store(reinterpret_cast<bf16*>(&val));
+                    va.store(reinterpret_cast<HT*>(&val));
                 }
                 *reinterpret_cast<uint4*>(y + ov * Cout + n0 + cidx * 8) = val;
             }
@@ -338,7 +341,7 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
                 const unsigned wds[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float lo = __uint_as_float(wds[e] << 16), hi = __uint_as_float(wds[e] & 0xffff0000u);
+                    const float lo = H::lo(wds[e]), hi = H::hi(wds[e]);
                     s1[2 * e] += lo; s2[2 * e] += lo * lo;
                     s1[2 * e + 1] += hi; s2[2 * e + 1] += hi * hi;
                 }
@@ -367,14 +370,14 @@ conv3_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ 
     }
 }
 
-template <int NT, bool XT, bool ZP, bool PERM, bool EXT = false>
-static int launch_view(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
+template <int NT, bool XT, bool ZP, bool PERM, bool EXT, bool HF>
+static int launch_view_h(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                        const ConvViews& v, int Cout, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
                        const void* a1, const void* a2, const void* init) {
     constexpr int BN = NT * 32;
     constexpr int HXv = (XT ? 2 : 4) + 2, HYv = (XT ? 16 : 8) + 2, SZv = XT ? 10 : 12;
     const size_t lds = (size_t)2 * (HXv * HYv * SZv * 16 + 64) + (size_t)27 * BN * 32 + 128;
-    auto kern = conv3_mfma_kernel<NT, XT, ZP, PERM, EXT>;
+    auto kern = conv3_mfma_kernel<NT, XT, ZP, PERM, EXT, HF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -386,10 +389,17 @@ static int launch_view(const void* x1, int C1, const void* x2, int C2, const voi
                        (bf16*)y, v, Cout, gn_acc, (bf16*)d1, D1, (bf16*)d2, (const bf16*)a1, (const bf16*)a2, (const bf16*)init);
     return tdx_launch_status();
 }
+template <int NT, bool XT, bool ZP, bool PERM, bool EXT = false>
+static int launch_view(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
+                       const ConvViews& v, int Cout, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
+                       const void* a1, const void* a2, const void* init, bool hf) {
+    if (hf) return launch_view_h<NT, XT, ZP, PERM, EXT, true>(x1, C1, x2, C2, wp, bias, y, v, Cout, st, gn_acc, d1, D1, d2, a1, a2, init);
+    return launch_view_h<NT, XT, ZP, PERM, EXT, false>(x1, C1, x2, C2, wp, bias, y, v, Cout, st, gn_acc, d1, D1, d2, a1, a2, init);
+}
 
 int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y,
                       const Conv3Geom& g, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1,
-                      void* d2, const void* a1, const void* a2, const Conv3Ext* ext, const int* slabs_beyond) {
+                      void* d2, const void* a1, const void* a2, const Conv3Ext* ext, const int* slabs_beyond, bool hf) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const void* init = ext ? ext->init : nullptr;
     if ((int64_t)g.Xi * g.Yi * g.Zi * 2 >= (1ll << 31) || (int64_t)g.Xo * g.Yo * g.Zo >= (1ll << 31)) return TDX_ESHAPE;
@@ -440,16 +450,16 @@ int conv3_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void
         if (vs.start[3] == 0) return TDX_OK;
 #define M3_GO(NTV, XTV, PV)                                                                                             \
     (zero_pad ? launch_view<NTV, XTV, true, PV>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1, a2,  \
-                                                nullptr)                                                                \
+                                                nullptr, hf)                                                           \
               : launch_view<NTV, XTV, false, PV>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1, a2, \
-                                                 nullptr))
+                                                 nullptr, hf))
         if (ext != nullptr) {  // strided input / init tensor: forward main bricks only
             if (zero_pad || xt || permuted) return TDX_ESHAPE;
             if (NT == 2)
                 return launch_view<2, false, false, false, true>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2,
-                                                                 a1, a2, init);
+                                                                 a1, a2, init, hf);
             return launch_view<1, false, false, false, true>(x1, C1, x2, C2, wp, bias, y, vs, Cout, st, gn_acc, d1, D1, d2, a1,
-                                                             a2, init);
+                                                             a2, init, hf);
         }
         if (NT == 2) return xt ? M3_GO(2, true, false) : (permuted ? M3_GO(2, false, true) : M3_GO(2, false, false));
         return xt ? M3_GO(1, true, false) : (permuted ? M3_GO(1, false, true) : M3_GO(1, false, false));

@@ -133,9 +133,11 @@ struct RingShape {
                                   64 /* zero entry */ + BN * 4 /* bias */ + (size_t)RG_WAVES * BN * 2 * 4 /* statistics */;
 };
 
-template <int NT, bool ZP, int LW>
+template <int NT, bool ZP, int LW, bool HF>
 __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(RingArgs A) {
     typedef RingShape<NT, LW> S;
+    typedef H16<HF> H;                  // operand format: bf16 or fp16 words (the pointers of RingArgs are raw 16-bit rows)
+    typedef typename H::T HT;
     constexpr int BN = S::BN, MT = S::MT, XP = S::XP, BPW = S::BPW, WPW = S::WPW, CH = S::CH, VPI = S::VPI, NST = S::NST;
     static_assert(LW > 0 || BPW + WPW < RG_STEPS, "one DMA instruction per K step");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[p % 3][nt], xf[p % 3][mt], acc[nt][mt], 0, 0, 0);
+                        acc[nt][mt] = H::mfma(wf[p % 3][nt], xf[p % 3][mt], acc[nt][mt]);
                 if (p + 2 < RG_STEPS) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -436,8 +438,8 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ch = nt * 32 + 8 * j + 4 * hh;
-                    const unsigned lo2 = pack_bf16x2(acc[nt][mt][4 * j], acc[nt][mt][4 * j + 1]);
-                    const unsigned hi2 = pack_bf16x2(acc[nt][mt][4 * j + 2], acc[nt][mt][4 * j + 3]);
+                    const unsigned lo2 = H::pack2(acc[nt][mt][4 * j], acc[nt][mt][4 * j + 1]);
+                    const unsigned hi2 = H::pack2(acc[nt][mt][4 * j + 2], acc[nt][mt][4 * j + 3]);
                     *reinterpret_cast<uint2*>(tile + rg_tile_addr<BN>(vw, ch >> 3) + (ch & 7) * 2) = make_uint2(lo2, hi2);
                 }
 #pragma unroll
@@ -455,12 +457,12 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
                     const bf16* asrc = lo1 ? (A.a1 ? A.a1 + ov * A.D1 + n : nullptr)
                                            : (A.a2 ? A.a2 + ov * (A.Cout - A.D1) + (n - A.D1) : nullptr);
                     if (asrc) {
-                        Vec8<bf16> va, vb;
-                        va.load(reinterpret_cast<const bf16*>(&val));
-                        vb.load(asrc);
+                        Vec8<HT> va, vb;
+                        va.load(reinterpret_cast<const HT*>(&val));
+                        vb.load(reinterpret_cast<const HT*>(asrc));
 #pragma unroll
                         for (int e = 0; e < 8; ++e) va.v[e] += vb.v[e];
-                        va.store(dst);
+                        va.store(reinterpret_cast<HT*>(dst));
                     } else {
                         *reinterpret_cast<uint4*>(dst) = val;
                     }
@@ -470,7 +472,7 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
                         const unsigned wds[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const f32x2 lh = {__uint_as_float(wds[e] << 16), __uint_as_float(wds[e] & 0xffff0000u)};
+                            const f32x2 lh = {H::lo(wds[e]), H::hi(wds[e])};
                             p1[e] += lh;
                             p2[e] = __builtin_elementwise_fma(lh, lh, p2[e]);
                         }
@@ -527,13 +529,13 @@ bool conv3_ring_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z) 
 static unsigned long long* rg_stamp_buffer = nullptr;
 #endif
 
-template <int NT, bool ZP, int LW>
+template <int NT, bool ZP, int LW, bool HF>
 static int ring_go(const RingArgs& a, hipStream_t st) {
     size_t lds = RingShape<NT, LW>::LDS;
 #ifdef RG_STAMPS
     if (NT == 1) lds += (size_t)RG_WAVES * RG_NSTAMP * 8;
 #endif
-    auto kern = conv3_ring_kernel<NT, ZP, LW>;
+    auto kern = conv3_ring_kernel<NT, ZP, LW, HF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -550,7 +552,7 @@ static int ring_go(const RingArgs& a, hipStream_t st) {
 // TDX_ESHAPE = not a case for this kernel, take the brick kernel
 int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y, int B, int X,
                       int Y, int Z, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
-                      const void* a1, const void* a2) {
+                      const void* a1, const void* a2, bool hf) {
     if (!conv3_ring_supported(C1, C2, Cout, B, X, Y, Z)) return TDX_ESHAPE;
     if (zero_pad && (tdx_scratch_ptr() == nullptr || tdx_scratch_bytes() < 16)) return TDX_ESHAPE;  // zero source
     const int NT = Cout % 64 == 0 ? 2 : 1;
@@ -569,12 +571,15 @@ int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void
     const char* env = getenv("TDX_RING_LOADERS");  // A/B switch: 0 = the computing waves issue the copies themselves
     const bool lw = env ? atoi(env) != 0 : RG_DEFAULT_LOADERS;
     int rc;
-    if (NT == 2) {
-        if (lw) rc = zero_pad ? ring_go<2, true, 4>(a, st) : ring_go<2, false, 4>(a, st);
-        else rc = zero_pad ? ring_go<2, true, 0>(a, st) : ring_go<2, false, 0>(a, st);
+    if (hf) {  // fp16 operands: the loader-wave form only (the loader-less form is an A/B build of the bf16 kernels)
+        if (NT == 2) rc = zero_pad ? ring_go<2, true, 4, true>(a, st) : ring_go<2, false, 4, true>(a, st);
+        else rc = zero_pad ? ring_go<1, true, 4, true>(a, st) : ring_go<1, false, 4, true>(a, st);
+    } else if (NT == 2) {
+        if (lw) rc = zero_pad ? ring_go<2, true, 4, false>(a, st) : ring_go<2, false, 4, false>(a, st);
+        else rc = zero_pad ? ring_go<2, true, 0, false>(a, st) : ring_go<2, false, 0, false>(a, st);
     } else {
-        if (lw) rc = zero_pad ? ring_go<1, true, 4>(a, st) : ring_go<1, false, 4>(a, st);
-        else rc = zero_pad ? ring_go<1, true, 0>(a, st) : ring_go<1, false, 0>(a, st);
+        if (lw) rc = zero_pad ? ring_go<1, true, 4, false>(a, st) : ring_go<1, false, 4, false>(a, st);
+        else rc = zero_pad ? ring_go<1, true, 0, false>(a, st) : ring_go<1, false, 0, false>(a, st);
     }
     const int bxr = NT == 2 ? 8 : 16;
     if (rc != TDX_OK || ((X % bxr) == 0 && (Y % 8) == 0 && (Z % 8) == 0)) return rc;
@@ -582,7 +587,7 @@ int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void
     // operands, same epilogue incl. the statistics accumulators and the data gradient's split / addends)
     const int beyond[3] = {X - X % bxr, Y - Y % 8, Z - Z % 8};
     const Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
-    return conv3_mfma_launch(x1, C1, x2, C2, wp, bias, y, g, Cout, zero_pad, st, gn_acc, d1, D1, d2, a1, a2, nullptr, beyond);
+    return conv3_mfma_launch(x1, C1, x2, C2, wp, bias, y, g, Cout, zero_pad, st, gn_acc, d1, D1, d2, a1, a2, nullptr, beyond, hf);
 }
 
 extern "C" int tdx_conv3_uses_ring(int C1, int C2, int Cout, int B, int X, int Y, int Z) {

@@ -34,11 +34,13 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define SH_BF16 0
 #define SH_F32 1
 #define SH_SPLIT 2
+#define SH_F16 3    // as SH_BF16 with IEEE half tensors / operands (v_mfma_f32_32x32x16_f16, global_atomic_pk_add_f16)
 
 // Diagnostic builds only (tools/micro/shell_stamp.hip defines SH_STAMPS): s_memtime stamps of every wave's phases, written
 // straight to sh_stamps_dev; the product build carries none of it.
@@ -171,7 +173,9 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
 
     // registers of the slice in flight: 16 B per piece (32 B of fp32 source in split mode)
     uint4 areg[A_PER_THREAD][MODE == SH_SPLIT ? 2 : 1], breg[B_PER_THREAD];
-    const int esz = MODE == SH_BF16 ? 2 : 4;  // bytes per dy element
+    constexpr bool H16M = MODE == SH_BF16 || MODE == SH_F16;  // 16-bit tensors
+    typedef H16<MODE == SH_F16> H;
+    const int esz = H16M ? 2 : 4;  // bytes per dy element
     auto load_slice = [&](int c) {
         const unsigned char* xs = reinterpret_cast<const unsigned char*>(dy_) + (batch_vox * K + (int64_t)c * KC * S) * esz;
 #pragma unroll
@@ -275,7 +279,7 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(x.w), acc[nt][mt], 0, 0, 0);
                     } else {
                         const bf16x8 wh = *reinterpret_cast<const bf16x8*>(&f.w[0][nt]), xh = *reinterpret_cast<const bf16x8*>(&f.x[0][mt]);
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[nt][mt], 0, 0, 0);
+                        acc[nt][mt] = H::mfma(wh, xh, acc[nt][mt]);
                         if (MODE == SH_SPLIT) {
                             const bf16x8 wl = *reinterpret_cast<const bf16x8*>(&f.w[PARTS - 1][nt]);
                             const bf16x8 xl = *reinterpret_cast<const bf16x8*>(&f.x[PARTS - 1][mt]);
@@ -321,7 +325,7 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
         }
     __syncthreads();
     SH_T();  // transposed tile in LDS
-    constexpr int CH = MODE == SH_BF16 ? 8 : 4;  // channels per 16-B piece of dx
+    constexpr int CH = H16M ? 8 : 4;  // channels per 16-B piece of dx
     constexpr int CHUNKS = BN / CH;
 #pragma unroll 4
     for (int i = 0; i < CHUNKS; ++i) {
@@ -354,17 +358,22 @@ conv3_shell_kernel(const void* __restrict__ dy_, const void* __restrict__ wb_, v
             const float4 t = *reinterpret_cast<const float4*>(sO + v * (BN * 4) + ((c4 ^ (v & (BN / 4 - 1))) << 4));
             val[4 * q] = t.x; val[4 * q + 1] = t.y; val[4 * q + 2] = t.z; val[4 * q + 3] = t.w;
         }
-        if (MODE == SH_BF16) {
-            bf16* dst = reinterpret_cast<bf16*>(lo ? d1_ : d2_) + idx;
+        if (H16M) {
+            typedef typename H::T HT;
+            HT* dst = reinterpret_cast<HT*>(lo ? d1_ : d2_) + idx;
             if (shared) {
 #pragma unroll
                 for (int e = 0; e < CH / 2; ++e) {
-                    const unsigned pk = pack_bf16x2(val[2 * e], val[2 * e + 1]);
-                    __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) bf16x2_t*)(dst + 2 * e),
-                                                               *reinterpret_cast<const bf16x2_t*>(&pk));
+                    const unsigned pk = H::pack2(val[2 * e], val[2 * e + 1]);
+                    if (MODE == SH_F16)
+                        __builtin_amdgcn_global_atomic_fadd_v2f16((__attribute__((address_space(1))) f16x2_t*)(dst + 2 * e),
+                                                                  *reinterpret_cast<const f16x2_t*>(&pk));
+                    else
+                        __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) bf16x2_t*)(dst + 2 * e),
+                                                                   *reinterpret_cast<const bf16x2_t*>(&pk));
                 }
             } else {
-                Vec8<bf16> o;
+                Vec8<HT> o;
                 o.load(dst);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o.v[e] += val[e < CH ? e : 0];
@@ -516,6 +525,7 @@ int conv3_shell_launch(const void* dy, const void* wb, void* d1, int D1, void* d
 #define SH_PICK(M) (wide_n ? (two ? SH_GO(M, 2, 2) : SH_GO(M, 2, 1)) : (two ? SH_GO(M, 1, 2) : SH_GO(M, 1, 1)))
     int rc;
     if (mode == SH_BF16) rc = SH_PICK(SH_BF16);
+    else if (mode == SH_F16) rc = SH_PICK(SH_F16);
     else if (mode == SH_F32) rc = SH_PICK(SH_F32);
     else if (wide_n) rc = SH_GO(SH_SPLIT, 2, 1);
     else rc = two ? SH_GO(SH_SPLIT, 1, 2) : SH_GO(SH_SPLIT, 1, 1);
@@ -525,7 +535,9 @@ int conv3_shell_launch(const void* dy, const void* wb, void* d1, int D1, void* d
     const int64_t nz = 2 * (int64_t)X * Y, ny = Z > 2 ? 2 * (int64_t)X * (Z - 2) : 0, nx = (Z > 2 && Y > 2) ? 2 * (int64_t)(Y - 2) * (Z - 2) : 0;
     const int64_t per_sample = (Z == 1 ? nz / 2 : nz) + (Y == 1 ? ny / 2 : ny) + (X == 1 ? nx / 2 : nx);
     const int64_t threads = (int64_t)B * per_sample * (N / 8);
-    if (mode == SH_BF16)
+    if (mode == SH_F16)
+        hipLaunchKernelGGL(conv3_shell_fold_kernel<f16>, dim3(ceil_div(threads, 256)), dim3(256), 0, st, sbuf, (f16*)d1, D1, (f16*)d2, R, X, Y, Z, N);
+    else if (mode == SH_BF16)
         hipLaunchKernelGGL(conv3_shell_fold_kernel<bf16>, dim3(ceil_div(threads, 256)), dim3(256), 0, st, sbuf, (bf16*)d1, D1, (bf16*)d2, R, X, Y, Z, N);
     else
         hipLaunchKernelGGL(conv3_shell_fold_kernel<float>, dim3(ceil_div(threads, 256)), dim3(256), 0, st, sbuf, (float*)d1, D1, (float*)d2, R, X, Y, Z, N);

@@ -166,11 +166,18 @@ int conv3_small_go_6b(SMALL_GO_ARGS);
 int conv3_small_go_6s(SMALL_GO_ARGS);
 int conv3_small_go_7b(SMALL_GO_ARGS);
 int conv3_small_go_7s(SMALL_GO_ARGS);
+int conv3_small_go_3h(SMALL_GO_ARGS);
+int conv3_small_go_4h(SMALL_GO_ARGS);
+int conv3_small_go_5h(SMALL_GO_ARGS);
+int conv3_small_go_6h(SMALL_GO_ARGS);
+int conv3_small_go_7h(SMALL_GO_ARGS);
 
-template <bool SPLIT>
+// FMT: 0 bf16 tensors, 1 split-precision fp32 tensors, 2 fp16 tensors
+template <int FMT>
 static int small_dispatch(int mtw, SMALL_GO_ARGS) {
-#define GO(M) (SPLIT ? conv3_small_go_##M##s(x1, C1, x2, C2, wp, slab, zero16, g, lds, lo_offset, st) \
-                     : conv3_small_go_##M##b(x1, C1, x2, C2, wp, slab, zero16, g, lds, lo_offset, st))
+#define GO(M) (FMT == 1 ? conv3_small_go_##M##s(x1, C1, x2, C2, wp, slab, zero16, g, lds, lo_offset, st)   \
+               : FMT == 2 ? conv3_small_go_##M##h(x1, C1, x2, C2, wp, slab, zero16, g, lds, lo_offset, st) \
+                          : conv3_small_go_##M##b(x1, C1, x2, C2, wp, slab, zero16, g, lds, lo_offset, st))
     switch (mtw) {
         case 1: case 2: case 3: return GO(3);
         case 4: return GO(4);
@@ -197,7 +204,7 @@ bool conv3_small_applies(int C1, int C2, int B, int X, int Y, int Z, int N, bool
 // Returns TDX_ESHAPE when the launch is not a small-grid case (the caller then takes the brick kernels).
 int conv3_small_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* out1, int D1,
                        void* out2, const void* add1, const void* add2, int B, int X, int Y, int Z, int N, bool data_gradient,
-                       bool split, hipStream_t st) {
+                       bool split, hipStream_t st, bool hf) {
     char* arena = (char*)tdx_scratch_ptr();
     if (arena == nullptr) return TDX_ESHAPE;
     if ((C1 % SM_KC) || (C2 % SM_KC)) return TDX_ESHAPE;
@@ -209,13 +216,18 @@ int conv3_small_launch(const void* x1, int C1, const void* x2, int C2, const voi
     const int mtw = ceil_div(ceil_div(rows, 32), 4);
     if (mtw > SM_MAX_TILES / 4) return TDX_ESHAPE;  // never drop rows silently: the brick kernels take the call
     const int64_t lo = (int64_t)27 * (C1 + C2) * N;  // elements between the hi and the lo weight image
-    const int rc = split ? small_dispatch<true>(mtw, x1, C1, x2, C2, wp, slab, arena, g, lds, lo, st)
-                         : small_dispatch<false>(mtw, x1, C1, x2, C2, wp, slab, arena, g, lds, 0, st);
+    if (split && hf) return TDX_EINVAL;
+    const int rc = split ? small_dispatch<1>(mtw, x1, C1, x2, C2, wp, slab, arena, g, lds, lo, st)
+                   : hf ? small_dispatch<2>(mtw, x1, C1, x2, C2, wp, slab, arena, g, lds, 0, st)
+                         : small_dispatch<0>(mtw, x1, C1, x2, C2, wp, slab, arena, g, lds, 0, st);
     if (rc != TDX_OK) return rc;
     const int64_t total = (int64_t)B * X * Y * Z * (N / 8);
     if (split)
         hipLaunchKernelGGL(conv3_small_reduce_kernel<float>, dim3(ceil_div(total, 256)), dim3(256), 0, st, slab, bias, (float*)out1,
                            D1, (float*)out2, (const float*)add1, (const float*)add2, B, X, Y, Z, N, g.nsplit, data_gradient ? 1 : 0);
+    else if (hf)
+        hipLaunchKernelGGL(conv3_small_reduce_kernel<f16>, dim3(ceil_div(total, 256)), dim3(256), 0, st, slab, bias, (f16*)out1,
+                           D1, (f16*)out2, (const f16*)add1, (const f16*)add2, B, X, Y, Z, N, g.nsplit, data_gradient ? 1 : 0);
     else
         hipLaunchKernelGGL(conv3_small_reduce_kernel<bf16>, dim3(ceil_div(total, 256)), dim3(256), 0, st, slab, bias, (bf16*)out1,
                            D1, (bf16*)out2, (const bf16*)add1, (const bf16*)add2, B, X, Y, Z, N, g.nsplit, data_gradient ? 1 : 0);

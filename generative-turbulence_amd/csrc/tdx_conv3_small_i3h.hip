@@ -1,0 +1,3 @@
+// One instantiation of the small-grid conv kernel (tdx_conv3_small_kernel.h): 3 M tiles per wave, fp16 tensors.
+#include "tdx_conv3_small_kernel.h"
+SMALL_INSTANCE_F16(3, conv3_small_go_3h)

@@ -1,0 +1,3 @@
+// One instantiation of the small-grid conv kernel (tdx_conv3_small_kernel.h): 5 M tiles per wave, fp16 tensors.
+#include "tdx_conv3_small_kernel.h"
+SMALL_INSTANCE_F16(5, conv3_small_go_5h)

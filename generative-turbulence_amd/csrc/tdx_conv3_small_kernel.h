@@ -38,7 +38,8 @@ struct SmallGeom {
 // the computing waves at the slice barrier, as in tdx_conv3_ring.hip; the computing waves carry no vector-memory
 // instruction besides their final stores.
 #define SM_LOADERS 4
-template <int MTW, bool SPLIT>
+// HF (SPLIT = false only): the 16-bit tensors and the packed weight are IEEE half instead of bfloat16 (H16<HF>).
+template <int MTW, bool SPLIT, bool HF>
 __global__ void __launch_bounds__(256 + 64 * SM_LOADERS, 1)
 conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict__ x2_, int C2, const bf16* __restrict__ wp,
                    float* __restrict__ slab, const void* __restrict__ zero16, SmallGeom g, int64_t lo_offset) {
@@ -225,7 +226,7 @@ conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict_
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w, xl, acc[i], 0, 0, 0);
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.wl, xh, acc[i], 0, 0, 0);
                 } else {
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.w, f.x[i], acc[i], 0, 0, 0);
+                    acc[i] = H16<HF>::mfma(f.w, f.x[i], acc[i]);
                 }
             }
         };
@@ -283,9 +284,10 @@ conv3_small_kernel(const void* __restrict__ x1_, int C1, const void* __restrict_
 // instantiations build in parallel), declared here for the dispatcher in tdx_conv3_small.hip
 #define SMALL_GO_ARGS const void* x1, int C1, const void* x2, int C2, const void* wp, float* slab, const void* zero16, \
                       const SmallGeom& g, size_t lds, int64_t lo_offset, hipStream_t st
-template <int MTW, bool SPLIT>
+template <int MTW, bool SPLIT, bool HF = false>
 static int small_go(SMALL_GO_ARGS) {
-    auto kern = conv3_small_kernel<MTW, SPLIT>;
+    static_assert(!(SPLIT && HF), "split precision has bf16 halves");
+    auto kern = conv3_small_kernel<MTW, SPLIT, HF>;
     static size_t attr = 0;
     if (lds > attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -299,4 +301,6 @@ static int small_go(SMALL_GO_ARGS) {
 }
 #define SMALL_INSTANCE(MTW, SPLIT, NAME) \
     int NAME(SMALL_GO_ARGS) { return small_go<MTW, SPLIT>(x1, C1, x2, C2, wp, slab, zero16, g, lds, lo_offset, st); }
+#define SMALL_INSTANCE_F16(MTW, NAME) \
+    int NAME(SMALL_GO_ARGS) { return small_go<MTW, false, true>(x1, C1, x2, C2, wp, slab, zero16, g, lds, lo_offset, st); }
 

@@ -84,7 +84,8 @@ __device__ unsigned long long* w3_stamps_dev;
 #define W3_T() do { } while (0)
 #endif
 
-template <int NT>
+// HF: operand format (H16<HF>: bf16 or fp16 words behind the bf16-typed pointers)
+template <int NT, bool HF>
 __global__ void __launch_bounds__(256, NT == 2 ? 1 : 2)
 conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2,
                         const bf16* __restrict__ dy, float* __restrict__ dwp, float* __restrict__ dbias, WgradView gv,
@@ -190,8 +191,8 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                 const unsigned wds[4] = {greg[i].x, greg[i].y, greg[i].z, greg[i].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    bs[2 * e] += __uint_as_float(wds[e] << 16);
-                    bs[2 * e + 1] += __uint_as_float(wds[e] & 0xffff0000u);
+                    bs[2 * e] += H16<HF>::lo(wds[e]);
+                    bs[2 * e + 1] += H16<HF>::hi(wds[e]);
                 }
             }
         }
@@ -248,7 +249,7 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                     if (t == 0) read_b(so, B1);
     #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[t], B0[nt], acc[t][nt], 0, 0, 0);
+                        acc[t][nt] = H16<HF>::mfma(A0[t], B0[nt], acc[t][nt]);
                     if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NT, 0);
                     else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
@@ -259,7 +260,7 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                     if (t == 0) read_b(sn, B0);
     #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[t], B1[nt], acc[t][nt], 0, 0, 0);
+                        acc[t][nt] = H16<HF>::mfma(A1[t], B1[nt], acc[t][nt]);
                     if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * NT, 0);
                     else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
@@ -278,7 +279,7 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                     const bf16x8 af = read_a(soff, t);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf[nt], acc[t][nt], 0, 0, 0);
+                        acc[t][nt] = H16<HF>::mfma(af, bf[nt], acc[t][nt]);
                 }
             }
         }
@@ -334,13 +335,13 @@ conv3_wgrad_mfma_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
 
 int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias,
                             int B, int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs,
-                            int* nslab_out) {
+                            int* nslab_out, bool hf) {
     {   // deep U-Net levels: packed-K kernel (tdx_conv3_wgrad_small.hip); TDX_ESHAPE = not such a case
-        int rs = conv3_wgrad_small_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st, slabs, max_slabs, nslab_out);
+        int rs = conv3_wgrad_small_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st, slabs, max_slabs, nslab_out, hf);
         if (rs != TDX_ESHAPE) return rs;
 #ifndef W3_STAMPS
         // fine levels: the producer / consumer form (8 computing + 4 loader waves)
-        rs = conv3_wgrad_ring_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st, slabs, max_slabs, nslab_out);
+        rs = conv3_wgrad_ring_launch(x1, C1, x2, C2, dy, dwp, dbias, B, X, Y, Z, Cout, st, slabs, max_slabs, nslab_out, hf);
         if (rs != TDX_ESHAPE) return rs;
 #endif
     }
@@ -382,15 +383,16 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
     const int64_t slab_stride = use_slabs ? (int64_t)27 * Cin * Cout : 0;
     float* out = use_slabs ? slabs : dwp;
     if (nslab_out) *nslab_out = use_slabs ? nsplit : 0;
-#define W3_LAUNCH(NTV)                                                                                               \
+#define W3_LAUNCH(NTV, HFV)                                                                                          \
     do {                                                                                                             \
-        auto kern = conv3_wgrad_mfma_kernel<NTV>;                                                                    \
+        auto kern = conv3_wgrad_mfma_kernel<NTV, HFV>;                                                                  \
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return (int)e;                                                                          \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2, (const bf16*)dy, \
                            out, dbias, g, Cout, nsplit, n_ci, slab_stride);                               \
     } while (0)
-    if (NT == 2) W3_LAUNCH(2); else W3_LAUNCH(1);
+    if (NT == 2) { if (hf) W3_LAUNCH(2, true); else W3_LAUNCH(2, false); }
+    else { if (hf) W3_LAUNCH(1, true); else W3_LAUNCH(1, false); }
 #undef W3_LAUNCH
     return tdx_launch_status();
 }

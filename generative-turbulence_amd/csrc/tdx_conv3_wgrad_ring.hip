@@ -91,7 +91,8 @@ __device__ __forceinline__ void wr_barrier() {
     asm volatile("" ::: "memory");
 }
 
-template <int NTN>
+// HF: operand format (H16<HF>: bf16 or fp16 words behind the bf16-typed pointers)
+template <int NTN, bool HF>
 __global__ void __launch_bounds__(768, 3)
 conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2, const bf16* __restrict__ dy,
                         float* __restrict__ dwp, float* __restrict__ dbias, WgradRingView gv, int Cout, int nsplit, int n_ci_tiles,
@@ -194,9 +195,7 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     // the bias gradient comes from a slot a wave does not need for a tap: it multiplies ones with a dy N tile
     const bool bias_slot = NTN == 2 ? cnt == 6 : wave == 7;   // NTN = 2: waves 6, 7 (N tile wave - 6); NTN = 1: wave 7
-    bf16x8 ones;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    const bf16x8 ones = H16<HF>::ones();
 
     // The brick loop, specialised at compile time (NTN = 2: on the parity of the wave's first pair = which slots share an x
     // fragment; NTN = 1: on whether the wave's fourth slot is in use).  The K-step loop stays ROLLED, two steps per trip (dy
@@ -237,35 +236,35 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                     const bf16x8 a6 = bias_slot ? ones : A[3];
                     const bf16x8 b6 = bias_slot ? (wave == 7 ? Bq[cur][1] : Bq[cur][0]) : (ODD ? Bq[cur][1] : Bq[cur][0]);
                     if (!ODD) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bq[cur][0], acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bq[cur][1], acc[1], 0, 0, 0);
+                        acc[0] = H16<HF>::mfma(A[0], Bq[cur][0], acc[0]);
+                        acc[1] = H16<HF>::mfma(A[0], Bq[cur][1], acc[1]);
                         A[0] = read_a(sn, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][0], acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][1], acc[3], 0, 0, 0);
+                        acc[2] = H16<HF>::mfma(A[1], Bq[cur][0], acc[2]);
+                        acc[3] = H16<HF>::mfma(A[1], Bq[cur][1], acc[3]);
                         A[1] = read_a(sn, 1);
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][0], acc[4], 0, 0, 0);
-                        acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][1], acc[5], 0, 0, 0);
+                        acc[4] = H16<HF>::mfma(A[2], Bq[cur][0], acc[4]);
+                        acc[5] = H16<HF>::mfma(A[2], Bq[cur][1], acc[5]);
                         A[2] = read_a(sn, 2);
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a6, b6, acc[6], 0, 0, 0);
+                        acc[6] = H16<HF>::mfma(a6, b6, acc[6]);
                         A[3] = read_a(sn, 3);
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     } else {
-                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[0], Bq[cur][1], acc[0], 0, 0, 0);
+                        acc[0] = H16<HF>::mfma(A[0], Bq[cur][1], acc[0]);
                         A[0] = read_a(sn, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][0], acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[1], Bq[cur][1], acc[2], 0, 0, 0);
+                        acc[1] = H16<HF>::mfma(A[1], Bq[cur][0], acc[1]);
+                        acc[2] = H16<HF>::mfma(A[1], Bq[cur][1], acc[2]);
                         A[1] = read_a(sn, 1);
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][0], acc[3], 0, 0, 0);
-                        acc[4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[2], Bq[cur][1], acc[4], 0, 0, 0);
+                        acc[3] = H16<HF>::mfma(A[2], Bq[cur][0], acc[3]);
+                        acc[4] = H16<HF>::mfma(A[2], Bq[cur][1], acc[4]);
                         A[2] = read_a(sn, 2);
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        acc[5] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[3], Bq[cur][0], acc[5], 0, 0, 0);
-                        acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a6, b6, acc[6], 0, 0, 0);
+                        acc[5] = H16<HF>::mfma(A[3], Bq[cur][0], acc[5]);
+                        acc[6] = H16<HF>::mfma(a6, b6, acc[6]);
                         A[3] = read_a(sn, 3);
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     }
@@ -273,12 +272,12 @@ conv3_wgrad_ring_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restr
                     // one slot per tap: every x fragment feeds one MFMA and is re-read for the next step right behind it
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[t], Bq[cur][0], acc[t], 0, 0, 0);
+                        acc[t] = H16<HF>::mfma(A[t], Bq[cur][0], acc[t]);
                         A[t] = read_a(sn, t);
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     }
                     if (ODD) {  // the fourth tap (waves 0-2) or the bias column sums (wave 7)
-                        acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bias_slot ? ones : A[3], Bq[cur][0], acc[3], 0, 0, 0);
+                        acc[3] = H16<HF>::mfma(bias_slot ? ones : A[3], Bq[cur][0], acc[3]);
                         A[3] = read_a(sn, 3);
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                     }
@@ -324,7 +323,7 @@ bool conv3_wgrad_ring_supported(int C1, int C2, int Cout) {
 
 // same contract as conv3_wgrad_mfma_launch; TDX_ESHAPE = not a case for this kernel
 int conv3_wgrad_ring_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias, int B, int X,
-                            int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out) {
+                            int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out, bool hf) {
     if (!conv3_wgrad_ring_supported(C1, C2, Cout)) return TDX_ESHAPE;
     const int Cin = C1 + C2;
     // local axes: brick 4 x 8 x 8; the short axis goes where it leaves the fewest bricks
@@ -362,18 +361,20 @@ int conv3_wgrad_ring_launch(const void* x1, int C1, const void* x2, int C2, cons
     const int64_t slab_stride = use_slabs ? (int64_t)27 * Cin * Cout : 0;
     float* out = use_slabs ? slabs : dwp;
     if (nslab_out) *nslab_out = use_slabs ? nsplit : 0;
-    static bool attr_set[2] = {false, false};
-    const void* kern = NTN == 2 ? (const void*)conv3_wgrad_ring_kernel<2> : (const void*)conv3_wgrad_ring_kernel<1>;
-    if (!attr_set[NTN - 1]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set[NTN - 1] = true;
-    }
-    if (NTN == 2)
-        hipLaunchKernelGGL(conv3_wgrad_ring_kernel<2>, dim3((unsigned)(ntiles * nsplit)), dim3(768), lds, st, (const bf16*)x1, C1,
-                           (const bf16*)x2, C2, (const bf16*)dy, out, dbias, g, Cout, nsplit, n_ci, slab_stride, tdx_scratch_ptr());
-    else
-        hipLaunchKernelGGL(conv3_wgrad_ring_kernel<1>, dim3((unsigned)(ntiles * nsplit)), dim3(768), lds, st, (const bf16*)x1, C1,
-                           (const bf16*)x2, C2, (const bf16*)dy, out, dbias, g, Cout, nsplit, n_ci, slab_stride, tdx_scratch_ptr());
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
+#define WR_GO(NTNV, HFV)                                                                                                          \
+    do {                                                                                                                          \
+        auto kern = conv3_wgrad_ring_kernel<NTNV, HFV>;                                                                           \
+        if (!attr_set[NTNV - 1][HFV]) {                                                                                           \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+            if (e != hipSuccess) return (int)e;                                                                                   \
+            attr_set[NTNV - 1][HFV] = true;                                                                                       \
+        }                                                                                                                         \
+        hipLaunchKernelGGL(kern, dim3((unsigned)(ntiles * nsplit)), dim3(768), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2, \
+                           (const bf16*)dy, out, dbias, g, Cout, nsplit, n_ci, slab_stride, tdx_scratch_ptr());                   \
+    } while (0)
+    if (NTN == 2) { if (hf) WR_GO(2, true); else WR_GO(2, false); }
+    else { if (hf) WR_GO(1, true); else WR_GO(1, false); }
+#undef WR_GO
     return tdx_launch_status();
 }

@@ -55,7 +55,8 @@ __device__ __forceinline__ void ws_dma16(const void* gsrc, const unsigned char* 
                  : "=&s"(keep) : "v"(gsrc), "s"(a) : "memory");
 }
 
-template <int NT>
+// HF: operand format (H16<HF>: bf16 or fp16 words behind the bf16-typed pointers)
+template <int NT, bool HF>
 __global__ void __launch_bounds__(256, 1)
 conv3_wgrad_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __restrict__ x2, int C2, const bf16* __restrict__ dy,
                          float* __restrict__ dwp, float* __restrict__ dbias, WsGeom g, int Cout, int nsplit, int n_ci_tiles,
@@ -127,9 +128,7 @@ conv3_wgrad_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __rest
     // multiplies an all-ones A fragment instead of a duplicate tap: every row of that tile is sum_v dy[v][co].
     const bool do_bias = dbias != nullptr && ci0 == 0;
     const bool ones_slot = wave == 3;
-    bf16x8 ones;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+    const bf16x8 ones = H16<HF>::ones();
 
     // ---- staging of one row group by LDS-DMA: a piece = 64 lanes x 16 B = 16 rows of 64 B
     auto group_shape = [&](int grp, int& b0, int& x0, int& nb, int& nx) {
@@ -204,7 +203,7 @@ conv3_wgrad_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __rest
             for (int t = 0; t < WS_TAPS_PER_WAVE; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[t][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[t], Bf[nt], acc[t][nt], 0, 0, 0);
+                    acc[t][nt] = H16<HF>::mfma(A[t], Bf[nt], acc[t][nt]);
         };
         constexpr int NRD = 2 * WS_TAPS_PER_WAVE + 2 + 2 * NT, NMF = WS_TAPS_PER_WAVE * NT;
         read_a(min(1, nsteps - 1), A0);
@@ -254,7 +253,7 @@ conv3_wgrad_small_kernel(const bf16* __restrict__ x1, int C1, const bf16* __rest
 
 // Launch if this is a small-grid case; TDX_ESHAPE otherwise (the caller then takes the brick kernel).
 int conv3_wgrad_small_launch(const void* x1, int C1, const void* x2, int C2, const void* dy, float* dwp, float* dbias, int B,
-                             int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out) {
+                             int X, int Y, int Z, int Cout, hipStream_t st, float* slabs, int max_slabs, int* nslab_out, bool hf) {
     static const int mode = getenv("TDX_WGRAD_SMALL") ? atoi(getenv("TDX_WGRAD_SMALL")) : 1;  // A/B switch
     if (mode == 0) return TDX_ESHAPE;
     const int Cin = C1 + C2;
@@ -291,9 +290,9 @@ int conv3_wgrad_small_launch(const void* x1, int C1, const void* x2, int C2, con
     float* out = use_slabs ? slabs : dwp;
     if (nslab_out) *nslab_out = use_slabs ? nsplit : 0;
     dim3 grid((unsigned)(ntiles * nsplit));
-#define WS_LAUNCH(NTV)                                                                                                \
+#define WS_LAUNCH(NTV, HFV)                                                                                           \
     do {                                                                                                              \
-        auto kern = conv3_wgrad_small_kernel<NTV>;                                                                    \
+        auto kern = conv3_wgrad_small_kernel<NTV, HFV>;                                                               \
         static size_t attr = 0;                                                                                       \
         if (lds > attr) {                                                                                             \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -303,7 +302,8 @@ int conv3_wgrad_small_launch(const void* x1, int C1, const void* x2, int C2, con
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16*)x1, C1, (const bf16*)x2, C2, (const bf16*)dy, out, \
                            dbias, g, Cout, nsplit, n_ci, slab_stride);                                                \
     } while (0)
-    if (NT == 2) WS_LAUNCH(2); else WS_LAUNCH(1);
+    if (NT == 2) { if (hf) WS_LAUNCH(2, true); else WS_LAUNCH(2, false); }
+    else { if (hf) WS_LAUNCH(1, true); else WS_LAUNCH(1, false); }
 #undef WS_LAUNCH
     return tdx_launch_status();
 }

@@ -63,6 +63,9 @@ __global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, int64_
         else if ((di) == TDX_F32 && (dto) == TDX_BF16) { typedef float TI; typedef bf16 TO; CALL; } \
         else if ((di) == TDX_BF16 && (dto) == TDX_F32) { typedef bf16 TI; typedef float TO; CALL; } \
         else if ((di) == TDX_BF16 && (dto) == TDX_BF16) { typedef bf16 TI; typedef bf16 TO; CALL; } \
+        else if ((di) == TDX_F32 && (dto) == TDX_F16) { typedef float TI; typedef f16 TO; CALL; }   \
+        else if ((di) == TDX_F16 && (dto) == TDX_F32) { typedef f16 TI; typedef float TO; CALL; }   \
+        else if ((di) == TDX_F16 && (dto) == TDX_F16) { typedef f16 TI; typedef f16 TO; CALL; }     \
         else return TDX_EDTYPE;                                                    \
     } while (0)
 

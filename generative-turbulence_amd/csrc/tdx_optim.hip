@@ -40,9 +40,13 @@ opt_sumsq_kernel(const TdxOptTensor* __restrict__ table, const int* __restrict__
     if (threadIdx.x == 0) partial[c] = red[0] + red[1] + red[2] + red[3];
 }
 
-// out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0)
+// out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (1 if max_norm <= 0).
+// SCALED (loss-scaled gradients, fp16 training): the stored gradients are inv_scale^-1 times the true ones -- out[0] is the
+// TRUE norm, out[1] the factor that takes a stored gradient to the clipped true one (inv_scale x clip coefficient), and
+// out[2] = 1 when the norm is not finite (an overflow somewhere in the fp16 backward: the step must be skipped), else 0.
+template <bool SCALED>
 __global__ void __launch_bounds__(OPT_THREADS)
-opt_norm_finalize_kernel(const float* __restrict__ partial, int nchunks, float max_norm, float* __restrict__ out) {
+opt_norm_finalize_kernel(const float* __restrict__ partial, int nchunks, float max_norm, float inv_scale, float* __restrict__ out) {
     double s = 0.0;
     for (int i = threadIdx.x; i < nchunks; i += OPT_THREADS) s += (double)partial[i];
     __shared__ double red[OPT_THREADS / 64];
@@ -50,9 +54,17 @@ opt_norm_finalize_kernel(const float* __restrict__ partial, int nchunks, float m
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float norm = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+        float norm = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+        if (SCALED) norm *= inv_scale;
+        const float coef = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
         out[0] = norm;
-        out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (norm + 1e-6f)) : 1.0f;
+        if (SCALED) {
+            const bool bad = !(fabsf(norm) <= 3.0e38f);  // inf or nan
+            out[1] = bad ? 0.f : coef * inv_scale;
+            out[2] = bad ? 1.f : 0.f;
+        } else {
+            out[1] = coef;
+        }
     }
 }
 
@@ -75,10 +87,12 @@ __device__ __forceinline__ void radam_elem(float& p, float g, float& m, float& v
 template <bool WRITE_GRAD>
 __global__ void __launch_bounds__(OPT_THREADS)
 opt_radam_kernel(const TdxOptTensor* __restrict__ table, const int* __restrict__ chunk_tensor,
-                 const int64_t* __restrict__ chunk_off, const float* __restrict__ clip, RAdamArgs a) {
+                 const int64_t* __restrict__ chunk_off, const float* __restrict__ clip, const float* __restrict__ skip,
+                 RAdamArgs a) {
     const int c = blockIdx.x;
     const TdxOptTensor t = table[chunk_tensor[c]];
     if (t.grad == nullptr) return;  // parameter without a gradient this step: untouched, as torch does
+    if (skip != nullptr && *skip != 0.f) return;  // non-finite loss-scaled gradients: nothing is touched (GradScaler's skipped step)
     const float coef = clip ? clip[1] : 1.0f;
     const int64_t o = chunk_off[c];
     const int64_t n = min((int64_t)OPT_CHUNK, t.numel - o);
@@ -117,13 +131,22 @@ extern "C" int tdx_grad_norm(const TdxOptTensor* table, const int* chunk_tensor,
     TDX_CHECK_ARG(table && chunk_tensor && chunk_off && partial && out && nchunks > 0);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(opt_sumsq_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, st, table, chunk_tensor, chunk_off, partial);
-    hipLaunchKernelGGL(opt_norm_finalize_kernel, dim3(1), dim3(OPT_THREADS), 0, st, partial, nchunks, max_norm, out);
+    hipLaunchKernelGGL(opt_norm_finalize_kernel<false>, dim3(1), dim3(OPT_THREADS), 0, st, partial, nchunks, max_norm, 1.0f, out);
     return tdx_launch_status();
 }
 
-extern "C" int tdx_radam_step(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
-                              const float* clip, int64_t step, float lr, float beta1, float beta2, float eps,
-                              int write_grad, void* stream) {
+extern "C" int tdx_grad_norm_scaled(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
+                                    float max_norm, float inv_scale, float* partial, float* out, void* stream) {
+    TDX_CHECK_ARG(table && chunk_tensor && chunk_off && partial && out && nchunks > 0 && inv_scale > 0.f);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(opt_sumsq_kernel, dim3(nchunks), dim3(OPT_THREADS), 0, st, table, chunk_tensor, chunk_off, partial);
+    hipLaunchKernelGGL(opt_norm_finalize_kernel<true>, dim3(1), dim3(OPT_THREADS), 0, st, partial, nchunks, max_norm, inv_scale, out);
+    return tdx_launch_status();
+}
+
+static int radam_step_impl(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
+                           const float* clip, const float* skip, int64_t step, float lr, float beta1, float beta2, float eps,
+                           int write_grad, void* stream) {
     TDX_CHECK_ARG(table && chunk_tensor && chunk_off && nchunks > 0 && step >= 1);
     TDX_CHECK_ARG(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f);
     // scalar schedule of torch.optim.radam._single_tensor_radam, in double like the Python floats there
@@ -138,8 +161,22 @@ extern "C" int tdx_radam_step(const TdxOptTensor* table, const int* chunk_tensor
     a.rect = rho_t > 5.0 ? (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t)) : -1.0f;
     hipStream_t st = as_stream(stream);
     if (write_grad)
-        hipLaunchKernelGGL(opt_radam_kernel<true>, dim3(nchunks), dim3(OPT_THREADS), 0, st, table, chunk_tensor, chunk_off, clip, a);
+        hipLaunchKernelGGL(opt_radam_kernel<true>, dim3(nchunks), dim3(OPT_THREADS), 0, st, table, chunk_tensor, chunk_off, clip, skip, a);
     else
-        hipLaunchKernelGGL(opt_radam_kernel<false>, dim3(nchunks), dim3(OPT_THREADS), 0, st, table, chunk_tensor, chunk_off, clip, a);
+        hipLaunchKernelGGL(opt_radam_kernel<false>, dim3(nchunks), dim3(OPT_THREADS), 0, st, table, chunk_tensor, chunk_off, clip, skip, a);
     return tdx_launch_status();
+}
+
+extern "C" int tdx_radam_step(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
+                              const float* clip, int64_t step, float lr, float beta1, float beta2, float eps,
+                              int write_grad, void* stream) {
+    return radam_step_impl(table, chunk_tensor, chunk_off, nchunks, clip, nullptr, step, lr, beta1, beta2, eps, write_grad, stream);
+}
+
+extern "C" int tdx_radam_step_scaled(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
+                                     const float* scaled_norm, int64_t step, float lr, float beta1, float beta2, float eps,
+                                     int write_grad, void* stream) {
+    TDX_CHECK_ARG(scaled_norm);
+    return radam_step_impl(table, chunk_tensor, chunk_off, nchunks, scaled_norm, scaled_norm + 2, step, lr, beta1, beta2, eps,
+                           write_grad, stream);
 }

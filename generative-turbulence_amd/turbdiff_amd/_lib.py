@@ -18,7 +18,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("TDX_LIB", _HERE / "libtdx_hip.so"))  # TDX_LIB: kernel-development builds
 
 F32, BF16 = 0, 1
-F16 = 3  # TDX_F16: the attention entry points only
+F16 = 3  # TDX_F16: IEEE half tensors (fp16 MFMA operands, fp32 accumulation)
 CONV_AUTO, CONV_DIRECT, CONV_MFMA, CONV_SPLIT = 0, 1, 2, 3
 F32_SPLIT = 2  # TDX_F32_SPLIT: pack code of fp32 weights for CONV_SPLIT
 WS_CLEAN = 0x100  # TDX_WS_CLEAN (include/tdx.h)
@@ -91,6 +91,8 @@ SIGNATURES = {
     "tdx_opt_chunk_elems": (_i64, []),
     "tdx_grad_norm": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "tdx_radam_step": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
+    "tdx_grad_norm_scaled": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
+    "tdx_radam_step_scaled": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
 }
 
 FILM_MAX_LAYERS = 32  # TDX_FILM_MAX_LAYERS
@@ -201,14 +203,17 @@ def scratch_arena(device=None):
     return _SCRATCH.get(_ACTIVE) if _SCRATCH is not None else None
 
 
+H16_DTYPES = (torch.bfloat16, torch.float16)  # 16-bit storage formats that share the matrix-core kernels
+
+
 def dtype_code(dt: torch.dtype) -> int:
     if dt == torch.float32:
         return F32
     if dt == torch.bfloat16:
         return BF16
     if dt == torch.float16:
-        return F16  # accepted by tdx_attn_fwd / tdx_attn_bwd only; every other entry point answers TDX_EDTYPE
-    raise TypeError(f"tdx kernels support float32 and bfloat16 activations, got {dt}")
+        return F16
+    raise TypeError(f"tdx kernels support float32, bfloat16 and float16 activations, got {dt}")
 
 
 _CONV_IMPLS = {"auto": CONV_AUTO, "direct": CONV_DIRECT, "mfma": CONV_MFMA, "split": CONV_SPLIT}
@@ -368,7 +373,7 @@ KERNEL_DIRECT, KERNEL_BRICK, KERNEL_SMALL, KERNEL_RING = 0, 1, 2, 3  # TDX_KERNE
 def conv3_fwd_meta(C1, C2, Cout, B, X, Y, Z, dt, real=None):
     """Bookkeeping of one forward conv call for the timers: the kernel family that serves it and its algorithmic HBM
     bytes (input + output + weights once; `real` = input channels that carry data)."""
-    es = 2 if dt == torch.bfloat16 else 4
+    es = 2 if dt in H16_DTYPES else 4
     cin = real or (C1 + C2)
     return {"kind": query("tdx_conv3_fwd_kernel", C1, C2, Cout, B, X, Y, Z, dtype_code(dt), conv_impl()),
             "bytes": float((cin + Cout) * B * X * Y * Z * es + 27 * cin * Cout * es)}

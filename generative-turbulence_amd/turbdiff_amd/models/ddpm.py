@@ -389,8 +389,10 @@ class DenoisingModel(nn.Module):
         return {id(b): f for b, f in zip(blocks, films)}
 
     def set_compute_dtype(self, dtype: torch.dtype):
-        """float32 (parity mode) or bfloat16 (activation storage + MFMA operands)."""
-        assert dtype in (torch.float32, torch.bfloat16)
+        """float32 (parity modes), bfloat16 or float16 (activation storage + MFMA operands; float16 = 11 significand bits,
+        the arithmetic of the reference's TF32 GPU runs, at the bfloat16 kernels' speed -- training in it needs a loss scale:
+        training.DiffusionTrainer(compute_mode="fp16"))."""
+        assert dtype in (torch.float32, torch.bfloat16, torch.float16)
         self.compute_dtype = dtype
         return self
 

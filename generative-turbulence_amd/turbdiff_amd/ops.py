@@ -1,6 +1,6 @@
 """Differentiable operators of the hot path, executed by the HIP kernels in libtdx_hip.so.
 
-Activations are NDHWC tensors ``(B, X, Y, Z, C)`` in float32 or bfloat16; parameters stay in
+Activations are NDHWC tensors ``(B, X, Y, Z, C)`` in float32, bfloat16 or float16; parameters stay in
 the reference's shapes and float32 (so state_dicts round-trip).  Each
 ``torch.autograd.Function`` here replaces one stock PyTorch call of the reference:
 
@@ -338,8 +338,8 @@ def prefetch_weights(conv3_weights, conv1_weights, dtype: torch.dtype, plan: "Pa
 
 
 def conv3_partial_supported(x, weight, n_lead: int) -> bool:
-    """tdx_conv3_fwd_partial: bf16 MFMA path on the leading n_lead input channels."""
-    return (x.dtype == torch.bfloat16 and n_lead % 16 == 0 and weight.shape[0] % 32 == 0 and x.shape[-1] % 8 == 0
+    """tdx_conv3_fwd_partial: 16-bit MFMA path on the leading n_lead input channels."""
+    return (x.dtype in L.H16_DTYPES and n_lead % 16 == 0 and weight.shape[0] % 32 == 0 and x.shape[-1] % 8 == 0
             and L.conv_impl() != L.CONV_DIRECT)
 
 
@@ -990,7 +990,7 @@ class _ResnetBlock(torch.autograd.Function):
             res = x1
         else:
             wr2 = wr.detach().reshape(Cout, Cin).contiguous()
-            if FUSE_SKIP_TAIL and dt == torch.bfloat16 and C1 % 32 == 0 and C2 % 32 == 0 and Cout % 32 == 0:
+            if FUSE_SKIP_TAIL and dt in L.H16_DTYPES and C1 % 32 == 0 and C2 % 32 == 0 and Cout % 32 == 0:
                 # y = silu(GN(h2)) + conv1x1([x1|x2]) in one pass: the skip tensor is never written or re-read
                 L.call("tdx_conv1_fwd_gn", L.ptr(x1), C1, L.ptr(x2), C2, L.ptr(_conv1_wt(wr)), Cout, L.ptr(br), L.ptr(h2),
                        L.ptr(st2), L.ptr(g2), L.ptr(be2), groups, L.ptr(y), B, V, Cout, code, st)

@@ -69,17 +69,19 @@ def _metric_placeholders():
 # torch.set_float32_matmul_precision(config.matmul_precision) of the reference's entry points (train.py,
 # scripts/eval_ckpt.py:57) -> compute mode here: "highest" keeps IEEE fp32 products (fp32 MFMA convs); "high" and
 # "medium" allow reduced-precision products on fp32 tensors (TF32 / bf16 in stock PyTorch) -> split-precision convs
-# (bf16 hi + lo: 16 significand bits, more than TF32's 10).  bf16 STORAGE is never implied by a reference config;
-# ask for it explicitly (compute_mode="bf16").
+# (bf16 hi + lo: 16 significand bits, more than TF32's 10).  16-bit STORAGE is never implied by a reference config;
+# ask for it explicitly: compute_mode="fp16" (IEEE half tensors + fp16 MFMA operands: TF32's 11 significand bits at the
+# bf16 kernels' speed; training runs under a power-of-two loss scale, optim.ClipRAdam) or "bf16" (8 bits, no scale needed).
 MATMUL_PRECISION_TO_MODE = {"highest": "f32", "high": "f32s", "medium": "f32s"}
-COMPUTE_MODES = ("f32", "f32s", "bf16")
+COMPUTE_MODES = ("f32", "f32s", "bf16", "fp16")
+_MODE_DTYPE = {"f32": torch.float32, "f32s": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 def apply_compute_mode(net: DenoisingModel, mode: str) -> None:
-    """f32: fp32 tensors, IEEE fp32 MFMA convs; f32s: fp32 tensors, split-precision convs; bf16: bf16 tensors."""
+    """f32: fp32 tensors, IEEE fp32 MFMA convs; f32s: fp32 tensors, split-precision convs; bf16 / fp16: 16-bit tensors."""
     if mode not in COMPUTE_MODES:
         raise ValueError(f"compute mode {mode!r} not in {COMPUTE_MODES}")
-    net.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
+    net.set_compute_dtype(_MODE_DTYPE[mode])
     # per model, not per process: a second trainer in another mode leaves this one's arithmetic alone
     net.conv_impl = "split" if mode == "f32s" else "auto"
 
@@ -140,7 +142,7 @@ class DiffusionTrainer(nn.Module):
                              u_net_levels=u_net_levels, actfn=ACTFNS[actfn], norm_type=norm_type,
                              with_geometry_embedding=with_geometry_embedding)
         if compute_mode is None:
-            compute_mode = "bf16" if compute_dtype == torch.bfloat16 else None
+            compute_mode = {torch.bfloat16: "bf16", torch.float16: "fp16"}.get(compute_dtype)
         self.compute_mode = compute_mode
         if compute_mode is not None:
             apply_compute_mode(net, compute_mode)
@@ -158,6 +160,9 @@ class DiffusionTrainer(nn.Module):
         self.elbo_weight, self.detach_elbo_mean, self.actfn = elbo_weight, detach_elbo_mean, actfn
         self.gradient_clip_val = gradient_clip_val
         self.fused_optimizer = True  # ClipRAdam on GPU; False -> clip_grad_norm_ + torch.optim.RAdam
+        # fp16 training: initial loss scale (a power of two), or None = chosen from the first batch so that the seed of the
+        # backward pass, 2 (eps_hat - eps) / (B F n_cells), lands near 2^-3 (initial_loss_scale)
+        self.loss_scale = None
         self._opt = self._sched = None
         self.ddp = None  # set to a parallel.BucketedDataParallel(self) for multi-GPU training
         self.stats = None
@@ -279,8 +284,14 @@ class DiffusionTrainer(nn.Module):
     def _global_trajectory_ids(B: int):
         import torch.distributed as dist
 
-        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-        return [rank * B + i for i in range(B)]
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return list(range(B))
+        # offset = the batch sizes of the lower ranks (ranks may hold different B: a ragged last validation batch), not
+        # rank * local B, which made ids overlap -- and identically seeded ranks then drew identical noise streams
+        sizes = [None] * dist.get_world_size()
+        dist.all_gather_object(sizes, int(B))
+        first = sum(sizes[: dist.get_rank()])
+        return [first + i for i in range(B)]
 
     @torch.no_grad()
     def validation_step(self, batch, store):
@@ -298,14 +309,28 @@ class DiffusionTrainer(nn.Module):
         if self.optimizer == "radam" and self.fused_optimizer and params[0].is_cuda:
             from .optim import ClipRAdam  # clip + RAdam fused; same arithmetic as the two torch calls
 
-            opt = ClipRAdam(params, lr=self.learning_rate, max_norm=self.gradient_clip_val or None)
+            opt = ClipRAdam(params, lr=self.learning_rate, max_norm=self.gradient_clip_val or None,
+                            loss_scale=self._loss_scale_for_optimizer())
         else:
+            if self.model.model.compute_dtype == torch.float16:
+                raise RuntimeError("fp16 training needs the loss-scaling optimiser: optimizer='radam' with fused_optimizer on a GPU")
             opt = klass(params, lr=self.learning_rate)
         sched = None
         if self.lr_decay == "exp":
             rate = math.log(self.min_learning_rate / self.learning_rate) / self.max_train_steps
             sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: math.exp(rate * min(step, self.max_train_steps)))
         return opt, sched
+
+    @staticmethod
+    def initial_loss_scale(n_loss_elements: int) -> float:
+        """Power-of-two loss scale for an error mean over `n_loss_elements` = B F n_cells values: the backward pass of
+        S * loss then starts from ~(eps_hat - eps) / 8 instead of from 1e-7, far below fp16's smallest normal number."""
+        return float(2.0 ** max(0, math.floor(math.log2(max(n_loss_elements, 1))) - 4))
+
+    def _loss_scale_for_optimizer(self):
+        if self.model.model.compute_dtype != torch.float16:
+            return None
+        return self.loss_scale if self.loss_scale is not None else 2.0**16
 
     def enable_graph_step(self, on: bool = True):
         """fit_step runs forward + backward as ONE captured hipGraph per input signature (GraphedTrainingStep) instead of
@@ -318,7 +343,12 @@ class DiffusionTrainer(nn.Module):
     def fit_step(self, batch):
         """zero_grad -> training_step -> backward -> [grad all-reduce] -> clip -> optimizer -> LR schedule."""
         if self._opt is None:
+            if self.loss_scale is None and self.model.model.compute_dtype == torch.float16:
+                with torch.no_grad():
+                    x0, _ = self._model_input(batch)  # (first step only: the batch size behind the loss's mean)
+                self.loss_scale = self.initial_loss_scale(int(x0.shape[0]) * int(x0.shape[1]) * int(self._cell_idx(batch).numel()))
             self._opt, self._sched = self.configure_optimizers()
+        scale_loss = getattr(self._opt, "scale_loss", None)
         gs = getattr(self, "_graph_step", None)
         if gs is not None:
             if self.ddp is not None:
@@ -327,7 +357,7 @@ class DiffusionTrainer(nn.Module):
         else:
             self._opt.zero_grad(set_to_none=True)
             loss = self.training_step(batch)
-            loss.backward()
+            (loss if scale_loss is None else scale_loss(loss)).backward()
         if self.ddp is not None:
             self.ddp.finish()
         if self.gradient_clip_val and not hasattr(self._opt, "max_norm"):
@@ -390,12 +420,18 @@ class GraphedTrainingStep:
         m = self.tr.model.model
         return (tuple(x.shape), str(x.device), tuple(sorted((str(k), tuple(v.shape), str(v.dtype), bool(v.requires_grad))
                                                             for k, v in self._tensors(C).items())),
-                getattr(m, "compute_dtype", None), getattr(m, "conv_impl", None), L.conv_impl())
+                getattr(m, "compute_dtype", None), getattr(m, "conv_impl", None), L.conv_impl(),
+                # what else the capture bakes in: parameter storage and which of them take gradients, the loss
+                # configuration, whether the backward runs on a scaled loss
+                tuple((id(p), p.data_ptr(), bool(p.requires_grad)) for p in self.tr.parameters()),
+                self.tr.model.loss_type, bool(self.tr.model.noise_bcs), getattr(self.tr._opt, "loss_scale", None) is not None)
 
     def __call__(self, batch):
         tr = self.tr
         x, C = tr._model_input(batch)
         mask, n_cells = tr.model.domain_mask(tr._cell_idx(batch), x[0, 0].numel())
+        if int(n_cells) <= 0:
+            raise ValueError("no in-domain cells: the loss is a mean over an empty set (tdx_masked_loss rejects it too)")
         sig = self._signature(x, C)
         slot = self.slots.get(sig)
         if slot is None:
@@ -410,6 +446,7 @@ class GraphedTrainingStep:
                 slot.C[k].copy_(v)
             slot.mask.copy_(mask)
             slot.n.fill_(int(n_cells))
+            slot.scale.fill_(float(getattr(tr._opt, "loss_scale", None) or 1.0))  # fp16: the optimiser's current loss scale
             if self.inject:
                 slot.t.copy_(self._draws[0])
                 slot.noise.copy_(self._draws[1])
@@ -421,7 +458,8 @@ class GraphedTrainingStep:
         chain = [(v, slot.C[k].grad) for k, v in self._tensors(C).items() if v.requires_grad]
         if chain:
             torch.autograd.backward([v for v, _ in chain], [g for _, g in chain])
-        return slot.loss.detach()
+        # a fresh tensor per step (a 4-byte copy enqueued behind the replay): slot.loss is overwritten by the next replay
+        return slot.loss.detach().clone()
 
     def _capture(self, x, C, mask, n_cells):
         from . import _lib as L
@@ -436,6 +474,8 @@ class GraphedTrainingStep:
             slot.C[k] = v.detach().clone().requires_grad_(v.requires_grad)
         slot.mask = mask.clone()
         slot.n = torch.tensor([int(n_cells)], dtype=torch.int64, device=dev)
+        slot.scale = torch.ones((), dtype=torch.float32, device=dev)  # loss scale, read when the graph runs
+        scaled = getattr(tr._opt, "loss_scale", None) is not None
         md = SimpleNamespace(cell_idx=None, domain_mask=(slot.mask, slot.n))
         params = [p for p in tr.parameters() if p.requires_grad]
         leaves = params + [v for v in self._tensors(slot.C).values() if v.requires_grad]
@@ -449,7 +489,7 @@ class GraphedTrainingStep:
                 loss, _ = tr.model.p_losses(slot.x, slot.t, slot.C, md, None, noise=slot.noise)
             else:
                 loss, _ = tr.model(slot.x, slot.C, md, None)
-            loss.backward()
+            (loss * slot.scale if scaled else loss).backward()
             return loss
 
         import warnings
@@ -483,6 +523,9 @@ class GraphedTrainingStep:
             slot.loss = body().detach()  # (no autograd graph outlives the capture: its nodes belong to this stream)
         torch.autograd.graph.increment_version([p for p in tr.model.parameters()])
         # parameters the captured backward did not reach get their gradient from the eager chain (cell-type table)
+        # the packed operands the captured launches read and refresh live in the model's pack plans: held here, so that a
+        # plan the model rebuilds later (other parameter storage, other operand format) cannot free them under the graph
+        slot.pack_plans = list(tr.model.model._static_lists()[3].values())
         slot.chained = [p for p in params if p.grad is None]
         slot.grads = [(p, p.grad) for p in params if p.grad is not None]  # the tensors every replay writes
         return slot

@@ -12,7 +12,9 @@
  *     grid (X, Y, Z) and C channels lives at ((((b*X + x)*Y + y)*Z + z)*C + c).  The
  *     reference's NCDHW tensors (B, C, X, Y, Z) are converted at the model boundary by
  *     tdx_ncv_to_nvc / tdx_nvc_to_ncv (or fused into encode/decode).
- *   - dtype: TDX_F32 = 0 (float), TDX_BF16 = 1 (bfloat16 storage, fp32 accumulation).
+ *   - dtype: TDX_F32 = 0 (float), TDX_BF16 = 1 (bfloat16 storage, fp32 accumulation), TDX_F16 = 3 (IEEE half storage,
+ *     fp32 accumulation: the same kernels as TDX_BF16 with v_mfma_f32_32x32x16_f16 -- 11 significand bits, the precision of
+ *     the reference's TF32 GPU convs (train.py:144-156), at the bfloat16 kernels' speed).
  *     Parameters, statistics, gradients of parameters and schedule tables are always f32.
  *   - Every pointer is a DEVICE pointer.  No entry point allocates, frees or synchronises;
  *     work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream),
@@ -50,7 +52,7 @@ extern "C" {
                               split kernel does not cover run as TDX_CONV_AUTO                */
 /* dtype code accepted by tdx_conv3_pack_weight only: fp32 weights packed for TDX_CONV_SPLIT */
 #define TDX_F32_SPLIT 2
-/* fp16 tensors: accepted by tdx_attn_fwd / tdx_attn_bwd only (BASELINE configs[4]: fp16 MFMA QK^T / AV) */
+/* fp16 tensors: every entry point that takes TDX_BF16 takes TDX_F16 (round 6; BASELINE configs[4] names fp16 MFMA QK^T / AV) */
 #define TDX_F16 3
 /* OR-able into `impl` of tdx_conv3_fwd_gn and tdx_conv3_bwd_weight: the caller guarantees that the
  * workspace is all-zero on entry; the call skips its memsets and, as always, leaves the workspace
@@ -414,6 +416,18 @@ int64_t tdx_opt_chunk_elems(void);
  * (1 when max_norm <= 0).  partial: nchunks floats of scratch.  No host synchronisation. */
 int tdx_grad_norm(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
                   float max_norm, float* partial, float* out, void* stream);
+/* The same for LOSS-SCALED gradients (fp16 training: the backward pass ran on S x loss, S = 1 / inv_scale a power of two, so
+ * that fp16 activation gradients stay representable; the reference has no such mode -- its GPU runs are TF32, train.py:144-156).
+ * out: 4 floats -- out[0] = the TRUE gradient norm (stored norm x inv_scale), out[1] = inv_scale x clip coefficient (the
+ * factor from a stored gradient to the clipped true one; 0 when the norm is not finite), out[2] = 1.0 when the norm is
+ * inf / nan (fp16 overflow: tdx_radam_step_scaled then leaves parameters and moments untouched; the host halves S), else 0. */
+int tdx_grad_norm_scaled(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
+                         float max_norm, float inv_scale, float* partial, float* out, void* stream);
+/* tdx_radam_step with scaled_norm = the `out` of tdx_grad_norm_scaled: gradients x scaled_norm[1]; the whole step is a
+ * no-op when scaled_norm[2] != 0. */
+int tdx_radam_step_scaled(const TdxOptTensor* table, const int* chunk_tensor, const int64_t* chunk_off, int nchunks,
+                          const float* scaled_norm, int64_t step, float lr, float beta1, float beta2, float eps,
+                          int write_grad, void* stream);
 /* One RAdam step number `step` (1-based) with gradients scaled by clip[1] (clip: the `out` of
  * tdx_grad_norm, or NULL for no clipping); write_grad != 0 also stores the scaled gradients back,
  * as clip_grad_norm_ does. */

@@ -43,7 +43,7 @@ def test_schedule_buffers_match_golden_on_device(golden):
         assert torch.equal(getattr(diff, k).cpu(), g[f"log-snr-linear/10/{k}"])
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2), (torch.float16, 4e-3)])
 def test_denoiser_forward_golden(golden, dtype, tol):
     g = golden("model_cfg1")
     diff = build_cfg1(golden, dtype=dtype)
@@ -171,6 +171,13 @@ def test_full_size_forward_matches_oracle_fp32(monkeypatch):
     with torch.no_grad():
         yb = net(x.to(dev()), t.to(dev()), cond(c_local))
     assert rel_l2(yb.cpu(), ref) < 3e-2
+    # fp16 storage + fp16 MFMA operands (11 significand bits, the precision of the reference's TF32 GPU convs): the same
+    # kernels as bf16, an order of magnitude closer to the oracle (<= 2e-3; bf16 measures 8.9e-3)
+    net.set_compute_dtype(torch.float16)
+    with torch.no_grad():
+        yh = net(x.to(dev()), t.to(dev()), cond(c_local))
+    assert rel_l2(yh.cpu(), ref) < 2e-3, rel_l2(yh.cpu(), ref)
+    assert rel_l2(yh.cpu(), ref) < 0.5 * rel_l2(yb.cpu(), ref)
 
 
 def _full_size_problem(seed=0):
@@ -229,17 +236,26 @@ def _check_modes_against_oracle(monkeypatch, diff, inputs, md, ref_loss, leaves,
     headline mode: ring / brick conv kernels, level-0 split-K weight gradient with atomics, bf16 halo-shell atomics) at
     0.1 per tensor and 3e-2 on the loss."""
     x, t, c_local, noise = inputs
+    from turbdiff_amd.training import DiffusionTrainer
+
+    # fp16 (round 6): fp16 tensors / MFMA operands under a power-of-two loss scale (the backward pass of S * loss; the
+    # fp32 parameter gradients come out S times too large and are divided here, as ClipRAdam does): 2e-2 per tensor, 5x
+    # inside the bf16 gate, and 2e-3 on the loss
+    n_loss = x.shape[0] * x.shape[1] * int(md.cell_idx.numel())
     for mode, impl, dtype, tol, ltol in (("f32", "auto", torch.float32, 1e-3, 1e-4), ("f32s", "split", torch.float32, 1e-3, 1e-4),
-                                         ("bf16", "auto", torch.bfloat16, 0.1, 3e-2)):
+                                         ("bf16", "auto", torch.bfloat16, 0.1, 3e-2), ("fp16", "auto", torch.float16, 2e-2, 2e-3)):
         monkeypatch.setenv("TDX_CONV_IMPL", impl)
         diff.model.set_compute_dtype(dtype)
         diff.zero_grad(set_to_none=True)
+        S = DiffusionTrainer.initial_loss_scale(n_loss) if mode == "fp16" else 1.0
         loss, _ = diff.p_losses(x.to(dev()), t.to(dev()), cond(c_local), md, None, noise=noise.to(dev()))
-        loss.backward()
+        (loss * S).backward()
         assert abs(loss.item() - ref_loss.item()) < ltol * abs(ref_loss.item()), (mode, loss.item(), ref_loss.item())
         params = dict(diff.model.named_parameters())
         for name in watched:
-            assert_grad_close(f"{mode}:{name}", params[name].grad.float().cpu(), leaves[name].grad, tol)
+            g = params[name].grad.float().cpu() / S
+            assert torch.isfinite(g).all(), (mode, name)
+            assert_grad_close(f"{mode}:{name}", g, leaves[name].grad, tol)
     monkeypatch.delenv("TDX_CONV_IMPL")
     diff.model.set_compute_dtype(torch.float32)
 
@@ -376,7 +392,7 @@ def test_config3_full_size_graph_sampler_vs_oracle(monkeypatch):
     buf = O.schedule_buffers("log-snr-linear", T)
     ref = None
     for mode, impl, dtype, tol in (("f32", "auto", torch.float32, 1e-4), ("f32s", "split", torch.float32, 1e-4),
-                                   ("bf16", "auto", torch.bfloat16, 3e-2)):
+                                   ("bf16", "auto", torch.bfloat16, 3e-2), ("fp16", "auto", torch.float16, 4e-3)):
         monkeypatch.setenv("TDX_CONV_IMPL", impl)
         diff.model.set_compute_dtype(dtype)
         out2 = diff.p_sample_loop(xb8[:2].to(dev()), C, ci, start_from=3, seed=77, trajectory_ids=ids8[:2])
@@ -391,7 +407,7 @@ def test_config3_full_size_graph_sampler_vs_oracle(monkeypatch):
         assert rel_l2(out2.cpu(), ref) < tol, (mode, rel_l2(out2.cpu(), ref))
         out8 = diff.p_sample_loop(xb8.to(dev()), C, ci, start_from=3, seed=77, trajectory_ids=ids8)
         # same ids, same nonce: the same noise; the arithmetic differs only by kernel selection with the batch
-        assert rel_l2(out8[:2], out2) < (1e-5 if dtype == torch.float32 else 2e-2), (mode, rel_l2(out8[:2], out2))
+        assert rel_l2(out8[:2], out2) < {"f32": 1e-5, "f32s": 1e-5, "bf16": 2e-2, "fp16": 3e-3}[mode], (mode, rel_l2(out8[:2], out2))
         assert rel_l2(out8[2:].cpu(), out8[:2].repeat(3, 1, 1, 1, 1).cpu()) > 1e-2  # other ids: other samples
         inside = torch.zeros(X * Y * Z, dtype=torch.bool)
         inside[cell_idx] = True
@@ -438,7 +454,7 @@ def test_config0_48x32x32_two_levels_training_and_sampling_vs_oracle(monkeypatch
             ref = O.p_sample_loop(sdn, buf, x, c_local, cell_idx, noises, timesteps=10, noise_bcs=nb)
         diff.noise_bcs = nb
         for mode, impl, dtype, tol in (("f32", "auto", torch.float32, 1e-4), ("f32s", "split", torch.float32, 1e-4),
-                                       ("bf16", "auto", torch.bfloat16, 3e-2)):
+                                       ("bf16", "auto", torch.bfloat16, 3e-2), ("fp16", "auto", torch.float16, 4e-3)):
             monkeypatch.setenv("TDX_CONV_IMPL", impl)
             diff.model.set_compute_dtype(dtype)
             it = iter([n.to(dev()) for n in noises])
@@ -793,7 +809,7 @@ def test_unfused_block_composition_matches_golden(golden, monkeypatch):
         assert_grad_close(name, p.grad.cpu(), g[f"loss_nb1/grad/{name}"], 1e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_fused_resnet_block_golden(golden, dtype):
     """ops.resnet_block (one autograd node, hand-written backward) against the reference's
     ResnetBlock vectors: 1x1-projected skip (8 -> 16) and identity skip (16 -> 16)."""
@@ -803,7 +819,7 @@ def test_fused_resnet_block_golden(golden, dtype):
     d = dev()
     nvc = lambda x: x.permute(0, 2, 3, 4, 1).contiguous()
     ncv = lambda x: x.permute(0, 4, 1, 2, 3).contiguous()
-    tol, gtol = (1e-4, 1e-3) if dtype == torch.float32 else (3e-2, 8e-2)
+    tol, gtol = {torch.float32: (1e-4, 1e-3), torch.bfloat16: (3e-2, 8e-2), torch.float16: (4e-3, 1e-2)}[dtype]
     for tag in ["resnet_proj", "resnet_id"]:
         sd = {k: v.to(d).requires_grad_() for k, v in g.sub(f"{tag}/sd/").items()}
         x = nvc(g[f"{tag}/x"]).to(d).to(dtype).requires_grad_()
@@ -899,6 +915,74 @@ def test_trainer_training_step_and_sample(golden):
     assert task.measure_sample_time(batch) > 0
 
 
+def _dense_batch(g, d, seed=11):
+    X, Y, Z = g["x"].shape[-3:]
+    cell_types = torch.randint(0, 6, (X, Y, Z), generator=torch.Generator().manual_seed(seed))
+    mean, std = torch.tensor([0.3, -0.1, 0.2, 1.0]), torch.tensor([2.0, 1.5, 0.7, 3.0])
+    raw = g["x"] * std.view(4, 1, 1, 1) + mean.view(4, 1, 1, 1)
+    return SimpleNamespace(x=raw.to(d), cell_idx=g["cell_idx"].to(d), cell_types=cell_types.to(d), mean=mean.to(d), std=std.to(d))
+
+
+def test_fp16_trainer_tracks_the_f32s_trainer_and_recovers_from_overflow(golden):
+    """compute_mode="fp16" (round 6): fp16 tensors + fp16 MFMA operands, training under ClipRAdam's power-of-two loss scale.
+    (i) Eight optimiser steps from the same weights, the same draws of (t, noise) per step: the fp16 trainer's losses follow
+    the split-precision fp32 trainer's within 1 % and its parameters end within 2 % of that trainer's total movement; no step
+    is skipped, the scale is the one chosen from the first batch.  (ii) A scale that overflows fp16 (2^40 x the seed)
+    skips steps WITHOUT touching parameters or moments, halves its way down and resumes training by itself.  (iii) The
+    captured step (enable_graph_step) reads the scale from a device scalar: finite losses, moving parameters."""
+    from turbdiff_amd.training import DiffusionTrainer
+
+    g = golden("model_cfg1")
+    d = dev()
+    batch = _dense_batch(g, d)
+    cfg = {**DiffusionTrainer.SHIPPED_CONFIG, "dim": 8, "timesteps": 10}
+
+    def make(mode):
+        torch.manual_seed(3)
+        task = DiffusionTrainer(**cfg, u_net_levels=2, max_train_steps=20, compute_mode=mode).to(d)
+        task.model.model.load_state_dict(g.sub("sd/"))
+        return task
+
+    ref, half = make("f32s"), make("fp16")
+    start = {k: v.detach().clone() for k, v in ref.model.model.named_parameters()}
+    for i in range(8):
+        torch.manual_seed(100 + i)
+        la = ref.fit_step(batch).item()
+        torch.manual_seed(100 + i)
+        lb = half.fit_step(batch).item()
+        assert abs(la - lb) < 1e-2 * abs(la), (i, la, lb)
+    half._opt.settle()
+    n_loss = 1 * 4 * int(batch.cell_idx.numel())
+    assert half._opt.skipped_steps == 0 and half._opt.loss_scale == DiffusionTrainer.initial_loss_scale(n_loss)
+    pa, pb = dict(ref.model.model.named_parameters()), dict(half.model.model.named_parameters())
+    moved = sum(float((pa[k] - start[k]).norm() ** 2) for k in pa) ** 0.5
+    apart = sum(float((pa[k] - pb[k]).norm() ** 2) for k in pa) ** 0.5
+    assert apart < 2e-2 * moved, (apart, moved)
+    # (ii) overflow
+    half._opt.loss_scale = 2.0**40
+    frozen = {k: v.detach().clone() for k, v in pb.items()}
+    m0 = half._opt.state[pb["encode_x.weight"]]["exp_avg"].clone()
+    for _ in range(3):
+        assert torch.isfinite(half.fit_step(batch))  # the loss itself is computed in fp32 from finite activations
+    assert all(torch.equal(frozen[k], pb[k].detach()) for k in frozen), "overflowing steps must leave the parameters alone"
+    assert torch.equal(m0, half._opt.state[pb["encode_x.weight"]]["exp_avg"])
+    for _ in range(40):
+        half.fit_step(batch)
+    half._opt.settle()
+    assert half._opt.skipped_steps >= 10 and half._opt.loss_scale < 2.0**30
+    assert not torch.equal(frozen["encode_x.weight"], pb["encode_x.weight"].detach()), "training must resume at a lower scale"
+    steps = float(half._opt.state[pb["encode_x.weight"]]["step"])
+    assert steps == 8 + 43 - half._opt.skipped_steps, (steps, half._opt.skipped_steps)  # skipped steps are not counted
+    # (iii) the captured step
+    graphed = make("fp16")
+    graphed.enable_graph_step()
+    w0 = graphed.model.model.encode_x.weight.detach().clone()
+    losses = [graphed.fit_step(batch) for _ in range(4)]
+    assert all(torch.isfinite(l) for l in losses) and len({l.data_ptr() for l in losses}) == 4  # fresh tensors (ADVICE r5)
+    graphed._opt.settle()
+    assert graphed._opt.skipped_steps == 0 and not torch.equal(w0, graphed.model.model.encode_x.weight.detach())
+
+
 @pytest.mark.parametrize("grid,levels", [((50, 26, 18), 3), ((13, 7, 6), 2), ((97, 25, 25), 2)])
 def test_odd_grids_forward_and_grads_vs_oracle(grid, levels, monkeypatch):
     """Grids that do not divide the brick sizes (the reference's real data is 194x50x50 -> 97x25x25
@@ -974,7 +1058,7 @@ def test_cached_conditioning_conv_matches_plain_forward():
     assert getattr(enc2, "first_conv_partial", None) is None
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
 def test_deferred_encoder_output_is_bit_identical(dtype, monkeypatch):
     """The encoder output feeds only the first block's identity skip once the first conv is composed with the encoders;
     it is then evaluated inside that block's tail kernel (tdx_gn_apply_encoded, ops.encode_deferred) instead of being
@@ -1020,7 +1104,7 @@ def test_deferred_encoder_output_is_bit_identical(dtype, monkeypatch):
     assert ga["encode_x.weight"].abs().sum() > 0
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
 def test_inference_decodes_inside_the_last_block_bit_identically(dtype, monkeypatch):
     """Without autograd the last ResnetBlock's tail kernel applies the 1x1 decoder itself (tdx_gn_apply_decode): same
     output, bit for bit, as with models.ddpm.FUSE_DECODE = False; with autograd on, the block output is kept (the decoder's weight

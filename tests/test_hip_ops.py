@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 F32_TOL = 2e-5
 BF16_TOL = 6e-3
+FP16_TOL = 8e-4  # IEEE half storage: 2^-12 relative per element (~2.5e-4 rel-L2 measured), an eighth of bf16's
 
 
 def dev():
@@ -44,7 +45,10 @@ def q(x, dtype):
 
 
 def tol_for(dtype):
-    return F32_TOL if dtype == torch.float32 else BF16_TOL
+    return {torch.float32: F32_TOL, torch.bfloat16: BF16_TOL, torch.float16: FP16_TOL}[dtype]
+
+
+MODE_DTYPE = {"f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
 
 
 @pytest.fixture(autouse=True)
@@ -59,7 +63,7 @@ def test_library_loads_on_gpu_box():
     assert lib.tdx_version() >= 1 and lib.tdx_arch() == b"gfx950"
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_layout_roundtrip(dtype):
     from turbdiff_amd import ops
 
@@ -87,12 +91,12 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("mode", ["f32-direct", "f32-auto", "f32-split", "bf16-direct", "bf16-auto"])
+@pytest.mark.parametrize("mode", ["f32-direct", "f32-auto", "f32-split", "bf16-direct", "bf16-auto", "fp16-direct", "fp16-auto"])
 def test_conv3_fwd_bwd(case, mode, monkeypatch):
     from turbdiff_amd import ops
 
     B, C1, C2, Cout, X, Y, Z = case
-    dtype = torch.float32 if mode.startswith("f32") else torch.bfloat16
+    dtype = MODE_DTYPE[mode.split("-")[0]]
     monkeypatch.setenv("TDX_CONV_IMPL", mode.split("-")[1])
     Cin = C1 + C2
     x = q(rnd(B, Cin, X, Y, Z, seed=1), dtype)
@@ -137,7 +141,7 @@ def test_conv3_mfma_matches_direct_bf16(monkeypatch):
     assert rel_l2(outs["mfma"][1], outs["direct"][1]) < 3e-3
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(2, 4, 0, 32, 100), (1, 64, 64, 32, 333), (3, 128, 0, 384, 70), (2, 32, 0, 4, 257)])
 def test_conv1_fwd_bwd(dtype, case):
     from turbdiff_amd import ops
@@ -169,7 +173,7 @@ def test_conv1_fwd_bwd(dtype, case):
     assert rel_l2(ad.grad.float().cpu().reshape(B, V, Cout), ar.grad) < tol
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(2, 16, 8, 7, 5, 6, True, True), (1, 64, 8, 9, 4, 3, False, True), (2, 32, 32, 5, 5, 5, True, False),
                                   (1, 512, 8, 12, 4, 3, True, True), (2, 24, 1, 6, 5, 4, False, False)])
 def test_gn_film_silu(dtype, case):
@@ -209,7 +213,7 @@ def test_gn_film_silu(dtype, case):
         assert rel_l2(ncv(rd.grad.float().cpu()), rr.grad) < tol
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("sizes", [((13, 7, 6), (6, 3, 3)), ((6, 3, 3), (13, 7, 6)), ((12, 8, 9), (6, 4, 4)),
                                    ((6, 4, 4), (12, 8, 9)), ((3, 3, 3), (3, 3, 3)), ((5, 4, 3), (3, 3, 3)), ((3, 3, 3), (5, 4, 3))])
 def test_resize(dtype, sizes):
@@ -229,7 +233,7 @@ def test_resize(dtype, sizes):
     assert rel_l2(ncv(xd.grad.float().cpu()), xr.grad) < tol
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N", [37, 144, 200])
 def test_attention(dtype, N):
     from turbdiff_amd import ops
@@ -358,7 +362,7 @@ def test_p_sample_step_rng_refuses_unaligned_planes():
     assert not ops.p_sample_step_rng_supported(x)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
 @pytest.mark.parametrize("with_c", [True, False])
 @pytest.mark.parametrize("B,D,grid", [(2, 32, (13, 9, 11)), (1, 32, (1, 1, 1)), (3, 16, (5, 1, 7)), (1, 64, (33, 32, 32)),
                                       (2, 8, (17, 16, 2))])
@@ -392,7 +396,7 @@ def test_gn_apply_encoded_equals_encode_then_apply_bitwise(dtype, with_c, B, D, 
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
 @pytest.mark.parametrize("C", [32, 64])
 @pytest.mark.parametrize("B,grid", [(2, (13, 9, 11)), (1, (1, 1, 1)), (3, (5, 1, 7)), (1, (33, 32, 32))])
 def test_gn_apply_decode_equals_apply_then_decode_bitwise(dtype, C, B, grid):
@@ -475,7 +479,7 @@ def test_philox_randn_moments_and_replay():
     assert abs((a * c).mean().item()) < 5e-3  # other trajectory stream: independent
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("with_c", [True, False])
 @pytest.mark.parametrize("D", [8, 32])
 def test_encode_decode_fused(dtype, with_c, D):
@@ -883,6 +887,53 @@ def test_clip_radam_parameters_at_different_step_counts():
         for k, (a, b) in enumerate(zip(pa, pb)):
             assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), (step, k)
     assert [int(oa.state[p]["step"]) for p in pa] == [int(ob.state[p]["step"]) for p in pb] == [9, 5, 9, 5]
+
+
+def test_clip_radam_loss_scaling_unscales_skips_and_adapts():
+    """ClipRAdam(loss_scale=S) (fp16 training): gradients stored S times too large give the updates and the norm of the
+    unscaled reference (clip_grad_norm_ + torch.optim.RAdam); a step with a non-finite gradient changes NOTHING (parameters,
+    moments, and -- once its flag has reached the host, two steps later -- the step counters) and halves S; S doubles after
+    `scale_growth_interval` clean steps.  Parameter 3 takes no gradients on odd steps (per-parameter step counts)."""
+    from turbdiff_amd.optim import ClipRAdam
+
+    torch.manual_seed(3)
+    d = torch.device("cuda:0")
+    shapes = [(5,), (17, 3), (40000,), (9, 2)]
+    pa = [torch.randn(s, device=d).requires_grad_() for s in shapes]
+    pb = [p.detach().clone().requires_grad_() for p in pa]
+    oa = torch.optim.RAdam(pa, lr=1e-2)
+    ob = ClipRAdam(pb, lr=1e-2, max_norm=0.5, loss_scale=2.0**12, scale_growth_interval=4)
+    bad_steps, expect_scale, clean = {3, 4}, 2.0**12, 0
+    for step in range(12):
+        S = ob.loss_scale  # what scale_loss() multiplies this step's loss by
+        loss = torch.tensor(1.5, device=d)
+        assert ob.scale_loss(loss).item() == 1.5 * S
+        gs = [torch.randn(s, device=d) * (2.0 if step % 2 else 0.02) for s in shapes]
+        for k, (a, b, g) in enumerate(zip(pa, pb, gs)):
+            if k == 3 and step % 2 == 1:
+                a.grad, b.grad = None, None
+            else:
+                a.grad, b.grad = g.clone(), g * S
+        if step in bad_steps:
+            pb[2].grad[123] = float("inf") if step == 3 else float("nan")
+            before = [b.detach().clone() for b in pb]
+            ob.step()
+            assert all(torch.equal(b, v) for b, v in zip(pb, before)), "a skipped step must not touch the parameters"
+            continue
+        ref_norm = torch.nn.utils.clip_grad_norm_(pa, 0.5)
+        oa.step()
+        ob.step()
+        assert abs(ob.last_grad_norm.item() - ref_norm.item()) < 1e-5 * ref_norm.item()
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            assert torch.allclose(a, b, rtol=3e-6, atol=2e-7), (step, k, (a - b).abs().max().item())
+    ob.settle()
+    assert ob.skipped_steps == 2
+    # 12 steps: flags 0-2 clean, 3 and 4 skipped (S: 2^12 -> 2^10), then 7 clean steps = one doubling after 4 (-> 2^11)
+    assert ob.loss_scale == 2.0**11
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    for k in sa:
+        assert float(sa[k]["step"]) == float(sb[k]["step"]), (k, float(sa[k]["step"]), float(sb[k]["step"]))
+        assert torch.allclose(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-4, atol=1e-12)
 
 
 def test_clip_radam_with_bucket_view_gradients():
