@@ -45,9 +45,12 @@ V = GRID[0] * GRID[1] * GRID[2]
 PEAK_BF16_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 # f32s issues three bf16 MFMAs per algorithmic product: its matrix-core ceiling is a third of the bf16 peak
-PEAK = {"bf16": PEAK_BF16_TFLOPS, "f32": PEAK_F32_TFLOPS, "f32s": PEAK_BF16_TFLOPS / 3}
-CONV_BYTES = {"bf16": 1417.6e6, "f32": 2835.2e6, "f32s": 2835.2e6}  # conv-only bytes per sample forward
-KERNEL = {"bf16": "conv3_mfma_kernel", "f32": "conv3_mfma_f32_kernel", "f32s": "conv3_mfma_split_kernel"}
+# fp16 MFMA forms cost the same matrix-pipe cycles as the bf16 ones on gfx950: one peak for both 16-bit modes
+PEAK = {"bf16": PEAK_BF16_TFLOPS, "fp16": PEAK_BF16_TFLOPS, "f32": PEAK_F32_TFLOPS, "f32s": PEAK_BF16_TFLOPS / 3}
+CONV_BYTES = {"bf16": 1417.6e6, "fp16": 1417.6e6, "f32": 2835.2e6, "f32s": 2835.2e6}  # conv-only bytes per sample forward
+KERNEL = {"bf16": "conv3_mfma_kernel", "fp16": "conv3_mfma_kernel", "f32": "conv3_mfma_f32_kernel", "f32s": "conv3_mfma_split_kernel"}
+MODE_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32, "f32s": torch.float32}
+LOSS_ELEMENTS = lambda B, cell_idx: B * 4 * int(cell_idx.numel())  # values behind the loss's mean (sizes the fp16 loss scale)
 ACCURACY_T = 250  # diffusion time of the accuracy probe
 
 
@@ -87,9 +90,10 @@ def build_model(device, dtype=None, timesteps=500):
 
 
 def set_mode(diff, mode):
-    """bf16: bf16 storage + bf16 MFMA; f32: fp32 storage, IEEE fp32 MFMA convs; f32s: fp32 storage,
+    """bf16: bf16 storage + bf16 MFMA; fp16: fp16 storage + fp16 MFMA (TF32's 11 significand bits at the bf16 kernels' speed;
+    training steps run under ClipRAdam's loss scale); f32: fp32 storage, IEEE fp32 MFMA convs; f32s: fp32 storage,
     split-precision convs (bf16 hi + lo, three MFMAs per product)."""
-    diff.model.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
+    diff.model.set_compute_dtype(MODE_DTYPE[mode])
     diff.model.conv_impl = "split" if mode == "f32s" else "auto"  # per model: no process-wide switch, no environment edits
 
 
@@ -177,7 +181,9 @@ def torch_rocm_baseline(B, dev, amp, steps=2):
 
 # forward instantiations of the matrix-core conv kernels in a rocprofv3 kernel name (ZERO_PAD / ZP template argument false)
 FWD_KERNEL_PATTERNS = {
-    "bf16": r"conv3_ring_kernel<\d, false, \d>|conv3_mfma_kernel<\d, (true|false), false,",  # <NT, ZP, LW> | <NT, XT, ZERO_PAD, PERM, EXT>
+    # <NT, ZP, LW, HF> | <NT, XT, ZERO_PAD, PERM, EXT, HF>; HF = fp16 operands
+    "bf16": r"conv3_ring_kernel<\d, false, \d, false>|conv3_mfma_kernel<\d, (true|false), false, (true|false), (true|false), false>",
+    "fp16": r"conv3_ring_kernel<\d, false, \d, true>|conv3_mfma_kernel<\d, (true|false), false, (true|false), (true|false), true>",
     "f32": r"conv3_mfma_f32_kernel<\d, false,", "f32s": r"conv3_mfma_split_kernel<\d, false,"}
 
 
@@ -256,7 +262,7 @@ def roofline_block(timer, mode, B, K):
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE), same launches",
             "traffic_source": tsrc, "traffic_launches_sampled": tn,
             "algorithmic_bytes_per_launch": main["bytes"] / main["launches"] if main["bytes"] else None,
-            "kernel": ("conv3_ring_kernel + conv3_mfma_kernel" if mode == "bf16" else KERNEL[mode]) +
+            "kernel": ("conv3_ring_kernel + conv3_mfma_kernel" if mode in ("bf16", "fp16") else KERNEL[mode]) +
                       " (tdx_conv3_fwd launches on the brick / ring kernels)",
             "launches": main["launches"], "avg_launch_ms": main["ms"] / main["launches"],
             "ring_kernel": ({"launches": ring["launches"], "achieved": ring["work"] / (ring["ms"] * 1e-3) / 1e12,
@@ -271,16 +277,23 @@ def kernel_table(kern, K):
             for k, v in kern.items()}
 
 
+def new_optimizer(diff, mode, n_loss_elements):
+    """ClipRAdam (clip 0.1 + RAdam); in fp16 with the loss scale the trainer would choose for this batch."""
+    from turbdiff_amd.optim import ClipRAdam
+    from turbdiff_amd.training import DiffusionTrainer
+
+    scale = DiffusionTrainer.initial_loss_scale(n_loss_elements) if mode == "fp16" else None
+    return ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1, loss_scale=scale)
+
+
 def timed_train_steps(diff, x, C, md, mode, steps, warmup):
     """ms per training step (fwd + bwd + clip 0.1 + RAdam) of `diff` on (x, C, md) in `mode`, single rank."""
-    from turbdiff_amd.optim import ClipRAdam
-
     set_mode(diff, mode)
-    opt = ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1)
+    opt = new_optimizer(diff, mode, LOSS_ELEMENTS(x.shape[0], md.cell_idx))
 
     def step():
         loss, _ = diff(x, C, md, None)
-        loss.backward()
+        opt.scale_loss(loss).backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
 
@@ -297,8 +310,8 @@ def timed_train_steps(diff, x, C, md, mode, steps, warmup):
 class _Task:
     """What training.GraphedTrainingStep asks of a task, around a bare GaussianDiffusion and dense inputs."""
 
-    def __init__(self, diff):
-        self.model = diff
+    def __init__(self, diff, opt=None):
+        self.model, self._opt = diff, opt  # (_opt: GraphedTrainingStep reads the loss scale from it)
 
     def _model_input(self, b):
         return b.x, b.C
@@ -314,7 +327,6 @@ def host_and_graph_step(diff, x, C, md, mode, steps, warmup):
     """The same training step eagerly and with forward + backward replayed from ONE captured hipGraph
     (training.GraphedTrainingStep; clip + RAdam stay eager): ms per step and the HOST's share of it (time to enqueue a
     step, no device sync inside the timed loop; the device is drained before and after)."""
-    from turbdiff_amd.optim import ClipRAdam
     from turbdiff_amd.training import GraphedTrainingStep
 
     set_mode(diff, mode)
@@ -322,8 +334,8 @@ def host_and_graph_step(diff, x, C, md, mode, steps, warmup):
     res = {}
     for kind in ("eager", "graph"):
         diff.zero_grad(set_to_none=True)
-        opt = ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1)
-        gs = GraphedTrainingStep(_Task(diff)) if kind == "graph" else None
+        opt = new_optimizer(diff, mode, LOSS_ELEMENTS(x.shape[0], md.cell_idx))
+        gs = GraphedTrainingStep(_Task(diff, opt)) if kind == "graph" else None
 
         def step():
             if gs is not None:
@@ -331,7 +343,7 @@ def host_and_graph_step(diff, x, C, md, mode, steps, warmup):
             else:
                 opt.zero_grad(set_to_none=True)
                 loss, _ = diff(x, C, md, None)
-                loss.backward()
+                opt.scale_loss(loss).backward()
                 del loss
             opt.step()
 
@@ -383,7 +395,7 @@ def cfg1_leg(dev, with_cpu):
     x, c, cell_idx = synthetic_inputs(1, dev, CFG1_GRID)
     C, md = {Conditioning.Type.CELL_TYPE: c}, SimpleNamespace(cell_idx=cell_idx)
     sd0 = {k: v.detach().cpu().clone() for k, v in diff.model.state_dict().items()}
-    for mode in ("bf16", "f32s", "f32"):
+    for mode in ("bf16", "fp16", "f32s", "f32"):
         diff.model.load_state_dict(sd0)
         ms = timed_train_steps(diff, x, C, md, mode, 20, 5)
         diff.p_sample_loop(x, C, cell_idx)  # capture
@@ -500,7 +512,7 @@ def real_grid_leg(dev, B):
     C, md = {Conditioning.Type.CELL_TYPE: c}, SimpleNamespace(cell_idx=cell_idx)
     vr = REAL_GRID[0] * REAL_GRID[1] * REAL_GRID[2]
     res = {"grid": list(REAL_GRID), "batch": B, "modes": {}}
-    for mode, k, w in (("bf16", 10, 3), ("f32s", 5, 2)):
+    for mode, k, w in (("bf16", 10, 3), ("fp16", 10, 3), ("f32s", 5, 2)):
         ms = timed_train_steps(diff, x, C, md, mode, k, w)
         res["modes"][mode] = {"ms_per_step": ms, "voxels_per_s": B * vr / (ms * 1e-3), "steps": k}
     return res
@@ -530,8 +542,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)   # 0.5 s of timed steps; 5 steps after 2 warm-up measured 3 % slower
     ap.add_argument("--warmup", type=int, default=5)   # (clocks and allocator not settled) than 20 after 5 on the same box
     ap.add_argument("--batch", type=int, default=6, help="per-GPU batch (reference: 6, config/model/diffusion.yaml:3)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32s"],
-                    help="mode of the headline line.  bf16: bf16 storage + bf16 MFMA (BASELINE configs[1]); f32: fp32 storage, "
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32", "f32s"],
+                    help="mode of the headline line.  bf16: bf16 storage + bf16 MFMA (BASELINE configs[1]); fp16: fp16 storage + fp16 "
+                         "MFMA under a loss scale (the reference's TF32-grade arithmetic, same kernels); f32: fp32 storage, "
                          "IEEE fp32 MFMA convs; f32s: fp32 storage, split-precision convs (bf16 hi + lo, 3 MFMAs per product). "
                          "The other two modes are reported under extra.parity_modes / extra.accuracy in the same run")
     ap.add_argument("--sample-steps", type=int, default=50, help="reverse steps timed for the sampling leg (0 = skip)")
@@ -610,7 +623,7 @@ def main():
         accuracy = {"probe": f"eps-hat at t = {ACCURACY_T}, B = 1, 192x64x48, default init seed 0; rel-L2 vs the CPU oracle"}
         xt, tt = probe["x_t"].to(dev), probe["t"].to(dev)
         with torch.no_grad():
-            for m in ("bf16", "f32s", "f32"):
+            for m in ("bf16", "fp16", "f32s", "f32"):
                 set_mode(diff, m)
                 e = diff.model(xt, tt, C).float().cpu()
                 accuracy[m] = ((e - probe["eps"]).norm() / probe["eps"].norm()).item()
@@ -635,19 +648,21 @@ def main():
     def run_mode(mode, steps, warmup):
         """`steps` timed training steps in `mode` -> (elapsed s (max over ranks), merged conv-kernel times, last loss)."""
         set_mode(diff, mode)
-        opt = (ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1) if fused_opt
+        assert fused_opt or mode != "fp16", "fp16 training needs the loss-scaling optimiser (--optimizer fused)"
+        opt = (new_optimizer(diff, mode, LOSS_ELEMENTS(B, cell_idx)) if fused_opt
                else torch.optim.RAdam(diff.parameters(), lr=1e-4))
+        scale_loss = getattr(opt, "scale_loss", lambda l: l)
 
         def train_step():
             loss, _ = diff(x, C, md, None)
             if ddp.timing:
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                 ev[0].record()
-                loss.backward()
+                scale_loss(loss).backward()
                 ev[1].record()
                 bwd_events.append(ev)
             else:
-                loss.backward()
+                scale_loss(loss).backward()
             ddp.finish()
             if not fused_opt:
                 torch.nn.utils.clip_grad_norm_(diff.parameters(), 0.1)
@@ -671,6 +686,9 @@ def main():
         _lib.TIMER = None
         ddp.timing = False
         kern = merged_kernel_times(timer)
+        if hasattr(opt, "settle"):
+            opt.settle()
+            run_mode.skipped = opt.skipped_steps  # fp16: steps whose gradients overflowed (0 = every timed step updated)
         return elapsed, (kern, timer), loss.item(), train_step
 
     leg_done("build_model_and_accuracy_probe")
@@ -755,13 +773,17 @@ def main():
     # ---- the modes that meet the 1e-4 parity gate, same run, same model (N = 1 only: they are not scaling legs)
     if world == 1 and not args.no_extra and not args.no_parity_modes:
         pm = {}
-        for m in ("f32s", "f32"):
+        for m in ("fp16", "bf16", "f32s", "f32"):
             if m == args.dtype:
                 continue
-            k2 = 10
-            el, (kn, tm), _, _ = run_mode(m, k2, 2)
+            k2 = 20 if m in ("fp16", "bf16") else 10  # the 16-bit modes are compared with each other at the headline's step count
+            el, (kn, tm), _, _ = run_mode(m, k2, 3)
             d = {"ms_per_step": 1e3 * el / k2, "voxels_per_s": B * V * k2 / el, "steps": k2,
                  "roofline": roofline_block(tm, m, B, k2), "kernels": kernel_table(kn, k2)}
+            if m == "fp16":
+                d["skipped_steps"] = getattr(run_mode, "skipped", None)
+                d["note"] = ("fp16 tensors + fp16 MFMA operands (11 significand bits: the reference's TF32 arithmetic, train.py:144-156), "
+                             "ClipRAdam loss scale; same kernels as bf16 templated on the operand format")
             if accuracy is not None:
                 d["rel_l2_vs_cpu_oracle"] = accuracy[m]
             pm[m] = d
@@ -813,6 +835,22 @@ def main():
                                  "ddpm_samples_per_s_T500": Bs * world / (per_step * 500),
                                  "note": "whole-job aggregate; per-step time x T" + ("" if full else " (extrapolated from the timed steps)")}
             del sampler
+            if world == 1 and args.dtype != "fp16":
+                # the same captured reverse step on fp16 tensors / fp16 MFMA operands: sampling needs no loss scale, so
+                # this is the at-speed sampler at the reference's own (TF32-grade) precision
+                set_mode(sdiff, "fp16")
+                s16 = GraphSampler(sdiff, xs, C, cell_idx, seed=0, trajectory_ids=ids)
+                s16.run_steps(2)
+                n16 = min(n, 300)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                s16.run_steps(n16)
+                torch.cuda.synchronize()
+                p16 = (time.perf_counter() - t0) / n16
+                extra["sampling"]["fp16"] = {"ms_per_reverse_step": 1e3 * p16, "reverse_steps_timed": n16,
+                                             "ddpm_samples_per_s_T1000": Bs / (p16 * T)}
+                del s16
+                set_mode(sdiff, args.dtype)
             if world == 1:
                 # the PUBLIC method (what DiffusionTraining.sample / eval_ckpt.py / a dropin user call, reference
                 # diffusion.py:152-158): graph path vs the eager loop (TDX_GRAPH_SAMPLER=0), 30 reverse steps each via

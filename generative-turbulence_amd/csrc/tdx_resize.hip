@@ -141,8 +141,10 @@ static bool pair_window_ok(const AxisMap& a) {
     return true;
 }
 
+// (256, 3): three workgroups per CU = three waves per SIMD, i.e. at most 168 VGPRs -- the fp16 instantiation came out at 169
+// (two waves per SIMD: 185 -> 309 us on the level-0 up-sampling) without the bound
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 resize_up_pairs_kernel(const T* __restrict__ x, T* __restrict__ y, AxisMap ax, AxisMap ay, AxisMap az, int C, TileGrid tg) {
     __shared__ PairTaps s_p[3][RS_MAXT / 2];
     int b, ox0, oy0, oz0;

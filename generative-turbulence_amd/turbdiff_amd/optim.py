@@ -16,9 +16,11 @@ Loss scaling (fp16 training, ``loss_scale=``): the backward pass runs on ``scale
 that fp16 activation gradients stay representable; the stored fp32 parameter gradients are then S times the true ones.
 ``tdx_grad_norm_scaled`` reports the true norm, folds 1 / S into the clip factor and raises a device flag when the norm is
 not finite, on which ``tdx_radam_step_scaled`` leaves parameters and moments untouched.  The host never waits for that flag:
-it reads the flag of step k - 2 at step k (an asynchronous copy into pinned memory behind an event that has long fired),
+it reads the flag of step k - 2 at the END of step k (an asynchronous copy into pinned memory behind an event that has long fired),
 halves S and takes the skipped step out of the step counters then; after ``scale_growth_interval`` clean steps S doubles.
 The lag is a constant two steps, so data-parallel ranks (which see identical all-reduced gradients) change S in lockstep.
+Its price: the one or two steps that follow an overflow run RAdam's bias corrections with a step count that still includes
+the skipped step(s) (``sync_flags=True`` waits for every step's own flag instead, as ``torch.cuda.amp.GradScaler`` does).
 """
 
 from __future__ import annotations
@@ -32,7 +34,7 @@ from . import _lib as L
 class ClipRAdam(torch.optim.Optimizer):
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float | None = None,
                  write_clipped_grads: bool = False, loss_scale: float | None = None, scale_growth_interval: int = 2000,
-                 min_loss_scale: float = 1.0, max_loss_scale: float = 2.0**24):
+                 min_loss_scale: float = 1.0, max_loss_scale: float = 2.0**24, sync_flags: bool = False):
         if not 0.0 <= lr:
             raise ValueError(f"Invalid learning rate: {lr}")
         if not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
@@ -47,6 +49,9 @@ class ClipRAdam(torch.optim.Optimizer):
         self.loss_scale = None if loss_scale is None else float(loss_scale)
         self.scale_growth_interval = int(scale_growth_interval)
         self.min_loss_scale, self.max_loss_scale = float(min_loss_scale), float(max_loss_scale)
+        # True: every step waits for its own flag (torch.cuda.amp.GradScaler's behaviour: one host sync per step, and the
+        # step counters of the steps right after an overflow are exact instead of one or two too high until the flag lands)
+        self.sync_flags = bool(sync_flags)
         self.skipped_steps = 0      # steps whose gradients were not finite (known with the two-step lag)
         self._clean_steps = 0       # since the last change of the scale
         self._flags = []            # [(step index, pinned (4,) float tensor, event, plan index)] not yet looked at
@@ -149,7 +154,6 @@ class ClipRAdam(torch.optim.Optimizer):
         scaled = self.loss_scale is not None
         if scaled:
             self._step_index += 1
-            self._settle_flags(self._step_index - 1, wait=True)  # the flags of steps <= k - 2: long on the host
         for gi, group in enumerate(self.param_groups):
             plan = self._plan(gi, group)
             if plan is None:
@@ -243,4 +247,8 @@ class ClipRAdam(torch.optim.Optimizer):
             # the kernels wrote through raw pointers: tell autograd (and the packed-weight caches keyed
             # on Tensor._version, ops._packed_conv3) that the parameters changed
             torch.autograd.graph.increment_version([p for p in plan["params"] if p.grad is not None])
+        if scaled:
+            # only now may the scale change: this step's backward ran on the scale its kernels above divided by.  The flags of
+            # steps <= k - 2 are long on the host (a constant lag: data-parallel ranks change the scale in lockstep)
+            self._settle_flags(self._step_index + 1 if self.sync_flags else self._step_index - 1, wait=True)
         return loss

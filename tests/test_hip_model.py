@@ -952,11 +952,11 @@ def test_fp16_trainer_tracks_the_f32s_trainer_and_recovers_from_overflow(golden)
         lb = half.fit_step(batch).item()
         assert abs(la - lb) < 1e-2 * abs(la), (i, la, lb)
     half._opt.settle()
-    n_loss = 1 * 4 * int(batch.cell_idx.numel())
+    n_loss = int(batch.x.shape[0]) * 4 * int(batch.cell_idx.numel())
     assert half._opt.skipped_steps == 0 and half._opt.loss_scale == DiffusionTrainer.initial_loss_scale(n_loss)
     pa, pb = dict(ref.model.model.named_parameters()), dict(half.model.model.named_parameters())
-    moved = sum(float((pa[k] - start[k]).norm() ** 2) for k in pa) ** 0.5
-    apart = sum(float((pa[k] - pb[k]).norm() ** 2) for k in pa) ** 0.5
+    moved = sum(float((pa[k].detach() - start[k]).norm() ** 2) for k in pa) ** 0.5
+    apart = sum(float((pa[k].detach() - pb[k].detach()).norm() ** 2) for k in pa) ** 0.5
     assert apart < 2e-2 * moved, (apart, moved)
     # (ii) overflow
     half._opt.loss_scale = 2.0**40

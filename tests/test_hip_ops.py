@@ -902,8 +902,10 @@ def test_clip_radam_loss_scaling_unscales_skips_and_adapts():
     pa = [torch.randn(s, device=d).requires_grad_() for s in shapes]
     pb = [p.detach().clone().requires_grad_() for p in pa]
     oa = torch.optim.RAdam(pa, lr=1e-2)
-    ob = ClipRAdam(pb, lr=1e-2, max_norm=0.5, loss_scale=2.0**12, scale_growth_interval=4)
-    bad_steps, expect_scale, clean = {3, 4}, 2.0**12, 0
+    # sync_flags: every step waits for its own flag (exact step counts right after an overflow, comparable with the
+    # reference step by step); the default lazy mode is checked below
+    ob = ClipRAdam(pb, lr=1e-2, max_norm=0.5, loss_scale=2.0**12, scale_growth_interval=4, sync_flags=True)
+    bad_steps = {3, 4}
     for step in range(12):
         S = ob.loss_scale  # what scale_loss() multiplies this step's loss by
         loss = torch.tensor(1.5, device=d)
@@ -929,11 +931,31 @@ def test_clip_radam_loss_scaling_unscales_skips_and_adapts():
     ob.settle()
     assert ob.skipped_steps == 2
     # 12 steps: flags 0-2 clean, 3 and 4 skipped (S: 2^12 -> 2^10), then 7 clean steps = one doubling after 4 (-> 2^11)
-    assert ob.loss_scale == 2.0**11
+    assert ob.loss_scale == 2.0**11 and ob._clean_steps == 3
     sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
     for k in sa:
         assert float(sa[k]["step"]) == float(sb[k]["step"]), (k, float(sa[k]["step"]), float(sb[k]["step"]))
         assert torch.allclose(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"], rtol=1e-4, atol=1e-12)
+    # the default: flags are read two steps late, never waited for.  Same bookkeeping once settled (scale, skipped steps,
+    # step counts); the scale a step's backward ran on is the scale its update divides by, also across a change
+    pc = [p.detach().clone().requires_grad_() for p in pa]
+    oc = ClipRAdam(pc, lr=1e-2, max_norm=0.5, loss_scale=2.0**12, scale_growth_interval=4)
+    norms = []
+    for step in range(12):
+        S = oc.loss_scale
+        for k, c in enumerate(pc):
+            c.grad = None if (k == 3 and step % 2 == 1) else torch.full_like(c, 0.25) * S
+        if step in bad_steps:
+            pc[2].grad[7] = float("inf")
+        oc.step()
+        if step not in bad_steps:
+            norms.append(oc.last_grad_norm.item())
+    oc.settle()
+    assert oc.skipped_steps == 2 and oc.loss_scale == 2.0**11
+    assert [int(oc.state[c]["step"]) for c in pc] == [10, 10, 10, 5]
+    full = 0.25 * (sum(c.numel() for c in pc)) ** 0.5
+    part = 0.25 * (sum(c.numel() for c in pc[:3])) ** 0.5
+    assert all(abs(n - (part if i % 2 else full)) < 1e-4 for i, n in zip([0, 1, 2, 5, 6, 7, 8, 9, 10, 11], norms)), norms
 
 
 def test_clip_radam_with_bucket_view_gradients():
