@@ -187,6 +187,9 @@ FWD_KERNEL_PATTERNS = {
     "f32": r"conv3_mfma_f32_kernel<\d, false,", "f32s": r"conv3_mfma_split_kernel<\d, false,"}
 
 
+FWD_KERNEL_FAMILY = r"conv3_ring_kernel<|conv3_mfma_kernel<|conv3_mfma_f32_kernel<|conv3_mfma_split_kernel<"
+
+
 def measured_traffic(mode="bf16"):
     """HBM bytes per launch of the mode's forward brick / ring conv kernels from the committed rocprofv3 PMC passes
     (profiles/*_traffic.json, produced by tools/collect_profiles.sh + summarize_profiles.py at B = 6): the newest file that
@@ -215,6 +218,10 @@ def measured_traffic(mode="bf16"):
                 num += n * (k["read_bytes_per_launch"] + k["write_bytes_per_launch"])
                 den += n
         if not den:
+            # a file from before the kernels carried the operand format in their names (rounds <= 5): other kernels
+            if data.get("kernel_sources_sha16") != now and any(re.search(FWD_KERNEL_FAMILY, name) for name in data["kernels"]):
+                refused.append({"file": f"profiles/{f.name}", "git_head": data.get("git_head"),
+                                "why": "collected on other conv-kernel sources than this tree's"})
             continue
         if data.get("kernel_sources_sha16") != now:
             refused.append({"file": f"profiles/{f.name}", "git_head": data.get("git_head"),

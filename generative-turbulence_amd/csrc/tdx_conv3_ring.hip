@@ -44,6 +44,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define RG_HY 10
 #define RG_SZ 12                        // padded z stride of the LDS brick image (conflict-free 16-B fragment reads)
+#define RG_SZ4 6                        // z stride of the 4-deep brick's image: no padding needed (RingShape)
 #define RG_WSLOTS 3                     // weight ring (lookahead 2 units)
 #define RG_WAVES 8
 #define RG_STEPS 14                     // K steps per unit: tap pairs (2p, 2p + 1); tap 27 is the zero dummy
@@ -111,14 +112,24 @@ __device__ __forceinline__ int rg_tile_addr(int v, int c) {  // wave-private [32
 // wave per SIMD) issue every copy, wait for their arrival and meet the computing waves at the unit barrier; the
 // computing waves then carry no vector-memory instruction in their MFMA stream (an LDS-DMA instruction costs the issuing
 // wave ~150 cycles there: profiles/r10_ring_stamps.txt, ablations).
-template <int NT, int LW = 0>
+// Z4 (round 6): bricks 4 voxels deep along z, for grids whose z extent is a multiple of 4 but not of 8 and that have too few
+// 8-deep bricks to fill a persistent launch -- level 2 of the benchmark grid, 48 x 16 x 12 (reference ddpm.py:358), which ran
+// on the brick kernel at 0.26 of the MFMA peak.  An M tile is then a whole 8 (y) x 4 (z) plane of the brick, a wave owns MT
+// planes, the brick is 8 MT x 8 x 4 (64-wide tiles: 16 x 8 x 4, 32-wide: 32 x 8 x 4: the same 512 voxels as before).  The
+// image's z stride is the halo'd extent 6 itself: lanes (y, z) -> y = (r >> 1) & 7, z = (r & 1) + 2 (r >> 4) put the 16 lanes
+// of every ds_read_b128 group on entries 6 y + z (+ const), y = 0..7, z in {0, 1}: 16 distinct residues mod 16, conflict-free
+// without padding -- so the image of an 18-plane brick (17 KiB) still fits beside the weight ring.
+template <int NT, int LW = 0, bool Z4 = false>
 struct RingShape {
     static constexpr int IW = LW ? LW : 8;                  // waves that issue copies
     static constexpr int BN = NT * 32;
     static constexpr int MT = 4 / NT;                       // M tiles per wave
-    static constexpr int XP = MT / 2;                       // x planes per wave
+    static constexpr int XP = Z4 ? MT : MT / 2;             // x planes per wave
     static constexpr int BX = 8 * XP;                       // brick extent along x
-    static constexpr int ENT = (BX + 2) * RG_HY * RG_SZ;    // LDS entries of a brick image (16 B = 8 channels of a voxel)
+    static constexpr int BZ = Z4 ? 4 : 8;                   // ... along z (y: 8)
+    static constexpr int HZ = BZ + 2;
+    static constexpr int SZ = Z4 ? RG_SZ4 : RG_SZ;          // z stride of the image
+    static constexpr int ENT = (BX + 2) * RG_HY * SZ;       // LDS entries of a brick image (16 B = 8 channels of a voxel)
     static constexpr int APIECES = (ENT + 63) / 64;         // 1-KiB DMA pieces: 19 / 34
     static constexpr int ABUF = APIECES * 1024;
     static constexpr int BPW = (APIECES + IW - 1) / IW;     // brick pieces per issuing wave and unit: 3 / 5 (LW = 4: 5 / 9)
@@ -133,9 +144,9 @@ struct RingShape {
                                   64 /* zero entry */ + BN * 4 /* bias */ + (size_t)RG_WAVES * BN * 2 * 4 /* statistics */;
 };
 
-template <int NT, bool ZP, int LW, bool HF>
+template <int NT, bool ZP, int LW, bool HF, bool Z4>
 __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(RingArgs A) {
-    typedef RingShape<NT, LW> S;
+    typedef RingShape<NT, LW, Z4> S;
     typedef H16<HF> H;                  // operand format: bf16 or fp16 words (the pointers of RingArgs are raw 16-bit rows)
     typedef typename H::T HT;
     constexpr int BN = S::BN, MT = S::MT, XP = S::XP, BPW = S::BPW, WPW = S::WPW, CH = S::CH, VPI = S::VPI, NST = S::NST;
@@ -185,8 +196,8 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
     for (int i = 0; i < BPW; ++i) {
         const int pi = min(max(iw, 0) * BPW + i, S::APIECES - 1);
         const int e = min(pi * 64 + lane, S::ENT - 1);
-        const int hx = e / (RG_HY * RG_SZ), rem = e - hx * (RG_HY * RG_SZ);
-        const int hy = rem / RG_SZ, hz = min(rem - hy * RG_SZ, 9);
+        const int hx = e / (RG_HY * S::SZ), rem = e - hx * (RG_HY * S::SZ);
+        const int hy = rem / S::SZ, hz = min(rem - hy * S::SZ, S::HZ - 1);
         hxyz[i] = hx | (hy << 8) | (hz << 16);
     }
     // weight piece j of this wave: pj = wave * WPW + j -> entries 64 pj .. of [28 taps][BN]; tap 27 copies tap 26 (its x
@@ -199,17 +210,21 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
         wlane[j] = (unsigned)((min(e / BN, 26) * A.Cout + (e % BN)) * 32);
     }
 
-    // ---- fragment geometry: M tile mt of wave w: x plane w XP + mt / 2, y = 4 (mt % 2) + (r & 3), z = r >> 2;
+    // ---- fragment geometry: M tile mt of wave w: x plane w XP + mt / 2, y = 4 (mt % 2) + (r & 3), z = r >> 2
+    // (Z4: x plane w XP + mt, y = (r >> 1) & 7, z = (r & 1) + 2 (r >> 4));
     // K step p: lanes 0-31 read tap 2p, lanes 32-63 tap 2p + 1 (the 28th: the zero entry)
+    const int ly = Z4 ? (r >> 1) & 7 : (r & 3), lz = Z4 ? (r & 1) + 2 * (r >> 4) : (r >> 2);  // voxel of this lane inside an M tile
     int a_h[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        a_h[mt] = (((wave * XP + mt / 2 + 1) * RG_HY + (4 * (mt % 2) + (r & 3) + 1)) * RG_SZ + ((r >> 2) + 1)) * 16;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int px = Z4 ? wave * XP + mt : wave * XP + mt / 2, py = Z4 ? ly : 4 * (mt % 2) + ly;
+        a_h[mt] = (((px + 1) * RG_HY + (py + 1)) * S::SZ + (lz + 1)) * 16;
+    }
     int xo[RG_STEPS];
 #pragma unroll
     for (int p = 0; p < RG_STEPS; ++p) {
         const int t = min(2 * p + hh, 26);
-        xo[p] = (((t / 9 - 1) * RG_HY + ((t / 3) % 3 - 1)) * RG_SZ + (t % 3 - 1)) * 16;
+        xo[p] = (((t / 9 - 1) * RG_HY + ((t / 3) % 3 - 1)) * S::SZ + (t % 3 - 1)) * 16;
     }
     int b_off[NT];
 #pragma unroll
@@ -223,7 +238,7 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
         const int bz = id % A.nbz; id /= A.nbz;
         const int by = id % A.nby; id /= A.nby;
         const int bx = id % A.nbx; id /= A.nbx;
-        b = id; o0 = bx * S::BX; o1 = by * 8; o2 = bz * 8;
+        b = id; o0 = bx * S::BX; o1 = by * 8; o2 = bz * S::BZ;
     };
     auto plan_brick = [&](int ord) {
         int b, o0, o1, o2;
@@ -425,14 +440,14 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
         }
 
         // ---------------- epilogue of the brick (no barrier: wave-private tiles).  Lane (r, hh) of wave w holds, for
-        // M tile mt, voxel (w XP + mt / 2, 4 (mt % 2) + (r & 3), r >> 2) and channels nt*32 + 8 j + 4 hh + (0..3) in
-        // accumulator registers 4 j .. 4 j + 3.
+        // M tile mt, voxel (w XP + mt / 2, 4 (mt % 2) + (r & 3), r >> 2) (Z4: (w XP + mt, ly, lz)) and channels
+        // nt*32 + 8 j + 4 hh + (0..3) in accumulator registers 4 j .. 4 j + 3.  Tile row = voxel in (y, z) order.
         RG_T();  // last MFMA issued
         unsigned char* tile = sT + wave * S::TILE;
         const int last_b = b;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int vw = (r & 3) * 8 + (r >> 2);
+            const int vw = ly * S::BZ + lz;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -445,7 +460,8 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
 #pragma unroll
             for (int i = 0; i < 32 / VPI; ++i) {
                 const int v = lane / CH + VPI * i, cidx = lane % CH;
-                const int c0 = o0 + wave * XP + mt / 2, c1 = o1 + 4 * (mt % 2) + (v >> 3), c2 = o2 + (v & 7);
+                const int c0 = o0 + (Z4 ? wave * XP + mt : wave * XP + mt / 2);
+                const int c1 = o1 + (Z4 ? (v >> 2) : 4 * (mt % 2) + (v >> 3)), c2 = o2 + (Z4 ? (v & 3) : (v & 7));
                 uint4 val = *reinterpret_cast<const uint4*>(tile + rg_tile_addr<BN>(v, cidx));
                 const int64_t ov = (int64_t)b * V + c0 * YZ + c1 * A.Z + c2;
                 const int n = n0 + cidx * 8;
@@ -500,10 +516,35 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
 #endif
 }
 
-bool conv3_ring_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z) {
+static bool ring_z8_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z, int mode);
+static bool ring_z4_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z, int mode) {
+    const char* env = getenv("TDX_RING_Z4");  // A/B switch, read per call: 0 = no 4-deep bricks (round 5's dispatch), 2 = prefer them
+    if (env && atoi(env) == 0) return false;
+    const int NT = Cout % 64 == 0 ? 2 : 1, bx = NT == 2 ? 16 : 32;
+    if (X < bx || Y < 8 || Z < 4 || (X % bx) > 2 || (Y % 8) > 2 || (Z % 4) > 2) return false;
+    const int ntn = Cout / (32 * NT);
+    if (ntn > tdx_persistent_cus() / 8) return false;
+    if ((int64_t)X * Y * Z * 1024 >= (1ll << 31)) return false;
+    if (mode == 2) return true;
+    if (NT == 1 && std::max(C1, C2) > 32) return false;  // (as for the 8-deep bricks)
+    // every CU should get work: (brick, N tile) pairs >= 3/4 of the CUs; a pair walks all of K (>= 16 units at level 2)
+    const int64_t nb = (int64_t)B * (X / bx) * (Y / 8) * (Z / 4);
+    return nb * ntn >= 192 && (C1 + C2) >= 64;
+}
+// brick shape of the ring kernel for this call: 0 = not a case for it, 8 = 8-deep bricks, 4 = 4-deep bricks (Z4)
+static int ring_brick_depth(int C1, int C2, int Cout, int B, int X, int Y, int Z) {
     const char* env = getenv("TDX_CONV3_RING");  // A/B switch, read per call: 0 off, 1 auto (default), 2 whenever legal
     const int mode = env ? atoi(env) : 1;
-    if (mode == 0 || !conv3_mfma_supported(C1, C2, Cout)) return false;
+    if (mode == 0 || !conv3_mfma_supported(C1, C2, Cout)) return 0;
+    const char* z4 = getenv("TDX_RING_Z4");  // 2: 4-deep bricks wherever they are legal (tests)
+    if (z4 && atoi(z4) == 2 && ring_z4_supported(C1, C2, Cout, B, X, Y, Z, 2)) return 4;
+    if (ring_z8_supported(C1, C2, Cout, B, X, Y, Z, mode)) return 8;
+    return ring_z4_supported(C1, C2, Cout, B, X, Y, Z, mode) ? 4 : 0;
+}
+bool conv3_ring_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z) {
+    return ring_brick_depth(C1, C2, Cout, B, X, Y, Z) != 0;
+}
+static bool ring_z8_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z, int mode) {
     const int NT = Cout % 64 == 0 ? 2 : 1, bx = NT == 2 ? 8 : 16;
     // The kernel walks WHOLE bricks (every wave issues all of its epilogue stores: the counted vmcnt waits of the
     // loader-less form assume it).  A grid may leave 1-2 voxels per axis beyond its whole bricks: those remainder slabs go
@@ -529,13 +570,13 @@ bool conv3_ring_supported(int C1, int C2, int Cout, int B, int X, int Y, int Z) 
 static unsigned long long* rg_stamp_buffer = nullptr;
 #endif
 
-template <int NT, bool ZP, int LW, bool HF>
+template <int NT, bool ZP, int LW, bool HF, bool Z4 = false>
 static int ring_go(const RingArgs& a, hipStream_t st) {
-    size_t lds = RingShape<NT, LW>::LDS;
+    size_t lds = RingShape<NT, LW, Z4>::LDS;
 #ifdef RG_STAMPS
     if (NT == 1) lds += (size_t)RG_WAVES * RG_NSTAMP * 8;
 #endif
-    auto kern = conv3_ring_kernel<NT, ZP, LW, HF>;
+    auto kern = conv3_ring_kernel<NT, ZP, LW, HF, Z4>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -553,14 +594,16 @@ static int ring_go(const RingArgs& a, hipStream_t st) {
 int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void* wp, const float* bias, void* y, int B, int X,
                       int Y, int Z, int Cout, bool zero_pad, hipStream_t st, double* gn_acc, void* d1, int D1, void* d2,
                       const void* a1, const void* a2, bool hf) {
-    if (!conv3_ring_supported(C1, C2, Cout, B, X, Y, Z)) return TDX_ESHAPE;
+    const int depth = ring_brick_depth(C1, C2, Cout, B, X, Y, Z);
+    if (depth == 0) return TDX_ESHAPE;
     if (zero_pad && (tdx_scratch_ptr() == nullptr || tdx_scratch_bytes() < 16)) return TDX_ESHAPE;  // zero source
     const int NT = Cout % 64 == 0 ? 2 : 1;
+    const int bxr = (NT == 2 ? 8 : 16) * (depth == 4 ? 2 : 1);  // brick extent along x
     RingArgs a;
     a.x1 = (const bf16*)x1; a.x2 = (const bf16*)x2; a.C1 = C1; a.C2 = C2;
     a.wp = (const bf16*)wp; a.bias = bias; a.y = (bf16*)y;
     a.B = B; a.X = X; a.Y = Y; a.Z = Z; a.Cout = Cout;
-    a.nbx = X / (NT == 2 ? 8 : 16); a.nby = Y / 8; a.nbz = Z / 8; a.ntn = Cout / (32 * NT);
+    a.nbx = X / bxr; a.nby = Y / 8; a.nbz = Z / depth; a.ntn = Cout / (32 * NT);
     a.gn_acc = gn_acc;
     a.d1 = (bf16*)d1; a.d2 = (bf16*)d2; a.D1 = D1; a.a1 = (const bf16*)a1; a.a2 = (const bf16*)a2;
     a.zeros = tdx_scratch_ptr();
@@ -571,7 +614,12 @@ int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void
     const char* env = getenv("TDX_RING_LOADERS");  // A/B switch: 0 = the computing waves issue the copies themselves
     const bool lw = env ? atoi(env) != 0 : RG_DEFAULT_LOADERS;
     int rc;
-    if (hf) {  // fp16 operands: the loader-wave form only (the loader-less form is an A/B build of the bf16 kernels)
+    if (depth == 4) {  // 4-deep bricks: the loader-wave form only
+#define RG_Z4(NTV) (hf ? (zero_pad ? ring_go<NTV, true, 4, true, true>(a, st) : ring_go<NTV, false, 4, true, true>(a, st)) \
+                       : (zero_pad ? ring_go<NTV, true, 4, false, true>(a, st) : ring_go<NTV, false, 4, false, true>(a, st)))
+        rc = NT == 2 ? RG_Z4(2) : RG_Z4(1);
+#undef RG_Z4
+    } else if (hf) {  // fp16 operands: the loader-wave form only (the loader-less form is an A/B build of the bf16 kernels)
         if (NT == 2) rc = zero_pad ? ring_go<2, true, 4, true>(a, st) : ring_go<2, false, 4, true>(a, st);
         else rc = zero_pad ? ring_go<1, true, 4, true>(a, st) : ring_go<1, false, 4, true>(a, st);
     } else if (NT == 2) {
@@ -581,15 +629,17 @@ int conv3_ring_launch(const void* x1, int C1, const void* x2, int C2, const void
         if (lw) rc = zero_pad ? ring_go<1, true, 4, false>(a, st) : ring_go<1, false, 4, false>(a, st);
         else rc = zero_pad ? ring_go<1, true, 0, false>(a, st) : ring_go<1, false, 0, false>(a, st);
     }
-    const int bxr = NT == 2 ? 8 : 16;
-    if (rc != TDX_OK || ((X % bxr) == 0 && (Y % 8) == 0 && (Z % 8) == 0)) return rc;
+    if (rc != TDX_OK || ((X % bxr) == 0 && (Y % 8) == 0 && (Z % depth) == 0)) return rc;
     // the 1-2 voxel remainder slabs beyond the whole bricks: thin 2 x 16 x 8 bricks, all slabs in one launch (same
     // operands, same epilogue incl. the statistics accumulators and the data gradient's split / addends)
-    const int beyond[3] = {X - X % bxr, Y - Y % 8, Z - Z % 8};
+    const int beyond[3] = {X - X % bxr, Y - Y % 8, Z - Z % depth};
     const Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
     return conv3_mfma_launch(x1, C1, x2, C2, wp, bias, y, g, Cout, zero_pad, st, gn_acc, d1, D1, d2, a1, a2, nullptr, beyond, hf);
 }
 
 extern "C" int tdx_conv3_uses_ring(int C1, int C2, int Cout, int B, int X, int Y, int Z) {
     return conv3_ring_supported(C1, C2, Cout, B, X, Y, Z) ? 1 : 0;
+}
+extern "C" int tdx_conv3_ring_brick_depth(int C1, int C2, int Cout, int B, int X, int Y, int Z) {
+    return ring_brick_depth(C1, C2, Cout, B, X, Y, Z);
 }

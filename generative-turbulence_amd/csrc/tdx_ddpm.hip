@@ -474,3 +474,20 @@ extern "C" int tdx_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_i
     hipLaunchKernelGGL(advance_offset, dim3(1), dim3(1), 0, as_stream(stream), offset_dev, (uint64_t)n4);
     return tdx_launch_status();
 }
+
+
+// ------------------------------------------------------------------ host signal ----------
+// One lane stores gen * TDX_SIGNAL_STRIDE + k into a word of HOST memory (pinned, device-mapped) with a system-scope release:
+// everything enqueued before it on the stream -- the staging kernels of a gradient bucket inside a captured backward pass --
+// has completed and is visible.  This runtime refuses event-record nodes inside a captured graph
+// (hipEventRecordWithFlags(..., hipEventRecordExternal) -> hipErrorInvalidValue; torch: "External events are disallowed in
+// rocm", tools/micro/external_event_probe.py), so a graph-external stream cannot wait on a point INSIDE a graph; the host
+// can: it polls this word and launches the bucket's all-reduce on its communication stream while the rest of the graph runs.
+__global__ void signal_host_kernel(uint32_t* __restrict__ flag, const uint32_t* __restrict__ gen, uint32_t k) {
+    __hip_atomic_store(flag, gen[0] * (uint32_t)TDX_SIGNAL_STRIDE + k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" int tdx_signal_host(uint32_t* host_flag, const uint32_t* gen_dev, uint32_t k, void* stream) {
+    TDX_CHECK_ARG(host_flag && gen_dev && k < (uint32_t)TDX_SIGNAL_STRIDE);
+    hipLaunchKernelGGL(signal_host_kernel, dim3(1), dim3(1), 0, as_stream(stream), host_flag, gen_dev, k);
+    return tdx_launch_status();
+}

@@ -38,6 +38,7 @@ SIGNATURES = {
     "tdx_transpose_many": (_i, [_vp, _i, _vp]),
     "tdx_conv3_fwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_uses_ring": (_i, [_i] * 7),
+    "tdx_conv3_ring_brick_depth": (_i, [_i] * 7),
     "tdx_conv3_fwd_kernel": (_i, [_i] * 9),
     "tdx_conv3_fwd_gn": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tdx_conv3_fwd_partial": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
@@ -91,6 +92,7 @@ SIGNATURES = {
     "tdx_opt_chunk_elems": (_i64, []),
     "tdx_grad_norm": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "tdx_radam_step": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
+    "tdx_signal_host": (_i, [_vp, _vp, C.c_uint32, _vp]),
     "tdx_grad_norm_scaled": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "tdx_radam_step_scaled": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
 }

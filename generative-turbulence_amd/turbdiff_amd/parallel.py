@@ -132,6 +132,8 @@ class BucketedDataParallel:
         self._wait_events: list = []
         self._bucket_events: list = []                 # timing: per step {bucket: (launch event, wait start, wait end)}
         self._step_launch: dict = {}
+        self._cap = None                               # begin_capture() .. end_capture(): the hooks run inside a graph capture
+        self._comm_stream = None                       # replay_launch(): the stream the collectives of a replayed step start from
         if self.active and self.world > 1 and self.params and self.params[0].is_cuda and dist.get_backend(group) == "nccl":
             # RCCL's kernels and the persistent conv kernels share the chip: a launch script that did not size both gets a
             # warning (the run is correct, the overlap is not), not an error -- bench.py --gpus N sets both
@@ -235,6 +237,17 @@ class BucketedDataParallel:
 
     def _launch(self, b: int):
         assert b not in self._launched, "bucket launched twice in one step"
+        if self._cap is not None:
+            # inside a graph capture: no collective can be captured (gloo runs on the host; this runtime has no event-record
+            # graph nodes to release an RCCL stream either).  Leave a mark the HOST can see behind the bucket's staging
+            # kernels instead; replay_launch() starts the all-reduce when the mark appears
+            from . import _lib as L
+
+            cap = self._cap
+            cap["order"].append(b)
+            L.call("tdx_signal_host", cap["flag"].data_ptr(), L.ptr(cap["gen"]), len(cap["order"]), L.stream())
+            self._launched.add(b)
+            return
         flat = self._flat[b]
         if self.compress == "bf16":
             wire = self._wire[b]
@@ -247,6 +260,61 @@ class BucketedDataParallel:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()  # on the compute stream: where in backward this bucket's collective was enqueued
             self._step_launch[b] = ev
+
+    # -- captured training step (training.GraphedTrainingStep) -------------------------------
+    def begin_capture(self, gen: torch.Tensor):
+        """The next backward pass runs inside a hipGraph capture: the hooks' staging kernels (g / world -> bucket slice) are
+        captured as they are; where a hook would launch a bucket's all-reduce it captures `tdx_signal_host` instead (a word
+        of pinned host memory <- gen * 64 + position in the launch order; `gen`: int32 device scalar the graph increments
+        once per replay).  Needs the buckets (a static ready order, or one eager step before)."""
+        if not self.active:
+            return
+        if self._buckets is None:
+            raise RuntimeError("BucketedDataParallel.begin_capture: run one eager step first (the ready order is not known yet)")
+        assert not self._seen and not self._launched, "begin_capture() in the middle of a step"
+        flag = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self._cap = {"gen": gen, "flag": flag, "order": []}
+
+    def end_capture(self):
+        """-> the plan replay_launch() needs for every replay of the graph just captured (None when inactive)."""
+        if self._cap is None:
+            return None
+        cap, self._cap = self._cap, None
+        per_bucket = {}
+        for i in self._seen:
+            per_bucket[self._bucket_of[i]] = per_bucket.get(self._bucket_of[i], 0) + 1
+        plan = {"order": list(cap["order"]), "flag": cap["flag"], "flag_np": cap["flag"].numpy(), "params": frozenset(self._seen),
+                "per_bucket": per_bucket}
+        self._launched.clear()
+        self._seen.clear()
+        self._pending = [len(b) for b in self._buckets]
+        return plan
+
+    def replay_launch(self, plan, generation: int, timeout_s: float = 120.0):
+        """After `graph.replay()` of a step captured between begin_capture() / end_capture(): account for the gradients the
+        graph stages, and start every bucket's all-reduce from the communication stream the moment its mark shows up in
+        host memory -- i.e. while the rest of the captured backward is still running.  `generation`: how many times the graph
+        has been replayed, this replay included.  finish() completes the step as usual."""
+        if plan is None or not self.active or not self.enabled:
+            return
+        dev = self._flat[0].device
+        if dev.type == "cuda" and self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        self._seen |= plan["params"]
+        for b, n in plan["per_bucket"].items():
+            self._pending[b] -= n
+        flag, base = plan["flag_np"], (generation * 64) & 0x7FFFFFFF
+        for k, b in enumerate(plan["order"], 1):
+            deadline = time.perf_counter() + timeout_s
+            while int(flag[0]) < base + k:  # written by the captured tdx_signal_host behind bucket b's staging kernels
+                if time.perf_counter() > deadline:
+                    raise RuntimeError(f"replay_launch: bucket {b} of the captured step never signalled (flag {int(flag[0])}, "
+                                       f"expected >= {base + k})")
+            if self._comm_stream is not None:
+                with torch.cuda.stream(self._comm_stream):
+                    self._launch(b)
+            else:
+                self._launch(b)
 
     # -- per-step API ----------------------------------------------------------------------
     def finish(self):

@@ -335,8 +335,9 @@ class DiffusionTrainer(nn.Module):
     def enable_graph_step(self, on: bool = True):
         """fit_step runs forward + backward as ONE captured hipGraph per input signature (GraphedTrainingStep) instead of
         ~700 eager launches: the host's share of a step drops from ~9 ms (B = 6 at 192x64x48) / ~6 ms (48x32x32, where
-        it was the whole step) to the optimiser's ~1 ms.  Single GPU only (the gradient all-reduce hooks are not
-        captured)."""
+        it was the whole step) to the optimiser's ~1 ms.  With `self.ddp` (parallel.BucketedDataParallel) the hooks' staging
+        kernels are captured and every bucket's all-reduce is started by the host when the captured backward passes the
+        bucket's boundary (BucketedDataParallel.replay_launch): overlap as in the eager step."""
         self._graph_step = GraphedTrainingStep(self) if on else None
         return self
 
@@ -351,8 +352,6 @@ class DiffusionTrainer(nn.Module):
         scale_loss = getattr(self._opt, "scale_loss", None)
         gs = getattr(self, "_graph_step", None)
         if gs is not None:
-            if self.ddp is not None:
-                raise RuntimeError("graph_step: data-parallel gradient hooks are not captured; use the eager step")
             loss = gs(batch)  # leaves the gradients in the tensors the captured backward owns
         else:
             self._opt.zero_grad(set_to_none=True)
@@ -455,6 +454,9 @@ class GraphedTrainingStep:
         for p in slot.chained:  # their gradients come from the eager chain below, accumulated: start from nothing
             p.grad = None
         slot.graph.replay()
+        if slot.ddp_plan is not None:
+            slot.replays += 1
+            tr.ddp.replay_launch(slot.ddp_plan, slot.replays)  # the buckets' all-reduces, as the captured backward reaches them
         chain = [(v, slot.C[k].grad) for k, v in self._tensors(C).items() if v.requires_grad]
         if chain:
             torch.autograd.backward([v for v, _ in chain], [g for _, g in chain])
@@ -494,6 +496,8 @@ class GraphedTrainingStep:
 
         import warnings
 
+        ddp = getattr(tr, "ddp", None)
+        ddp = ddp if (ddp is not None and ddp.active) else None
         s = self.stream
         s.wait_stream(torch.cuda.current_stream(dev))
         with warnings.catch_warnings(record=True) as caught:
@@ -503,6 +507,8 @@ class GraphedTrainingStep:
                     for t in leaves:
                         t.grad = None
                     body()
+                    if ddp is not None:
+                        ddp.finish()  # (eager data-parallel steps: every rank runs the same two; they also fix the bucket order)
                 slot.arena = L.scratch_arena(dev)  # held while the graph lives (the arena map is bounded)
         torch.cuda.current_stream(dev).wait_stream(s)
         if any("AccumulateGrad node's stream" in str(w.message) for w in caught):
@@ -518,9 +524,17 @@ class GraphedTrainingStep:
         # buffers for packed operands of the current version
         torch.autograd.graph.increment_version([p for p in tr.model.parameters()])
         slot.graph = torch.cuda.CUDAGraph()
+        slot.ddp_plan, slot.replays = None, 0
+        if ddp is not None:
+            slot.gen = torch.zeros(1, dtype=torch.int32, device=dev)  # replay counter, read by the captured bucket marks
+            ddp.begin_capture(slot.gen)
 
         with torch.cuda.graph(slot.graph, stream=s):
+            if ddp is not None:
+                slot.gen.add_(1)
             slot.loss = body().detach()  # (no autograd graph outlives the capture: its nodes belong to this stream)
+        if ddp is not None:
+            slot.ddp_plan = ddp.end_capture()
         torch.autograd.graph.increment_version([p for p in tr.model.parameters()])
         # parameters the captured backward did not reach get their gradient from the eager chain (cell-type table)
         # the packed operands the captured launches read and refresh live in the model's pack plans: held here, so that a

@@ -129,6 +129,10 @@ int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, const void* wf
  * of whole 8x8x8 bricks that fill the chip, i.e. the two finest U-Net levels), 0 = the brick / small-grid kernels.
  * For a data gradient pass the layer's (Cout, 0, Cin) as (C1, C2, Cout). */
 int tdx_conv3_uses_ring(int C1, int C2, int Cout, int B, int X, int Y, int Z);
+/* The ring kernel's brick depth along z for that call: 8 (8 MT/2 x 8 x 8 bricks), 4 (round 6: 8 MT x 8 x 4 bricks, for grids
+ * like level 2 of the benchmark grid, 48 x 16 x 12, whose z extent is a multiple of 4 only), or 0 = not a ring launch.
+ * TDX_RING_Z4 in the environment (read per call): 0 = never 4-deep, 2 = 4-deep wherever legal (tests). */
+int tdx_conv3_ring_brick_depth(int C1, int C2, int Cout, int B, int X, int Y, int Z);
 /* Kernel family that tdx_conv3_fwd / tdx_conv3_fwd_gn run for a call with these arguments (same bookkeeping purpose):
  * vector-ALU, brick MFMA kernels (tdx_conv3_mfma*.hip), small-grid kernel (tdx_conv3_small.hip), ring kernel. */
 #define TDX_KERNEL_DIRECT 0
@@ -396,6 +400,18 @@ int tdx_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, uint64_t
  * uint64 trajectory ids) and every row the same offset, which is then advanced once. */
 int tdx_randn_batched(float* out, int B, int64_t n, uint64_t seed, const uint64_t* stream_ids, uint64_t* offset_dev,
                       void* stream);
+
+/* ---- a point inside a captured graph that the HOST can see -----------------------------------------
+ * Stores *gen_dev * TDX_SIGNAL_STRIDE + k (k < TDX_SIGNAL_STRIDE) into *host_flag -- pinned host memory mapped into the
+ * device's address space -- with a system-scope release, in stream order: when the host reads that value, everything
+ * enqueued before the call on `stream` has completed and is visible to later launches on any stream.  Used by the
+ * data-parallel captured training step (parallel.BucketedDataParallel.replay_launch): the reference's DDP (Lightning's
+ * strategy around torch.nn.parallel.DistributedDataParallel, train.py) launches a bucket's all-reduce from an autograd hook;
+ * a replayed hipGraph runs no hooks, and this ROCm runtime has no event-record graph nodes, so the host polls the word a
+ * captured kernel writes behind each bucket's staging and launches the collective itself.  gen_dev: a device counter the
+ * graph increments once per replay, so the values rise monotonically and the word never needs resetting. */
+#define TDX_SIGNAL_STRIDE 64
+int tdx_signal_host(uint32_t* host_flag, const uint32_t* gen_dev, uint32_t k, void* stream);
 
 /* ---- optimiser tail of the training step ------------------------------------------------------
  * Replaces torch.nn.utils.clip_grad_norm_ (Lightning gradient_clip_val = 0.1, config/train.yaml:30-31)

@@ -1166,6 +1166,11 @@ def test_conv3_data_gradient_deterministic_shell_route(case, mode, monkeypatch):
     # remainders on every axis / on one axis only / 32-wide tiles (16 x 8 x 8 bricks) / the reference's real grid and its level 1
     (1, 64, 0, 64, (50, 26, 18)), (2, 32, 32, 64, (24, 17, 16)), (2, 32, 0, 32, (34, 17, 9)), (1, 16, 0, 64, (194, 50, 50)),
     (2, 64, 64, 128, (97, 25, 25)),
+    # 4-deep bricks (round 6; the trailing 4 forces them where 8-deep ones are legal too): level 2 of the benchmark grid at its
+    # own channel counts (48 x 16 x 12: 128 -> 256, 256 -> 256, [256 | 256] -> 128), one brick, 32-wide tiles (32 x 8 x 4 bricks),
+    # remainders on every axis, a grid both depths can tile
+    (6, 128, 0, 256, (48, 16, 12), 4), (2, 256, 0, 256, (48, 16, 12), 4), (1, 256, 256, 128, (48, 16, 12), 4),
+    (2, 64, 0, 64, (16, 8, 4), 4), (2, 32, 0, 32, (64, 16, 12), 4), (1, 64, 0, 64, (34, 17, 14), 4), (2, 32, 32, 64, (32, 16, 16), 4),
 ])
 def test_conv3_ring_kernel_vs_brick_kernel(case, monkeypatch):
     """The persistent LDS-DMA ring kernel (tdx_conv3_ring.hip) against the brick kernel it replaces on the two finest
@@ -1176,7 +1181,9 @@ def test_conv3_ring_kernel_vs_brick_kernel(case, monkeypatch):
     a launch or arrive late (counted vmcnt waits)."""
     from turbdiff_amd import _lib as L, ops
 
-    B, C1, C2, Co, (X, Y, Z) = case
+    B, C1, C2, Co, (X, Y, Z) = case[:5]
+    depth = case[5] if len(case) > 5 else 8
+    monkeypatch.setenv("TDX_RING_Z4", "2" if depth == 4 else "0")
     d = dev()
     Ci = C1 + C2
     dt, DT = torch.bfloat16, L.BF16
@@ -1241,6 +1248,9 @@ def test_conv3_ring_kernel_vs_brick_kernel(case, monkeypatch):
     # the switch does select the kernel: with one workgroup per CU the ring launch leaves the brick path's timing,
     # not its results; check the dispatcher's own report instead
     assert bool(L.query("tdx_conv3_uses_ring", C1, C2, Co, B, X, Y, Z))
+    assert L.query("tdx_conv3_ring_brick_depth", C1, C2, Co, B, X, Y, Z) == depth
+    if depth == 4:
+        assert L.query("tdx_conv3_ring_brick_depth", Co, 0, Ci, B, X, Y, Z) == depth  # the data gradient's launch
 
 
 @pytest.mark.gpu

@@ -150,3 +150,94 @@ def test_rccl_world_size_one_runs_the_communicator_path(tmp_path):
             continue
         assert ((res["f32"][name] - ref).norm() / ref.norm()).item() < 2e-3, name     # atomics: not bit-identical
         assert ((res["bf16"][name] - ref).norm() / ref.norm()).item() < 1e-2, name    # travelled as bfloat16
+
+
+class _GraphTask:
+    """What training.GraphedTrainingStep asks of a task, around a bare GaussianDiffusion, dense inputs and a
+    BucketedDataParallel (the trainer's `ddp` attribute)."""
+
+    def __init__(self, diff, ddp):
+        self.model, self.ddp, self._opt = diff, ddp, None
+
+    def _model_input(self, b):
+        return b.x, b.C
+
+    def _cell_idx(self, b):
+        return b.cell_idx
+
+    def parameters(self):
+        return self.model.parameters()
+
+
+def _graph_ddp_worker(rank, world, port, outdir, backend):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda:0")
+    diff, x, C, md, t, noise = _build(dev)
+    from turbdiff_amd.parallel import BucketedDataParallel, init_from_env
+    from turbdiff_amd.training import GraphedTrainingStep
+
+    init_from_env(backend, force=world == 1)
+    ddp = BucketedDataParallel(diff, bucket_mb=0.25, force=world == 1)
+    lo = rank % x.shape[0]
+    xs, ts, ns = x[lo : lo + 1], t[lo : lo + 1], noise[lo : lo + 1]
+    # the eager data-parallel step on this rank's sample
+    diff.zero_grad(set_to_none=True)
+    loss, _ = diff.p_losses(xs, ts, C, md, None, noise=ns)
+    loss.backward()
+    ddp.finish()
+    eager = {n: p.grad.detach().cpu().clone() for n, p in diff.model.named_parameters()}
+    eager_loss = loss.item()
+    del loss
+    # the same step replayed from ONE captured graph: staging kernels captured, all-reduces started by the host when the
+    # captured backward passes each bucket's boundary
+    gs = GraphedTrainingStep(_GraphTask(diff, ddp), inject=True)
+    gs.set_draws(ts, ns)
+    batch = SimpleNamespace(x=xs, C=C, cell_idx=md.cell_idx)
+    graphed, losses = [], []
+    for step in range(3):
+        l = gs(batch)
+        ddp.finish()
+        torch.cuda.synchronize()
+        graphed.append({n: p.grad.detach().cpu().clone() for n, p in diff.model.named_parameters()})
+        losses.append(l.item())
+    (slot,) = gs.slots.values()
+    plan = slot.ddp_plan
+    info = {"order": plan["order"], "flag": int(plan["flag_np"][0]), "replays": slot.replays, "layout": ddp.bucket_layout(),
+            "captured_params": len(plan["params"]), "n_params": len(ddp.params), "steps": ddp.stats["steps"]}
+    torch.save((eager, eager_loss, graphed, losses, info), f"{outdir}/rank{rank}.pt")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+def test_captured_training_step_under_data_parallelism(tmp_path, backend, world):
+    """enable_graph_step with BucketedDataParallel.  Two ranks on the one GPU over gloo, and RCCL at world
+    size 1: the gradients a replayed graph + host-launched bucket all-reduces leave in p.grad equal the eager data-parallel
+    step's (same kernels; the halo-shell atomics of the data gradient differ in the last bits), replay after replay, on
+    every rank; every bucket was marked inside the graph in launch order and the mark word counts the replays."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_ddp_worker, args=(r, world, port, str(tmp_path), backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=280)
+        assert p.exitcode == 0
+    res = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    for r, (eager, eager_loss, graphed, losses, info) in enumerate(res):
+        assert len(info["layout"]) >= 2 and info["order"] == list(range(len(info["layout"]))), info  # buckets in ready order
+        assert info["captured_params"] == info["n_params"] and info["replays"] == 3
+        assert info["flag"] == 3 * 64 + len(info["order"]), info  # the last bucket's mark of the third replay
+        assert info["steps"] == 1 + 2 + 3  # the eager step, the two warm-up steps of the capture, three replays
+        for step, g in enumerate(graphed):
+            assert abs(losses[step] - eager_loss) < 1e-5 * abs(eager_loss)
+            for name, ref in eager.items():
+                if ref.norm() < 1e-6:
+                    assert g[name].norm() < 1e-5, name
+                else:
+                    assert ((g[name] - ref).norm() / ref.norm()).item() < 1e-4, (name, r, step)
+    for name in res[0][0]:  # ranks hold the same averaged gradients
+        for step in range(3):
+            assert torch.equal(res[0][2][step][name], res[-1][2][step][name]), name

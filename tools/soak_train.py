@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Training-trajectory comparison of the three numeric modes on the same seeds: 150 optimiser steps of the
+"""Training-trajectory comparison of the numeric modes on the same seeds: 150 optimiser steps of the
 BASELINE configs[1] step (B = 6, 192x64x48) in fp32 (IEEE fp32 MFMA convs), f32s (fp32 tensors, split-precision
-convs) and bf16; prints the loss every 10 steps, the largest relative loss deviation from the fp32 run, time
-per step and peak memory.  GPU box: python tools/soak_train.py [--steps 150] [--modes f32,f32s,bf16]"""
+convs), bf16 and fp16 (loss-scaled); prints the loss every 10 steps, the largest relative loss deviation from the first
+mode's run, time per step, peak memory and (fp16) the loss scale / skipped steps.
+GPU box: python tools/soak_train.py [--steps 150] [--modes f32,f32s,bf16,fp16]"""
 import argparse, os, sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "generative-turbulence_amd")
 from types import SimpleNamespace
@@ -18,9 +19,9 @@ def run(mode, steps):
         os.environ["TDX_CONV_IMPL"] = "split"
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    diff = bench.build_model(dev, torch.bfloat16 if mode == "bf16" else torch.float32)
-    opt = ClipRAdam(diff.parameters(), lr=1e-4, max_norm=0.1)
+    diff = bench.build_model(dev, bench.MODE_DTYPE[mode])
     x, c, idx = bench.synthetic_inputs(6, dev)
+    opt = bench.new_optimizer(diff, mode, bench.LOSS_ELEMENTS(6, idx))
     C = {Conditioning.Type.CELL_TYPE: c}; md = SimpleNamespace(cell_idx=idx)
     torch.manual_seed(0)  # same t and noise draws in every mode
     torch.cuda.reset_peak_memory_stats()
@@ -28,10 +29,12 @@ def run(mode, steps):
     torch.cuda.synchronize(); t0 = time.time()
     for step in range(steps):
         loss, _ = diff(x, C, md, None)
-        loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
+        opt.scale_loss(loss).backward(); opt.step(); opt.zero_grad(set_to_none=True)
         losses.append(loss.detach())
     torch.cuda.synchronize()
     dt = (time.time() - t0) / steps * 1e3
+    opt.settle()
+    run.note = f"  loss scale 2^{int(torch.tensor(opt.loss_scale).log2())}, {opt.skipped_steps} skipped" if opt.loss_scale else ""
     return [l.item() for l in losses], dt, torch.cuda.max_memory_allocated() / 1e9
 
 
@@ -48,7 +51,7 @@ def main():
             dev_ = max(abs(a_ - b_) / abs(b_) for a_, b_ in zip(losses, ref))
             line += f"   max |dloss|/loss vs {a.modes.split(',')[0]}: {dev_:.2e}"
         assert all(l == l for l in losses), "non-finite loss"
-        print(line, flush=True)
+        print(line + run.note, flush=True)
 
 
 if __name__ == "__main__":
