@@ -525,6 +525,55 @@ def real_grid_leg(dev, B):
     return res
 
 
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out += list(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def pin_host_threads(local_rank, local_world):
+    """Before anything touches the GPU: bind this rank's host threads (the issuing thread, autograd's backward thread, the
+    collective's proxy thread) to cores of its GPU's NUMA node -- eight ranks x two busy threads on one host otherwise
+    migrate across sockets and stretch the enqueue path the step depends on when per-GPU batches are small.  The GPU's
+    node comes from sysfs (amdgpu display-class PCI functions in bus order = HIP's default device order; `numa_node` /
+    `local_cpulist`), without a HIP call; the node's cores are split evenly among the ranks that share it.  Where sysfs
+    says nothing (a container without it, one NUMA node) the allowed cores are split evenly by rank.  Returns what was
+    done, for extra.overlap.host_affinity."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return {"pinned": False, "why": "no sched_setaffinity on this platform"}
+    if os.environ.get("TDX_BENCH_PIN", "1") == "0" or local_world <= 1 or len(allowed) < 2 * local_world:
+        return {"pinned": False, "why": "TDX_BENCH_PIN=0" if os.environ.get("TDX_BENCH_PIN", "1") == "0" else
+                f"{len(allowed)} allowed cores for {local_world} ranks"}
+    cores, source, node = None, "even split of the allowed cores by rank", None
+    try:
+        gpus = []
+        for dev in sorted(Path("/sys/bus/pci/devices").iterdir()):
+            if (dev / "vendor").read_text().strip() == "0x1002" and (dev / "class").read_text().strip().startswith("0x03"):
+                gpus.append(dev)
+        if len(gpus) >= local_world:
+            mine = gpus[local_rank]
+            node = int((mine / "numa_node").read_text())
+            local = [c for c in _parse_cpulist((mine / "local_cpulist").read_text()) if c in allowed]
+            sharers = [i for i, g in enumerate(gpus[:local_world]) if int((g / "numa_node").read_text()) == node]
+            per = len(local) // max(len(sharers), 1)
+            if node >= 0 and per >= 2:
+                k = sharers.index(local_rank)
+                cores, source = local[k * per : (k + 1) * per], f"sysfs: {mine.name} on NUMA node {node}, shared by ranks {sharers}"
+    except (OSError, ValueError):
+        pass
+    if not cores:
+        per = len(allowed) // local_world
+        cores = allowed[local_rank * per : (local_rank + 1) * per]
+    os.sched_setaffinity(0, cores)
+    return {"pinned": True, "cores": [cores[0], cores[-1]], "n_cores": len(cores), "numa_node": node, "source": source}
+
+
 def self_launch(n):
     """`python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same flags>` as a CHILD process
     on a free loopback port; returns its exit code."""
@@ -582,6 +631,9 @@ def main():
         # the caller chose otherwise -- 221 MB of gradients per ~22 ms step need ~10 GB/s per rank, far below what 32
         # channels move.  Both must be in the environment before the communicator exists.
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
+
+    # N > 1: NUMA-local cores for this rank's host threads, before anything (the library, the communicator) touches the GPU
+    affinity = pin_host_threads(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
 
     from turbdiff_amd import _lib, parallel
 
@@ -688,6 +740,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = train_step()
+        run_mode.host_enqueue_ms = 1e3 * (time.perf_counter() - t0) / steps  # this rank's wall time to ISSUE a step
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         _lib.TIMER = None
@@ -700,6 +753,7 @@ def main():
 
     leg_done("build_model_and_accuracy_probe")
     elapsed, (kern, timer), last_loss, train_step = run_mode(args.dtype, K, Wm)
+    headline_enqueue_ms = run_mode.host_enqueue_ms
     leg_done("headline_steps")
     value = world * B * V * K / elapsed
     out = {
@@ -761,6 +815,9 @@ def main():
         barrier()
         t_comm = max_over_ranks(time.perf_counter() - t0) / K
         t_step = elapsed / K
+        per_rank = [None] * world  # every rank's host enqueue time per step and where its threads are pinned
+        torch.distributed.all_gather_object(per_rank, {"rank": rank, "host_enqueue_ms_per_step": headline_enqueue_ms,
+                                                       "host_affinity": affinity})
         exposed = max_over_ranks(sum(exposed_ev) / max(len(exposed_ev), 1)) * 1e-3
         extra["overlap"] = {"ms_step": 1e3 * t_step, "ms_step_without_allreduce": 1e3 * t_nocomm,
                             "ms_allreduce_alone": 1e3 * t_comm, "ms_exposed": 1e3 * exposed,
@@ -773,9 +830,48 @@ def main():
                             # finish() still waited for it, and the fraction backward hid
                             "per_bucket": [dict(r, alone_ms=a, hidden_fraction=(1.0 - r["exposed_ms"] / a) if a > 0 else None)
                                            for r, a in zip(per_bucket, ddp.allreduce_alone_ms())],
+                            "per_rank": per_rank,
                             "persistent_cus": int(os.environ.get("TDX_PERSISTENT_CUS", "256")),
                             "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                             "payload_MB": sum(b for _, b in (ddp.bucket_layout() or [])) / 1e6}
+
+    # ---- N > 1: the same step with forward + backward replayed from ONE captured graph under data parallelism: the
+    # hooks' staging kernels are captured, every bucket's all-reduce is started by the host when the captured backward
+    # passes the bucket's boundary (BucketedDataParallel.replay_launch) -- what un-binds the host where per-GPU batches are small
+    if world > 1 and not args.no_extra and fused_opt:
+        from turbdiff_amd.training import GraphedTrainingStep
+
+        task = _Task(diff, None)
+        task.ddp = ddp
+        opt_g = new_optimizer(diff, args.dtype, LOSS_ELEMENTS(B, cell_idx))
+        task._opt = opt_g
+        gs = GraphedTrainingStep(task)
+        gbatch = SimpleNamespace(x=x, C=C, cell_idx=cell_idx)
+
+        def graph_step():
+            gs(gbatch)
+            ddp.finish()
+            opt_g.step()
+
+        try:
+            diff.zero_grad(set_to_none=True)
+            for _ in range(3):
+                graph_step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                graph_step()
+            enq = 1e3 * (time.perf_counter() - t0) / K
+            barrier()
+            t_graph = max_over_ranks(time.perf_counter() - t0) / K
+            extra["overlap"]["captured_step"] = {"ms_per_step": 1e3 * t_graph, "host_enqueue_ms_per_step_rank0": enq,
+                                                 "voxels_per_s": world * B * V / t_graph,
+                                                 "note": "forward + backward as one hipGraph per rank; bucket all-reduces launched by "
+                                                         "the host at the captured bucket boundaries; clip + RAdam eager"}
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline line
+            extra["overlap"]["captured_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        del gs, opt_g
+        diff.zero_grad(set_to_none=True)
 
     # ---- the modes that meet the 1e-4 parity gate, same run, same model (N = 1 only: they are not scaling legs)
     if world == 1 and not args.no_extra and not args.no_parity_modes:

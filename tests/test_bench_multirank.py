@@ -78,3 +78,17 @@ def test_bench_bare_command_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["value"] > 0
     ov = d["extra"]["overlap"]
     assert ov["ms_backward"] > 0 and ov["ms_exposed"] >= 0 and "HIP events" in ov["method"]
+    # the per-bucket report is populated, and the buckets were enqueued in backward order
+    assert ov["hidden_fraction"] is not None and len(ov["per_bucket"]) == len(ov["buckets"]) >= 4
+    at = [b["enqueued_at_ms"] for b in ov["per_bucket"]]
+    assert all(a is not None and a > 0 for a in at) and at == sorted(at), at
+    assert all(b["alone_ms"] > 0 and b["exposed_ms"] >= 0 and b["hidden_fraction"] is not None for b in ov["per_bucket"])
+    # item 7b: every rank reports its host enqueue time per step and where its threads are pinned
+    assert [r["rank"] for r in ov["per_rank"]] == [0, 1] and all(r["host_enqueue_ms_per_step"] > 0 for r in ov["per_rank"])
+    aff = [r["host_affinity"] for r in ov["per_rank"]]
+    assert all("pinned" in a for a in aff)
+    if all(a["pinned"] for a in aff):
+        assert aff[0]["cores"] != aff[1]["cores"] or aff[0]["numa_node"] != aff[1]["numa_node"]
+    # item 7a: the captured step ran under data parallelism in the same call
+    cs = ov["captured_step"]
+    assert "error" not in cs and cs["ms_per_step"] > 0, cs
