@@ -21,6 +21,7 @@
 // 6 + 8 MFMAs per 32 x 32 tile against the forward's 4; no atomics, no running maximum.
 #include "tdx_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -29,10 +30,31 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 #define FB_D 32
-#define FB_T 64            // rows of the walked side per staged tile
-#define FB_RW 64           // resident rows per wave
-#define FB_RB (4 * FB_RW)  // resident rows per workgroup
+#define FB_RB 256          // resident rows per workgroup
+// TW = resident 32-row tiles per wave: 2 (the default: 4 waves per workgroup, 2 waves per SIMD, ~250 / 230 registers) or 1
+// (round 6 experiment: 8 waves per workgroup, 3-4 waves per SIMD at <= 168 / 128 registers, as the forward kernel since round 5).
+// The ablations (profiles/r13_attention_bwd_ablation.txt) put 2.4 of the 11.5 ms in vector-ALU work next to a 9.1-ms floor of
+// the 14 MFMAs per tile pair; more waves per SIMD do not hide it (10.99-12.3 ms): kept as an A/B knob (TDX_ATTN_BWD_TW).
+// The walked side is staged in tiles of FB_T(TW) rows, one 16-B piece per thread.
+#define FB_WAVES(TW) (FB_RB / (32 * (TW)))
+// waves per SIMD the one-tile-per-wave kernels are compiled for (HIP: the second __launch_bounds__ argument is waves per
+// execution unit): 4 = at most 128 registers, 3 = at most 168
+#ifndef FB_MINW_DQ
+#define FB_MINW_DQ 4
+#endif
+#ifndef FB_MINW_DKV
+#define FB_MINW_DKV 4
+#endif
+#define FB_T(TW) (16 * FB_WAVES(TW))
 #define FB_LOG2E 1.4426950408889634f
+// Diagnostic builds only (tools/attn_bwd_ablation.sh compiles this file with -DFB_ABL=<bits>): what bounds the two kernels.
+//   1 no exponentials (the score stands in for P)          2 no elementwise product dS = P o dP
+//   4 no fp32 -> 16-bit conversions of P / dS (a resident fragment stands in as the B operand)
+//   8 no dP products (2 of the 6 / 8 MFMAs per tile)      16 no transposed LDS fragment reads (K^T, Q^T, dO^T)
+// The product build defines none of it.
+#ifndef FB_ABL
+#define FB_ABL 0
+#endif
 
 
 // operand element: bf16 (the model's bf16 mode) or fp16 (BASELINE configs[4]); see tdx_attention_mfma.hip
@@ -80,31 +102,32 @@ __device__ __forceinline__ typename E::V8 fb_row_frag(const typename E::T* row, 
 }
 
 // ------------------------------------------------------------------ dQ ---------------------------
-template <typename E>
-__global__ void __launch_bounds__(256, 2)
+template <typename E, int TW>
+__global__ void __launch_bounds__(64 * FB_WAVES(TW), TW == 1 ? FB_MINW_DQ : 2)
 attn_bwd_dq_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E::T* __restrict__ dout, const float* __restrict__ lse,
                         const float* __restrict__ delta, typename E::T* __restrict__ dqkv, int N, int H) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * FB_T * 64];
+    constexpr int T = FB_T(TW), RW = 32 * TW;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * T * 64];
     unsigned char* sK = smem;                  // K tile, swizzled chunks (S^T = K Q^T: A operand rows = keys)
-    unsigned char* sKp = smem + FB_T * 64;     // K tile, plain rows (K^T fragments by transposed reads)
-    unsigned char* sV = smem + 2 * FB_T * 64;  // V tile, swizzled chunks (dP^T = V dO^T)
+    unsigned char* sKp = smem + T * 64;        // K tile, plain rows (K^T fragments by transposed reads)
+    unsigned char* sV = smem + 2 * T * 64;     // V tile, swizzled chunks (dP^T = V dO^T)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int ld = 3 * H * FB_D;
     const typename E::T* base = qkv + (int64_t)b * N * ld;
-    const int q0 = blockIdx.x * FB_RB + wave * FB_RW;
+    const int q0 = blockIdx.x * FB_RB + wave * RW;
     const float sm_scale = rsqrtf((float)FB_D);
 
-    typename E::V8 qf[2][2], gf[2][2];  // Q (pre-scaled) and dO as B operands: col = query r, k = d
+    typename E::V8 qf[TW][2], gf[TW][2];  // Q (pre-scaled) and dO as B operands: col = query r, k = d
     // -lse log2(e) and -delta of the lane's query, broadcast over the 16 accumulator registers: as the C operands of the
     // score / dP products they deliver S^T - lse and dP^T - delta straight from the matrix pipe (the kernel is bound by its
     // vector-ALU work: that was 32 subtractions and 32 zeroing moves of ~110 issue slots per 32 x 32 tile)
-    f32x16 nl[2], nd[2];
-    f32x16 dq[2];               // dQ^T[d][q]
+    f32x16 nl[TW], nd[TW];
+    f32x16 dq[TW];               // dQ^T[d][q]
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < TW; ++qt) {
         const int q = min(q0 + qt * 32 + r, N - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -128,13 +151,13 @@ attn_bwd_dq_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E:
     const int t_col = (16 * (g & 1) + 4 * tp) * 2;
 
     load_tile(0);
-    for (int k0 = 0; k0 < N; k0 += FB_T) {
+    for (int k0 = 0; k0 < N; k0 += T) {
         __syncthreads();
         *reinterpret_cast<uint4*>(sK + fb_sw64(st_row, st_c)) = kreg;
         *reinterpret_cast<uint4*>(sKp + st_row * 64 + st_c * 16) = kreg;
         *reinterpret_cast<uint4*>(sV + fb_sw64(st_row, st_c)) = vreg;
         __syncthreads();
-        if (k0 + FB_T < N) load_tile(k0 + FB_T);
+        if (k0 + T < N) load_tile(k0 + T);
 
         auto key_block = [&](int kb, auto tail_c) {
             constexpr bool TAIL = decltype(tail_c)::value;
@@ -147,35 +170,39 @@ attn_bwd_dq_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E:
 #pragma unroll
             for (int s = 0; s < 2; ++s) {  // K^T: rows = d, k = key 16 s + 8 (j >> 2) + 4 hh + (j & 3)
                 const unsigned char* kp = sKp + (kb * 32 + 16 * s + 4 * (g >> 1) + tq) * 64 + t_col;
-                ktf[s] = fb_tr_frag<typename E::V8>(kp, kp + 8 * 64);
+                ktf[s] = (FB_ABL & 16) ? kf[s] : fb_tr_frag<typename E::V8>(kp, kp + 8 * 64);
             }
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < TW; ++qt) {
                 f32x16 st = E::mfma(kf[0], qf[qt][0], nl[qt]);   // S^T - lse
                 st = E::mfma(kf[1], qf[qt][1], st);
-                f32x16 dp = E::mfma(vf[0], gf[qt][0], nd[qt]);   // dP^T - delta
-                dp = E::mfma(vf[1], gf[qt][1], dp);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float p = __builtin_amdgcn_exp2f(st[i]);
-                    if (TAIL && k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= N) p = 0.f;  // keys beyond N
-                    st[i] = p * dp[i];  // dS^T
+                f32x16 dp = nd[qt];
+                if (!(FB_ABL & 8)) {
+                    dp = E::mfma(vf[0], gf[qt][0], nd[qt]);   // dP^T - delta
+                    dp = E::mfma(vf[1], gf[qt][1], dp);
                 }
 #pragma unroll
-                for (int s = 0; s < 2; ++s) dq[qt] = E::mfma(ktf[s], fb_as_b<E>(st, s), dq[qt]);
+                for (int i = 0; i < 16; ++i) {
+                    float p = (FB_ABL & 1) ? st[i] : __builtin_amdgcn_exp2f(st[i]);
+                    if (TAIL && k0 + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh >= N) p = 0.f;  // keys beyond N
+                    st[i] = (FB_ABL & 2) ? p : p * dp[i];  // dS^T
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) dq[qt] = E::mfma(ktf[s], (FB_ABL & 4) ? qf[qt][s] : fb_as_b<E>(st, s), dq[qt]);
+                if (FB_ABL & 4) dq[qt][0] += st[0] + st[15];  // (keeps the elementwise work alive)
             }
         };
-        if (k0 + FB_T <= N) {
+        if (k0 + T <= N) {
 #pragma unroll
-            for (int kb = 0; kb < FB_T / 32; ++kb) key_block(kb, std::false_type{});
+            for (int kb = 0; kb < T / 32; ++kb) key_block(kb, std::false_type{});
         } else {
 #pragma unroll
-            for (int kb = 0; kb < FB_T / 32; ++kb) key_block(kb, std::true_type{});
+            for (int kb = 0; kb < T / 32; ++kb) key_block(kb, std::true_type{});
         }
     }
     // dQ[q][h*D + d] = scale * dQ^T[d][q];  lane holds d = (i & 3) + 8 (i >> 2) + 4 hh
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < TW; ++qt) {
         const int q = q0 + qt * 32 + r;
         if (q < N) {
             typename E::T* op = dqkv + ((int64_t)b * N + q) * ld + h * FB_D;
@@ -190,30 +217,31 @@ attn_bwd_dq_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E:
 }
 
 // ------------------------------------------------------------------ dK, dV -----------------------
-template <typename E>
-__global__ void __launch_bounds__(256, 2)
+template <typename E, int TW>
+__global__ void __launch_bounds__(64 * FB_WAVES(TW), TW == 1 ? FB_MINW_DKV : 2)
 attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E::T* __restrict__ dout, const float* __restrict__ lse,
                          const float* __restrict__ delta, typename E::T* __restrict__ dqkv, int N, int H) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * FB_T * 64 + 2 * FB_T * 4];
+    constexpr int T = FB_T(TW), RW = 32 * TW;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * T * 64 + 2 * T * 4];
     unsigned char* sQ = smem;                   // Q tile, swizzled (S = Q K^T: A operand rows = queries)
-    unsigned char* sQp = smem + FB_T * 64;      // Q tile, plain rows (Q^T fragments)
-    unsigned char* sG = smem + 2 * FB_T * 64;   // dO tile, swizzled (dP = dO V^T)
-    unsigned char* sGp = smem + 3 * FB_T * 64;  // dO tile, plain rows (dO^T fragments)
-    float* sL = reinterpret_cast<float*>(smem + 4 * FB_T * 64);  // -lse * log2(e) of the tile's queries (-inf beyond N)
-    float* sD = sL + FB_T;                                        // -delta
+    unsigned char* sQp = smem + T * 64;         // Q tile, plain rows (Q^T fragments)
+    unsigned char* sG = smem + 2 * T * 64;      // dO tile, swizzled (dP = dO V^T)
+    unsigned char* sGp = smem + 3 * T * 64;     // dO tile, plain rows (dO^T fragments)
+    float* sL = reinterpret_cast<float*>(smem + 4 * T * 64);  // -lse * log2(e) of the tile's queries (-inf beyond N)
+    float* sD = sL + T;                                        // -delta
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
     const int ld = 3 * H * FB_D;
     const typename E::T* base = qkv + (int64_t)b * N * ld;
-    const int j0 = blockIdx.x * FB_RB + wave * FB_RW;
+    const int j0 = blockIdx.x * FB_RB + wave * RW;
     const float sm_scale = rsqrtf((float)FB_D);
 
-    typename E::V8 kf[2][2], vf[2][2];  // K (pre-scaled) and V as B operands: col = key r, k = d
-    f32x16 dk[2], dv[2];        // dK^T[d][key], dV^T[d][key]
+    typename E::V8 kf[TW][2], vf[TW][2];  // K (pre-scaled) and V as B operands: col = key r, k = d
+    f32x16 dk[TW], dv[TW];        // dK^T[d][key], dV^T[d][key]
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < TW; ++kt) {
         const int key = min(j0 + kt * 32 + r, N - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -231,7 +259,7 @@ attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E
         const int q = min(i0 + st_row, N - 1);
         qreg = *reinterpret_cast<const uint4*>(base + (int64_t)q * ld + h * FB_D + st_c * 8);
         greg = *reinterpret_cast<const uint4*>(dout + ((int64_t)b * N + q) * (H * FB_D) + h * FB_D + st_c * 8);
-        if (tid < FB_T) {
+        if (tid < T) {
             const int qq = i0 + tid;
             lreg = qq < N ? -lse[((int64_t)b * H + h) * N + qq] * FB_LOG2E : -INFINITY;  // exp2(s - inf) = 0: no query there
             dreg = qq < N ? -delta[((int64_t)b * H + h) * N + qq] : 0.f;
@@ -241,18 +269,18 @@ attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E
     const int t_col = (16 * (g & 1) + 4 * tp) * 2;
 
     load_tile(0);
-    for (int i0 = 0; i0 < N; i0 += FB_T) {
+    for (int i0 = 0; i0 < N; i0 += T) {
         __syncthreads();
         *reinterpret_cast<uint4*>(sQ + fb_sw64(st_row, st_c)) = qreg;
         *reinterpret_cast<uint4*>(sQp + st_row * 64 + st_c * 16) = qreg;
         *reinterpret_cast<uint4*>(sG + fb_sw64(st_row, st_c)) = greg;
         *reinterpret_cast<uint4*>(sGp + st_row * 64 + st_c * 16) = greg;
-        if (tid < FB_T) { sL[tid] = lreg; sD[tid] = dreg; }
+        if (tid < T) { sL[tid] = lreg; sD[tid] = dreg; }
         __syncthreads();
-        if (i0 + FB_T < N) load_tile(i0 + FB_T);
+        if (i0 + T < N) load_tile(i0 + T);
 
 #pragma unroll
-        for (int qb = 0; qb < FB_T / 32; ++qb) {
+        for (int qb = 0; qb < T / 32; ++qb) {
             typename E::V8 qa[2], ga[2], qtf[2], gtf[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {  // A operands: row = query r, k = d
@@ -262,8 +290,8 @@ attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E
 #pragma unroll
             for (int s = 0; s < 2; ++s) {  // Q^T, dO^T: rows = d, k = query 16 s + 8 (j >> 2) + 4 hh + (j & 3)
                 const int off = (qb * 32 + 16 * s + 4 * (g >> 1) + tq) * 64 + t_col;
-                qtf[s] = fb_tr_frag<typename E::V8>(sQp + off, sQp + off + 8 * 64);
-                gtf[s] = fb_tr_frag<typename E::V8>(sGp + off, sGp + off + 8 * 64);
+                qtf[s] = (FB_ABL & 16) ? qa[s] : fb_tr_frag<typename E::V8>(sQp + off, sQp + off + 8 * 64);
+                gtf[s] = (FB_ABL & 16) ? ga[s] : fb_tr_frag<typename E::V8>(sGp + off, sGp + off + 8 * 64);
             }
             // per-register row scalars: register i <-> query row (i & 3) + 8 (i >> 2) + 4 hh of the block.  The sixteen
             // (negated) values ARE the C operands of the score / dP products: S - lse and dP - delta come out of the
@@ -277,27 +305,31 @@ attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E
                 drow[4 * c] = d4.x; drow[4 * c + 1] = d4.y; drow[4 * c + 2] = d4.z; drow[4 * c + 3] = d4.w;
             }
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
+            for (int kt = 0; kt < TW; ++kt) {
                 f32x16 st = E::mfma(qa[0], kf[kt][0], lrow);
                 st = E::mfma(qa[1], kf[kt][1], st);
-                f32x16 dp = E::mfma(ga[0], vf[kt][0], drow);
-                dp = E::mfma(ga[1], vf[kt][1], dp);
+                f32x16 dp = drow;
+                if (!(FB_ABL & 8)) {
+                    dp = E::mfma(ga[0], vf[kt][0], drow);
+                    dp = E::mfma(ga[1], vf[kt][1], dp);
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    st[i] = __builtin_amdgcn_exp2f(st[i]);  // P
-                    dp[i] = st[i] * dp[i];                   // dS
+                    if (!(FB_ABL & 1)) st[i] = __builtin_amdgcn_exp2f(st[i]);  // P
+                    if (!(FB_ABL & 2)) dp[i] = st[i] * dp[i];                   // dS
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    dv[kt] = E::mfma(gtf[s], fb_as_b<E>(st, s), dv[kt]);
-                    dk[kt] = E::mfma(qtf[s], fb_as_b<E>(dp, s), dk[kt]);
+                    dv[kt] = E::mfma(gtf[s], (FB_ABL & 4) ? kf[kt][s] : fb_as_b<E>(st, s), dv[kt]);
+                    dk[kt] = E::mfma(qtf[s], (FB_ABL & 4) ? vf[kt][s] : fb_as_b<E>(dp, s), dk[kt]);
                 }
+                if (FB_ABL & 4) dv[kt][0] += st[0] + st[15] + dp[0] + dp[15];  // (keeps the elementwise work alive)
             }
         }
     }
     // dK[key][..] = scale * dK^T, dV[key][..] = dV^T;  lane holds d = (i & 3) + 8 (i >> 2) + 4 hh
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < TW; ++kt) {
         const int key = j0 + kt * 32 + r;
         if (key < N) {
             typename E::T* okp = dqkv + ((int64_t)b * N + key) * ld + H * FB_D + h * FB_D;
@@ -317,16 +349,23 @@ attn_bwd_dkv_mfma_kernel(const typename E::T* __restrict__ qkv, const typename E
 int attn_bwd_mfma_launch(const void* qkv, const void* dout, const float* lse, const float* delta, void* dqkv, int B, int N,
                          int H, int dtype, hipStream_t st) {
     dim3 grid(ceil_div(N, FB_RB), B * H);
-    if (dtype == TDX_F16) {
-        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<AttnF16>, grid, dim3(256), 0, st, (const f16*)qkv, (const f16*)dout, lse, delta,
-                           (f16*)dqkv, N, H);
-        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<AttnF16>, grid, dim3(256), 0, st, (const f16*)qkv, (const f16*)dout, lse, delta,
-                           (f16*)dqkv, N, H);
-    } else {
-        hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<AttnBf16>, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse, delta,
-                           (bf16*)dqkv, N, H);
-        hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<AttnBf16>, grid, dim3(256), 0, st, (const bf16*)qkv, (const bf16*)dout, lse, delta,
-                           (bf16*)dqkv, N, H);
-    }
+    // TDX_ATTN_BWD_TW (A/B knob, read per call): tiles per wave of the dQ / dK-dV kernel, "<dq><dkv>", e.g. 21.  Default 22
+    // (two tiles per wave, two waves per SIMD): one tile per wave at three or four waves per SIMD measured 10.99-12.3 ms
+    // against 11.4-11.5 (profiles/r13_attention_bwd_ablation.txt) -- more waves do not hide the vector work either
+    const char* env = getenv("TDX_ATTN_BWD_TW");
+    const int twq = env && env[0] == '1' ? 1 : 2, twk = env && env[0] && env[1] == '1' ? 1 : 2;
+#define FB_GO(E, T)                                                                                                            \
+    do {                                                                                                                       \
+        if (twq == 2) hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E, 2>), grid, dim3(64 * FB_WAVES(2)), 0, st, (const T*)qkv,   \
+                                         (const T*)dout, lse, delta, (T*)dqkv, N, H);                                          \
+        else hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<E, 1>), grid, dim3(64 * FB_WAVES(1)), 0, st, (const T*)qkv,            \
+                                (const T*)dout, lse, delta, (T*)dqkv, N, H);                                                   \
+        if (twk == 2) hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E, 2>), grid, dim3(64 * FB_WAVES(2)), 0, st, (const T*)qkv,  \
+                                         (const T*)dout, lse, delta, (T*)dqkv, N, H);                                          \
+        else hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<E, 1>), grid, dim3(64 * FB_WAVES(1)), 0, st, (const T*)qkv,           \
+                                (const T*)dout, lse, delta, (T*)dqkv, N, H);                                                   \
+    } while (0)
+    if (dtype == TDX_F16) FB_GO(AttnF16, f16); else FB_GO(AttnBf16, bf16);
+#undef FB_GO
     return tdx_launch_status();
 }

@@ -563,7 +563,8 @@ static bool ring_z8_supported(int C1, int C2, int Cout, int B, int X, int Y, int
     if (NT == 1 && std::max(C1, C2) > 32) return false;
     // persistent one-workgroup-per-CU launch: every CU should get several bricks
     const int64_t nb = (int64_t)B * (X / bx) * (Y / 8) * (Z / 8);
-    return nb * ntn >= 3 * 256;
+    const char* mi = getenv("TDX_RING_MIN_ITEMS");  // A/B knob, read per call: (brick, N tile) pairs a launch must have
+    return nb * ntn >= (mi ? atoi(mi) : 3 * 256);
 }
 
 #ifdef RG_STAMPS
