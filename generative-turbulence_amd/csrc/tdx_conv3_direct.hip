@@ -820,13 +820,6 @@ static int w3_slab_capacity(int Cin, int Cout) {
     const int64_t c = ((int64_t)1 << 19) / ((int64_t)Cin * Cout);
     return (int)(c < W3_MAX_SLABS ? W3_MAX_SLABS : (c > 512 ? 512 : c));
 }
-// TIMING EXPERIMENT ONLY (TDX_WGRAD_SKIP_UNPACK=1, read per call): leave out the unpack / slab-sum launch behind every weight
-// gradient -- the gradients are then garbage -- to measure what those 22 launches (0.32 ms serialised) cost the STEP: they run
-// on the side stream beside the data-gradient chain (profiles/r13_ab_unpack_off_the_critical_path.txt)
-static bool w3_skip_unpack() {
-    const char* e = getenv("TDX_WGRAD_SKIP_UNPACK");
-    return e && atoi(e) == 1;
-}
 extern "C" size_t tdx_conv3_bwd_weight_workspace_bytes(int Cin, int Cout, int impl) {
     (void)impl;
     // dw + dbias accumulators (the part covered by TDX_WS_CLEAN), then the partial-sum slabs (scratch, never needs zeroing)
@@ -874,7 +867,6 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
                                          dtype == TDX_F16);
         slab_ptr = slabs;
         if (rc != TDX_OK) return rc;
-        if (w3_skip_unpack()) return tdx_launch_status();
         if (nslab > W3_MAX_SLABS) {
             hipLaunchKernelGGL(conv3_unpack_sum_kernel, dim3(ceil_div(Cin, 8), ceil_div(Cout, 32), 27), dim3(256), 0, st, dw, dbw,
                                dbias, Cin, Cout, slab_ptr, nslab);
@@ -888,7 +880,6 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
                                                       (const T*)x1, C1, (const T*)x2, C2, (const T*)dy, dwp,
                                                       dbias ? dbw : nullptr, B, X, Y, Z, Cout, nci));
     }
-    if (w3_skip_unpack()) return tdx_launch_status();
     hipLaunchKernelGGL(conv3_unpack_wgrad_kernel, dim3(ceil_div(Cin, 16), ceil_div(Cout, 16)), dim3(256), 0, st, dwp, dw,
                        dbw, dbias, Cin, Cout, slab_ptr, nslab);
     return tdx_launch_status();

@@ -116,9 +116,13 @@ __device__ __forceinline__ int rg_tile_addr(int v, int c) {  // wave-private [32
 // 8-deep bricks to fill a persistent launch -- level 2 of the benchmark grid, 48 x 16 x 12 (reference ddpm.py:358), which ran
 // on the brick kernel at 0.26 of the MFMA peak.  An M tile is then a whole 8 (y) x 4 (z) plane of the brick, a wave owns MT
 // planes, the brick is 8 MT x 8 x 4 (64-wide tiles: 16 x 8 x 4, 32-wide: 32 x 8 x 4: the same 512 voxels as before).  The
-// image's z stride is the halo'd extent 6 itself: lanes (y, z) -> y = (r >> 1) & 7, z = (r & 1) + 2 (r >> 4) put the 16 lanes
-// of every ds_read_b128 group on entries 6 y + z (+ const), y = 0..7, z in {0, 1}: 16 distinct residues mod 16, conflict-free
-// without padding -- so the image of an 18-plane brick (17 KiB) still fits beside the weight ring.
+// image keeps the 8-deep layout's y stride of 12 entries -- the one pattern of 8 (y) x 4 (z) fragment lanes that
+// tools/micro/lds_pattern_probe.hip measures conflict-free (y = r & 7, z = r >> 3 on entries 12 y + z; every layout with a y
+// stride of 6 .. 11 costs +42 % per ds_read_b128 under any permutation of the lane bits) -- and puts TWO x planes into each
+// 12-entry row (entries 0-5: even halo plane, 6-11: odd), so the image of an 18-plane brick stays 17 KiB and fits beside the
+// weight ring: entry(hx, hy, hz) = (hx >> 1) 120 + 12 hy + 6 (hx & 1) + hz.  A tap's x step then depends on the parity of the
+// fragment's plane (+6 / -114 from an even halo plane, +114 / -6 from an odd one): two tap-offset tables, picked per M tile at
+// compile time (a wave's planes are w XP + mt with XP even).
 template <int NT, int LW = 0, bool Z4 = false>
 struct RingShape {
     static constexpr int IW = LW ? LW : 8;                  // waves that issue copies
@@ -129,7 +133,8 @@ struct RingShape {
     static constexpr int BZ = Z4 ? 4 : 8;                   // ... along z (y: 8)
     static constexpr int HZ = BZ + 2;
     static constexpr int SZ = Z4 ? RG_SZ4 : RG_SZ;          // z stride of the image
-    static constexpr int ENT = (BX + 2) * RG_HY * SZ;       // LDS entries of a brick image (16 B = 8 channels of a voxel)
+    static constexpr int ENT = Z4 ? (BX + 2) / 2 * RG_HY * RG_SZ   // (two x planes per 12-entry row)
+                                  : (BX + 2) * RG_HY * SZ;         // LDS entries of a brick image (16 B = 8 channels of a voxel)
     static constexpr int APIECES = (ENT + 63) / 64;         // 1-KiB DMA pieces: 19 / 34
     static constexpr int ABUF = APIECES * 1024;
     static constexpr int BPW = (APIECES + IW - 1) / IW;     // brick pieces per issuing wave and unit: 3 / 5 (LW = 4: 5 / 9)
@@ -196,8 +201,15 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
     for (int i = 0; i < BPW; ++i) {
         const int pi = min(max(iw, 0) * BPW + i, S::APIECES - 1);
         const int e = min(pi * 64 + lane, S::ENT - 1);
-        const int hx = e / (RG_HY * S::SZ), rem = e - hx * (RG_HY * S::SZ);
-        const int hy = rem / S::SZ, hz = min(rem - hy * S::SZ, S::HZ - 1);
+        int hx, hy, hz;
+        if (Z4) {  // entry = (hx >> 1) 120 + 12 hy + 6 (hx & 1) + hz
+            const int xp = e / (RG_HY * RG_SZ), rem = e - xp * (RG_HY * RG_SZ), q = rem % RG_SZ;
+            hy = rem / RG_SZ; hx = 2 * xp + q / RG_SZ4; hz = q % RG_SZ4;
+        } else {
+            hx = e / (RG_HY * S::SZ);
+            const int rem = e - hx * (RG_HY * S::SZ);
+            hy = rem / S::SZ; hz = min(rem - hy * S::SZ, S::HZ - 1);
+        }
         hxyz[i] = hx | (hy << 8) | (hz << 16);
     }
     // weight piece j of this wave: pj = wave * WPW + j -> entries 64 pj .. of [28 taps][BN]; tap 27 copies tap 26 (its x
@@ -211,20 +223,31 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
     }
 
     // ---- fragment geometry: M tile mt of wave w: x plane w XP + mt / 2, y = 4 (mt % 2) + (r & 3), z = r >> 2
-    // (Z4: x plane w XP + mt, y = (r >> 1) & 7, z = (r & 1) + 2 (r >> 4));
+    // (Z4: x plane w XP + mt, y = r & 7, z = r >> 3);
     // K step p: lanes 0-31 read tap 2p, lanes 32-63 tap 2p + 1 (the 28th: the zero entry)
-    const int ly = Z4 ? (r >> 1) & 7 : (r & 3), lz = Z4 ? (r & 1) + 2 * (r >> 4) : (r >> 2);  // voxel of this lane inside an M tile
+    const int ly = Z4 ? (r & 7) : (r & 3), lz = Z4 ? (r >> 3) : (r >> 2);  // voxel of this lane inside an M tile
     int a_h[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int px = Z4 ? wave * XP + mt : wave * XP + mt / 2, py = Z4 ? ly : 4 * (mt % 2) + ly;
-        a_h[mt] = (((px + 1) * RG_HY + (py + 1)) * S::SZ + (lz + 1)) * 16;
+        const int hx = px + 1;
+        a_h[mt] = Z4 ? ((hx >> 1) * (RG_HY * RG_SZ) + (py + 1) * RG_SZ + (hx & 1) * RG_SZ4 + (lz + 1)) * 16
+                     : ((hx * RG_HY + (py + 1)) * S::SZ + (lz + 1)) * 16;
     }
-    int xo[RG_STEPS];
+    // tap offsets; Z4: [0] for fragments on an ODD halo plane (M tiles mt even: hx = w XP + mt + 1), [1] for an even one
+    int xo[Z4 ? 2 : 1][RG_STEPS];
 #pragma unroll
     for (int p = 0; p < RG_STEPS; ++p) {
         const int t = min(2 * p + hh, 26);
-        xo[p] = (((t / 9 - 1) * RG_HY + ((t / 3) % 3 - 1)) * S::SZ + (t % 3 - 1)) * 16;
+        const int dx = t / 9 - 1, dy = (t / 3) % 3 - 1, dz = t % 3 - 1;
+        if (Z4) {
+            const int step_odd = dx > 0 ? RG_HY * RG_SZ - RG_SZ4 : (dx < 0 ? -RG_SZ4 : 0);   // from an odd plane
+            const int step_even = dx > 0 ? RG_SZ4 : (dx < 0 ? RG_SZ4 - RG_HY * RG_SZ : 0);   // from an even plane
+            xo[0][p] = (step_odd + dy * RG_SZ + dz) * 16;
+            xo[Z4 ? 1 : 0][p] = (step_even + dy * RG_SZ + dz) * 16;
+        } else {
+            xo[0][p] = ((dx * RG_HY + dy) * S::SZ + dz) * 16;
+        }
     }
     int b_off[NT];
 #pragma unroll
@@ -394,7 +417,7 @@ __global__ void __launch_bounds__(512 + 64 * LW, LW ? 3 : 2) conv3_ring_kernel(R
             auto read_frags = [&](int p, int fb) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const unsigned char* src = xa[mt] + xo[p];
+                    const unsigned char* src = xa[mt] + xo[Z4 ? (mt & 1) : 0][p];
                     if (p == RG_STEPS - 1) src = hh ? sZ : src;  // the 28th tap multiplies zeros
                     xf[fb][mt] = *reinterpret_cast<const bf16x8*>(src);
                 }
