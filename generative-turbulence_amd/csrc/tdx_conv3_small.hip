@@ -130,10 +130,25 @@ static bool small_plan(SmallGeom& g, int B, int X, int Y, int Z, int K, int N, b
         g.xs = ceil_div(g.Ev[0], g.gx);  // even slabs
     }
     g.Ix = g.xs + 2; g.Iy = g.Ev[1] + 2; g.Iz = g.Ev[2] + 2;
-    const int img = g.Ix * g.Iy * g.Iz;
+    int img = g.Ix * g.Iy * g.Iz;
     auto lds_for = [&](int nbg) { return (size_t)4 * (((size_t)nbg * img + 63) & ~(size_t)63) * 16 + (size_t)4 * (27 * SM_BN * 16 + 512); };
     while (g.nbg > 1 && ((int64_t)g.nbg * img > 2048 || lds_for(g.nbg) > 160 * 1024)) --g.nbg;  // DMA plan: 4 x 8 x 64 entries
     if ((int64_t)g.nbg * img > 2048) return false;
+    {
+        // z stride of the image: a lane reads the fragment of ROW r of a densely packed M tile, i.e. of voxel r of a (y, z)-ordered
+        // run, so the 16-B slots a ds_read_b128 touches are runs of Ev[2] entries one image row apart; with the natural stride
+        // Ev[2] + 2 that costs 1.6-1.9x a conflict-free read (tools/micro/lds_pattern_probe.hip: 68-78 ticks against 41), with the
+        // strides below 1.43x (59: the best any stride <= 16 reaches).  The padding entries are copied like rim entries and never
+        // read.  Taken only where the group still fits the DMA plan and the LDS as planned (TDX_SMALL_ZPAD=0: off, A/B switch)
+        static const int good[9] = {0, 0, 0, 9, 0, 9, 10, 0, 12};  // Ev[2] -> stride
+        const char* env = getenv("TDX_SMALL_ZPAD");
+        const int want = (g.Ev[2] <= 8 && !(env && atoi(env) == 0)) ? good[g.Ev[2]] : 0;
+        if (want > g.Iz) {
+            const int padded = g.Ix * g.Iy * want, keep = img;
+            img = padded;
+            if ((int64_t)g.nbg * padded <= 2048 && lds_for(g.nbg) <= 160 * 1024) g.Iz = want; else img = keep;
+        }
+    }
     lds_bytes = lds_for(g.nbg);
     if (lds_bytes > 160 * 1024) return false;
     // K splits.  One workgroup per CU (LDS), so a launch runs in rounds of 256 workgroups; a split count is judged by

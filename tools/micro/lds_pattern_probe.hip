@@ -106,6 +106,33 @@ int main() {
             (void)hipFree(d_entry); (void)hipFree(out); (void)hipFree(cyc);
         }
     } while (std::next_permutation(perm, perm + 5));
+    // the small-grid kernel's rows (lane r = voxel r of a (y, z)-ordered run, Z voxels per z row) for image z strides Z + 2 .. 16
+    // and y strides Iy * sz (+ 0 .. 3 entries of padding per x plane): what would a padded image buy?
+    for (int Z : {3, 5, 6, 8}) {
+        const int Y = Z == 3 ? 4 : (Z == 5 ? 6 : (Z == 6 ? 8 : 10));
+        printf("rows of %d voxels (Y = %d):", Z, Y);
+        for (int sz = Z + 2; sz <= 16; ++sz) {
+            double worst = 0;
+            for (int start = 0; start < Z * Y; start += 5) {  // M tiles start anywhere in the run
+                for (int l = 0; l < 64; ++l) {
+                    const int v = start + (l & 31), lx = v / (Z * Y), ly = (v / Z) % Y, lz = v % Z;
+                    e[l] = (lx * (Y + 2) + ly) * sz + lz + (l >> 5) * 4096;
+                }
+                int* d_entry; unsigned* out; unsigned long long* cyc;
+                (void)hipMalloc(&d_entry, 256); (void)hipMalloc(&out, 4); (void)hipMalloc(&cyc, 8 * 256);
+                (void)hipMemcpy(d_entry, e, 256, hipMemcpyHostToDevice);
+                hipLaunchKernelGGL(probe, dim3(64), dim3(1024), 0, 0, d_entry, out, cyc, 64);
+                unsigned long long h[64];
+                (void)hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+                double sum = 0;
+                for (int i = 0; i < 64; ++i) sum += (double)h[i];
+                worst = std::max(worst, sum / 64 / (64 * 16.0));
+                (void)hipFree(d_entry); (void)hipFree(out); (void)hipFree(cyc);
+            }
+            printf(" sz %d: %.0f", sz, worst);
+        }
+        printf("\n");
+    }
     for (int sz = 6; sz < 12; ++sz)
         printf("z stride %2d: best %.2f ticks with v bits <- lane bits {%d %d %d %d %d} (y = v & 7, z = v >> 3)\n", sz, best[sz], best_perm[sz][0],
                best_perm[sz][1], best_perm[sz][2], best_perm[sz][3], best_perm[sz][4]);
