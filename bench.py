@@ -181,9 +181,9 @@ def torch_rocm_baseline(B, dev, amp, steps=2):
 
 # forward instantiations of the matrix-core conv kernels in a rocprofv3 kernel name (ZERO_PAD / ZP template argument false)
 FWD_KERNEL_PATTERNS = {
-    # <NT, ZP, LW, HF> | <NT, XT, ZERO_PAD, PERM, EXT, HF>; HF = fp16 operands
-    "bf16": r"conv3_ring_kernel<\d, false, \d, false>|conv3_mfma_kernel<\d, (true|false), false, (true|false), (true|false), false>",
-    "fp16": r"conv3_ring_kernel<\d, false, \d, true>|conv3_mfma_kernel<\d, (true|false), false, (true|false), (true|false), true>",
+    # <NT, ZP, LW, HF, Z4> | <NT, XT, ZERO_PAD, PERM, EXT, HF>; HF = fp16 operands, Z4 = 4-deep bricks
+    "bf16": r"conv3_ring_kernel<\d, false, \d, false, (true|false)>|conv3_mfma_kernel<\d, (true|false), false, (true|false), (true|false), false>",
+    "fp16": r"conv3_ring_kernel<\d, false, \d, true, (true|false)>|conv3_mfma_kernel<\d, (true|false), false, (true|false), (true|false), true>",
     "f32": r"conv3_mfma_f32_kernel<\d, false,", "f32s": r"conv3_mfma_split_kernel<\d, false,"}
 
 
@@ -232,6 +232,52 @@ def measured_traffic(mode="bf16"):
     return None, {"file": None, "kernel_sources_sha16": now, "refused": refused[:3]}, 0
 
 
+def live_traffic(mode, batch, timeout_s=240):
+    """HBM bytes per launch of the mode's forward brick / ring conv kernels, measured NOW on this box: two child runs of this
+    script (3 steps of the headline step, nothing else) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE`
+    -- separate passes, counters only, as MI355X_MICROARCH.md prescribes (FETCH_SIZE counts 64 B per 128-B request on gfx950:
+    doubled; both are in KB).  Started from main() BEFORE this process touches the GPU; children are ordinary subprocesses
+    (`rocprofv3 ... -- python3 bench.py ...`).  -> (bytes per launch | None, source dict, launches sampled)."""
+    import csv
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if Path("/opt/rocm/bin/rocprofv3").exists() else None)
+    if exe is None:
+        return None, {"live": False, "why": "rocprofv3 not on PATH"}, 0
+    pat = FWD_KERNEL_PATTERNS[mode]
+    env = dict(os.environ, TDX_BENCH_CHILD="1", TMPDIR="/tmp", TDX_WGRAD_STREAM="0")
+    sums, n_launch, note = {}, {}, []
+    with tempfile.TemporaryDirectory(dir="/tmp", prefix="tdx_traffic_") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = Path(tmp) / counter
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", str(out), "--", sys.executable,
+                   str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--dtype", mode,
+                   "--batch", str(batch)]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, {"live": False, "why": f"rocprofv3 --pmc {counter} pass did not finish in {timeout_s} s"}, 0
+            files = list(out.glob("**/*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, {"live": False, "why": f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-200:]}"}, 0
+            tot = cnt = 0.0
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter and re.search(pat, row["Kernel_Name"]):
+                    tot += float(row["Counter_Value"])
+                    cnt += 1
+            sums[counter], n_launch[counter] = tot, cnt
+    if not n_launch["FETCH_SIZE"] or n_launch["FETCH_SIZE"] != n_launch["WRITE_SIZE"]:
+        return None, {"live": False, "why": f"no matching launches in the counter tables ({n_launch})"}, 0
+    n = n_launch["FETCH_SIZE"]
+    per_launch = (2.0 * sums["FETCH_SIZE"] + sums["WRITE_SIZE"]) * 1024.0 / n
+    return per_launch, {"live": True, "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes of 3 headline steps in "
+                        "child processes of this run, kernels one after the other: TDX_WGRAD_STREAM=0); FETCH_SIZE x 2 (gfx950), KB -> bytes",
+                        "read_bytes_per_launch": 2.0 * sums["FETCH_SIZE"] * 1024.0 / n, "write_bytes_per_launch": sums["WRITE_SIZE"] * 1024.0 / n}, int(n)
+
+
 CONV_CALLS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add", "tdx_conv3_bwd_weight"}
 
 
@@ -246,6 +292,9 @@ def merged_kernel_times(timer, where=None):
             for k in f:
                 f[k] += g[k]
     return kern
+
+
+LIVE_TRAFFIC = {}  # mode -> live_traffic() result of this run (filled by main() before the GPU is touched)
 
 
 def roofline_block(timer, mode, B, K):
@@ -263,7 +312,12 @@ def roofline_block(timer, mode, B, K):
         return None
     ach = main["work"] / (main["ms"] * 1e-3) / 1e12
     ach_all = every["work"] / (every["ms"] * 1e-3) / 1e12
-    traffic, tsrc, tn = measured_traffic(mode)
+    traffic, tsrc, tn = LIVE_TRAFFIC.get(mode) or (None, None, 0)
+    if traffic is None:  # no live measurement (no rocprofv3, N > 1, --no-live-traffic): the committed PMC file of this tree's kernels
+        why = tsrc
+        traffic, tsrc, tn = measured_traffic(mode)
+        if why is not None:
+            tsrc = dict(tsrc, live_attempt=why)
     ring = merged_kernel_times(timer, lambda m: m.get("kind") == _lib.KERNEL_RING).get("tdx_conv3_fwd")
     return {"bound": "mfma", "achieved": ach, "peak": PEAK[mode], "unit": "TFLOP/s", "frac": ach / PEAK[mode],
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE), same launches",
@@ -617,6 +671,9 @@ def main():
                     help="skip the stock PyTorch-ROCm leg (BASELINE configs[1]: 'HIP Conv3d vs PyTorch-ROCm Conv3d': the same "
                          "step through MIOpen conv3d / ATen ops, 2 steps bf16 autocast + 1 step fp32 -> extra.torch_rocm_reference)")
     ap.add_argument("--torch-baseline", action="store_true", help="(default since round 3; kept for old command lines)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes, ~1 min); quote the committed "
+                         "PMC file of this tree's kernels instead")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -631,6 +688,15 @@ def main():
         # the caller chose otherwise -- 221 MB of gradients per ~22 ms step need ~10 GB/s per rank, far below what 32
         # channels move.  Both must be in the environment before the communicator exists.
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
+
+    # roofline.traffic of the headline mode, measured on THIS box in this run: before anything here touches the GPU
+    if (args.gpus == 1 and not args.no_live_traffic and not args.no_extra and os.environ.get("TDX_BENCH_CHILD") != "1"
+            and "WORLD_SIZE" not in os.environ):
+        t_live = time.perf_counter()
+        live_modes = [args.dtype] + ([m for m in ("fp16", "bf16", "f32s", "f32") if m != args.dtype] if not args.no_parity_modes else [])
+        for m in live_modes:  # the headline mode and every parity mode that gets a roofline block below
+            LIVE_TRAFFIC[m] = live_traffic(m, args.batch)
+        LIVE_TRAFFIC["wall_s"] = round(time.perf_counter() - t_live, 1)
 
     # N > 1: NUMA-local cores for this rank's host threads, before anything (the library, the communicator) touches the GPU
     affinity = pin_host_threads(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
@@ -1023,6 +1089,8 @@ def main():
         out.setdefault("extra", {})["torch_rocm_reference"] = ref
         leg_done("torch_rocm_reference")
     if rank == 0 and wall:
+        if "wall_s" in LIVE_TRAFFIC:
+            wall["live_traffic_pmc_passes"] = LIVE_TRAFFIC["wall_s"]
         out.setdefault("extra", {})["wall_s"] = wall
 
     if cpu is not None:
