@@ -367,3 +367,84 @@ def test_ddp_cu_budget_check():
         check_cu_budget({"NCCL_MAX_NCHANNELS": "8"})  # default: all 256 CUs
     with pytest.raises(RuntimeError, match="NCCL_MAX_NCHANNELS"):
         check_cu_budget({"TDX_PERSISTENT_CUS": "224"})
+
+
+def test_bench_pins_each_rank_to_its_own_cores(tmp_path):
+    """bench.py's N > 1 preamble: every rank binds its host threads to its own block of cores before
+    anything touches the GPU -- NUMA-local ones where sysfs names the GPU's node, an even split of the allowed cores
+    otherwise; one rank (the default run) is left alone.  Run in child processes: the affinity is per process."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 4:
+        import pytest
+
+        pytest.skip("needs at least four cores")
+    code = ("import json, os, sys; sys.path.insert(0, %r); import bench; r = bench.pin_host_threads(int(sys.argv[1]), int(sys.argv[2])); "
+            "r['now'] = sorted(os.sched_getaffinity(0)); print(json.dumps(r))" % str(root))
+    res = []
+    for rank in range(2):
+        out = subprocess.run([sys.executable, "-c", code, str(rank), "2"], capture_output=True, text=True, check=True)
+        res.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert all(r["pinned"] for r in res), res
+    assert not set(res[0]["now"]) & set(res[1]["now"]), "ranks must not share cores"
+    assert all(set(r["now"]) <= set(allowed) and len(r["now"]) >= 2 for r in res)
+    one = subprocess.run([sys.executable, "-c", code, "0", "1"], capture_output=True, text=True, check=True)
+    one = json.loads(one.stdout.strip().splitlines()[-1])
+    assert one["pinned"] is False and one["now"] == allowed
+    off = subprocess.run([sys.executable, "-c", code, "1", "2"], capture_output=True, text=True, check=True,
+                         env=dict(os.environ, TDX_BENCH_PIN="0"))
+    assert json.loads(off.stdout.strip().splitlines()[-1])["pinned"] is False
+
+
+def test_bench_live_traffic_reads_the_counter_tables(tmp_path, monkeypatch):
+    """bench.live_traffic (roofline.traffic measured in the run itself): drives `rocprofv3 --kernel-trace --pmc <counter> ... --
+    python bench.py ...` once per counter and turns the two counter tables into bytes per launch of the mode's FORWARD brick /
+    ring conv kernels only (FETCH_SIZE x 2 on gfx950, KB -> bytes).  Here a stand-in profiler writes the tables."""
+    import os
+    import stat
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    import bench
+
+    fake = tmp_path / "bin"
+    fake.mkdir()
+    script = fake / "rocprofv3"
+    script.write_text('''#!%s
+import os, sys
+a = sys.argv[1:]
+counter, out = a[a.index("--pmc") + 1], a[a.index("-d") + 1]
+assert "--kernel-trace" in a and a[a.index("--") + 1].endswith("python3") or "python" in a[a.index("--") + 1]
+assert os.environ.get("TDX_BENCH_CHILD") == "1" and "--no-extra" in a
+os.makedirs(out + "/host", exist_ok=True)
+rows = [("void conv3_ring_kernel<2, false, 4, false, false>(RingArgs)", 100.0, 50.0),   # forward, bf16: counted
+        ("void conv3_ring_kernel<2, false, 4, false, true>(RingArgs)", 20.0, 10.0),     # forward, 4-deep bricks: counted
+        ("void conv3_mfma_kernel<1, false, false, false, false, false>(x)", 300.0, 30.0),  # forward brick kernel: counted
+        ("void conv3_ring_kernel<2, true, 4, false, false>(RingArgs)", 999.0, 999.0),   # data gradient: not counted
+        ("void conv3_ring_kernel<2, false, 4, true, false>(RingArgs)", 777.0, 777.0),   # fp16 forward: not counted in bf16
+        ("gn_apply_kernel", 5.0, 5.0)]
+with open(out + "/host/1_counter_collection.csv", "w") as f:
+    f.write('"Kernel_Name","Counter_Name","Counter_Value"\\n')
+    for name, fetch, write in rows * 2:
+        f.write('"%%s","%%s",%%f\\n' %% (name, counter, fetch if counter == "FETCH_SIZE" else write))
+''' % sys.executable)
+    script.chmod(script.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", f"{fake}:{os.environ['PATH']}")
+    per_launch, src, n = bench.live_traffic("bf16", 6)
+    assert src["live"] is True and n == 6
+    assert per_launch == (2 * (100 + 20 + 300) + (50 + 10 + 30)) * 1024 / 3
+    assert src["read_bytes_per_launch"] == 2 * 420 * 1024 / 3 and src["write_bytes_per_launch"] == 90 * 1024 / 3
+    per16, _, n16 = bench.live_traffic("fp16", 6)
+    assert n16 == 2 and per16 == (2 * 777 + 777) * 1024
+    # a profiler that fails is reported, not fatal: bench.py then quotes the committed PMC file of this tree's kernels
+    script.write_text("#!/bin/sh\nexit 3\n")
+    bad, why, _ = bench.live_traffic("bf16", 6)
+    assert bad is None and why["live"] is False and "failed" in why["why"]

@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--cases", help="torch.save'd {'cases': [...], 'stats': OpenFOAMStats.stats} of the validation cases")
     ap.add_argument("--synthetic", type=int, default=0, help="evaluate on N synthetic cases instead")
     ap.add_argument("--start-from", type=int, default=None, help="start the reverse process at this step (smoke runs)")
-    ap.add_argument("--compute-mode", default=None, choices=[None, "f32", "f32s", "bf16"])
+    ap.add_argument("--compute-mode", default=None, choices=[None, "f32", "f32s", "bf16", "fp16"])
     ap.add_argument("ckpt", help="Path to .ckpt file")
     ap.add_argument("samples_path", help=".npz file for storing samples")
     ap.add_argument("overrides", nargs="*")
