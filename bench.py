@@ -694,8 +694,15 @@ def main():
             and "WORLD_SIZE" not in os.environ):
         t_live = time.perf_counter()
         live_modes = [args.dtype] + ([m for m in ("fp16", "bf16", "f32s", "f32") if m != args.dtype] if not args.no_parity_modes else [])
+        deadline = t_live + 300.0  # all passes together (normally ~30 s); a pass that fails or stalls ends the attempt for every mode
         for m in live_modes:  # the headline mode and every parity mode that gets a roofline block below
-            LIVE_TRAFFIC[m] = live_traffic(m, args.batch)
+            left = deadline - time.perf_counter()
+            if left < 20.0:
+                LIVE_TRAFFIC[m] = (None, {"live": False, "why": "the run's budget for PMC passes was used up"}, 0)
+                continue
+            LIVE_TRAFFIC[m] = live_traffic(m, args.batch, timeout_s=min(120.0, left))
+            if LIVE_TRAFFIC[m][0] is None:
+                deadline = 0.0
         LIVE_TRAFFIC["wall_s"] = round(time.perf_counter() - t_live, 1)
 
     # N > 1: NUMA-local cores for this rank's host threads, before anything (the library, the communicator) touches the GPU
