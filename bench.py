@@ -908,44 +908,6 @@ def main():
                             "nccl_max_nchannels": os.environ.get("NCCL_MAX_NCHANNELS"),
                             "payload_MB": sum(b for _, b in (ddp.bucket_layout() or [])) / 1e6}
 
-    # ---- N > 1: the same step with forward + backward replayed from ONE captured graph under data parallelism: the
-    # hooks' staging kernels are captured, every bucket's all-reduce is started by the host when the captured backward
-    # passes the bucket's boundary (BucketedDataParallel.replay_launch) -- what un-binds the host where per-GPU batches are small
-    if world > 1 and not args.no_extra and fused_opt:
-        from turbdiff_amd.training import GraphedTrainingStep
-
-        task = _Task(diff, None)
-        task.ddp = ddp
-        opt_g = new_optimizer(diff, args.dtype, LOSS_ELEMENTS(B, cell_idx))
-        task._opt = opt_g
-        gs = GraphedTrainingStep(task)
-        gbatch = SimpleNamespace(x=x, C=C, cell_idx=cell_idx)
-
-        def graph_step():
-            gs(gbatch)
-            ddp.finish()
-            opt_g.step()
-
-        try:
-            diff.zero_grad(set_to_none=True)
-            for _ in range(3):
-                graph_step()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(K):
-                graph_step()
-            enq = 1e3 * (time.perf_counter() - t0) / K
-            barrier()
-            t_graph = max_over_ranks(time.perf_counter() - t0) / K
-            extra["overlap"]["captured_step"] = {"ms_per_step": 1e3 * t_graph, "host_enqueue_ms_per_step_rank0": enq,
-                                                 "voxels_per_s": world * B * V / t_graph,
-                                                 "note": "forward + backward as one hipGraph per rank; bucket all-reduces launched by "
-                                                         "the host at the captured bucket boundaries; clip + RAdam eager"}
-        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline line
-            extra["overlap"]["captured_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
-        del gs, opt_g
-        diff.zero_grad(set_to_none=True)
-
     # ---- the modes that meet the 1e-4 parity gate, same run, same model (N = 1 only: they are not scaling legs)
     if world == 1 and not args.no_extra and not args.no_parity_modes:
         pm = {}
@@ -1099,6 +1061,62 @@ def main():
         if "wall_s" in LIVE_TRAFFIC:
             wall["live_traffic_pmc_passes"] = LIVE_TRAFFIC["wall_s"]
         out.setdefault("extra", {})["wall_s"] = wall
+
+    # ---- N > 1, LAST leg: the same step with forward + backward replayed from ONE captured graph under data parallelism: the
+    # hooks' staging kernels are captured, every bucket's all-reduce is started by the host when the captured backward
+    # passes the bucket's boundary (BucketedDataParallel.replay_launch) -- what un-binds the host where per-GPU batches are small.
+    # It has never met a second GPU, and a rank that fails alone leaves the others inside a collective: so it runs after
+    # everything else is measured, under a watchdog -- if it does not return in time, rank 0 prints the line it has (with a
+    # note instead of this leg) and every rank leaves.
+    if world > 1 and not args.no_extra and fused_opt and "overlap" in extra:
+        import threading
+
+        from turbdiff_amd.training import GraphedTrainingStep
+
+        def give_up():
+            extra["overlap"]["captured_step"] = {"error": "did not finish within its 240-s watchdog; the line was printed without it"}
+            if cpu is not None:
+                out["cpu_baseline"] = cpu
+            out["extra"] = extra
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(240.0, give_up)
+        dog.daemon = True
+        dog.start()
+        task = _Task(diff, None)
+        task.ddp = ddp
+        opt_g = new_optimizer(diff, args.dtype, LOSS_ELEMENTS(B, cell_idx))
+        task._opt = opt_g
+        gs = GraphedTrainingStep(task)
+        gbatch = SimpleNamespace(x=x, C=C, cell_idx=cell_idx)
+
+        def graph_step():
+            gs(gbatch)
+            ddp.finish()
+            opt_g.step()
+
+        try:
+            set_mode(diff, args.dtype)
+            diff.zero_grad(set_to_none=True)
+            for _ in range(3):
+                graph_step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                graph_step()
+            enq = 1e3 * (time.perf_counter() - t0) / K
+            barrier()
+            t_graph = max_over_ranks(time.perf_counter() - t0) / K
+            extra["overlap"]["captured_step"] = {"ms_per_step": 1e3 * t_graph, "host_enqueue_ms_per_step_rank0": enq,
+                                                 "voxels_per_s": world * B * V / t_graph,
+                                                 "note": "forward + backward as one hipGraph per rank; bucket all-reduces launched by "
+                                                         "the host at the captured bucket boundaries; clip + RAdam eager"}
+        except Exception as e:  # noqa: BLE001 -- reported, never fatal for the headline line
+            extra["overlap"]["captured_step"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        dog.cancel()
+        out["extra"] = extra
 
     if cpu is not None:
         out["cpu_baseline"] = cpu
