@@ -448,3 +448,37 @@ with open(out + "/host/1_counter_collection.csv", "w") as f:
     script.write_text("#!/bin/sh\nexit 3\n")
     bad, why, _ = bench.live_traffic("bf16", 6)
     assert bad is None and why["live"] is False and "failed" in why["why"]
+
+
+def test_fp16_compute_mode_host_side():
+    """Round 6's fp16 mode, the part that needs no GPU: the mode table, the model's compute dtype, the loss scale the trainer
+    derives from a batch (a power of two that puts the backward's seed 2 (eps_hat - eps) / n near 2^-3), ClipRAdam's argument
+    checks, and that a stock torch optimiser is refused (it does not know the scale)."""
+    import pytest
+    import torch
+
+    from turbdiff_amd import _lib
+    from turbdiff_amd.optim import ClipRAdam
+    from turbdiff_amd.training import COMPUTE_MODES, DiffusionTrainer
+
+    assert COMPUTE_MODES == ("f32", "f32s", "bf16", "fp16")
+    assert _lib.dtype_code(torch.float16) == _lib.F16 == 3 and torch.float16 in _lib.H16_DTYPES
+    # B F n_cells = 6 x 4 x 582 256 (the benchmark batch): 2^23 <= n < 2^24 -> S = 2^19; tiny problems never go below 1
+    assert DiffusionTrainer.initial_loss_scale(6 * 4 * 582256) == 2.0**19
+    assert DiffusionTrainer.initial_loss_scale(4 * 4048) == 2.0**9 and DiffusionTrainer.initial_loss_scale(3) == 1.0
+    for n in (17, 1000, 10**6, 10**8):
+        s = DiffusionTrainer.initial_loss_scale(n)
+        assert 2.0 ** round(__import__("math").log2(s)) == s and 1 / 32 < s / n <= 1 / 16
+    task = DiffusionTrainer(**{**DiffusionTrainer.SHIPPED_CONFIG, "dim": 8, "timesteps": 10}, u_net_levels=2, compute_mode="fp16")
+    assert task.model.model.compute_dtype == torch.float16 and task.model.model.conv_impl == "auto"
+    assert task._loss_scale_for_optimizer() == 2.0**16  # (before a batch has been seen)
+    task.optimizer = "adam"
+    with pytest.raises(RuntimeError, match="loss-scaling optimiser"):
+        task.configure_optimizers()
+    assert DiffusionTrainer(**{**DiffusionTrainer.SHIPPED_CONFIG, "dim": 8, "timesteps": 10}, u_net_levels=2,
+                            compute_dtype=torch.float16).compute_mode == "fp16"
+    p = [torch.nn.Parameter(torch.zeros(3))]
+    with pytest.raises(ValueError, match="power of two"):
+        ClipRAdam(p, loss_scale=1000.0)
+    opt = ClipRAdam(p, loss_scale=2.0**10)
+    assert opt.scale_loss(torch.tensor(1.5)).item() == 1536.0 and ClipRAdam(p).scale_loss(torch.tensor(1.5)).item() == 1.5
