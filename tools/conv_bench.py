@@ -75,13 +75,17 @@ def main():
     ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights (switching-activity experiment)")
     ap.add_argument("--miopen", action="store_true", help="time the same layers through F.conv3d (MIOpen) instead")
     ap.add_argument("--miopen-find", action="store_true", help="with --miopen: torch.backends.cudnn.benchmark = True")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp16"])
+    ap.add_argument("--bf16-values", action="store_true",
+                    help="fp16 tensors whose VALUES are bf16-representable (3 low mantissa bits zero): same kernels and opcodes as "
+                         "--dtype fp16, the operand bits of --dtype bf16 -- separates the opcode from the switching activity")
     ap.add_argument("--impl", default="auto", choices=["auto", "direct", "mfma", "split"])
     a = ap.parse_args()
     if a.miopen:
         return miopen_table(a)
     dev = torch.device("cuda:0"); B = a.batch
-    tdt, dc = (torch.bfloat16, 1) if a.dtype == "bf16" else (torch.float32, 0)
+    tdt, dc = {"bf16": (torch.bfloat16, 1), "fp16": (torch.float16, 3), "f32": (torch.float32, 0)}[a.dtype]
+    coarse = (lambda t: t.to(torch.bfloat16).to(tdt)) if a.bf16_values else (lambda t: t.to(tdt))
     os.environ["TDX_CONV_IMPL"] = a.impl; im = L.conv_impl()
     tot = {"fwd": 0, "dgrad": 0, "wgrad": 0}; totf = 0
     print(f"{'layer':12s} {'Cin':>5s} {'Cout':>5s} {'grid':>12s} | {'fwd ms':>8s} {'TF/s':>6s} | {'dgrad ms':>8s} {'TF/s':>6s} | {'wgrad ms':>8s} {'TF/s':>6s}")
@@ -90,11 +94,13 @@ def main():
         if a.layers and name not in a.layers.split(","): continue
         Ci = C1 + C2
         zf = 0.0 if a.zeros else 1.0
-        x1 = (torch.randn(B, X, Y, Z, C1, device=dev) * zf).to(tdt)
-        x2 = torch.randn(B, X, Y, Z, C2, device=dev).to(tdt) if C2 else None
+        x1 = coarse(torch.randn(B, X, Y, Z, C1, device=dev) * zf)
+        x2 = coarse(torch.randn(B, X, Y, Z, C2, device=dev)) if C2 else None
         w = (torch.randn(Co, Ci, 3, 3, 3, device=dev) * 0.02 * zf)
+        if a.bf16_values:
+            w = w.to(torch.bfloat16).float()
         bias = torch.zeros(Co, device=dev)
-        gy = (torch.randn(B, X, Y, Z, Co, device=dev) * zf).to(tdt)
+        gy = coarse(torch.randn(B, X, Y, Z, Co, device=dev) * zf)
         wf, wb = ops._packed_conv3(w, tdt)
         y = torch.empty(B, X, Y, Z, Co, device=dev, dtype=tdt)
         st = L.stream()
