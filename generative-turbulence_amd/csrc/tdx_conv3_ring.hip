@@ -31,6 +31,9 @@
 //   * Workgroup -> bricks: every XCD owns one contiguous range of bricks (halo voxels shared through one L2); inside
 //     an XCD the 32 workgroups interleave, and the N tiles of one brick run on neighbouring workgroups at the same time.
 //
+// Round 6: the operand format is a template argument (HF: bf16 or fp16 words in the same layouts, H16<HF> in tdx_common.h), and so
+// is the brick depth (Z4: 8 MT x 8 x 4 bricks for grids like 48 x 16 x 12 -- see RingShape).
+//
 // Same products and the same fp32 accumulation as the brick kernel up to summation order (taps in pairs, bias first).
 // Used when the grid's whole bricks fill the chip and leave at most 2 voxels per axis (conv3_ring_supported; those
 // remainder slabs go to the thin-brick kernel in a second launch); everything else stays on the brick kernel.

@@ -75,7 +75,7 @@ const char* tdx_arch(void);
 
 /* ------------------------------------------------------------------ layout ------------- */
 /* (B, C, V) -> (B, V, C) and back; replaces the implicit NCDHW layout of every op in
- * ddpm.py.  dtype_in/dtype_out may differ (f32 <-> bf16 cast fused). */
+ * ddpm.py.  dtype_in/dtype_out may differ (f32 <-> bf16 / fp16 cast fused). */
 int tdx_ncv_to_nvc(const void* x, void* y, int B, int C, int64_t V, int dtype_in, int dtype_out, void* stream);
 int tdx_nvc_to_ncv(const void* x, void* y, int B, int C, int64_t V, int dtype_in, int dtype_out, void* stream);
 /* plain cast of n elements */
@@ -89,7 +89,7 @@ int tdx_cast(const void* x, void* y, int64_t n, int dtype_in, int dtype_out, voi
  *   wb  data-gradient operand    (K = Cout, N = Cin, taps flipped, weights transposed)
  * each 27*Cin*Cout elements of `dtype`; either may be NULL.  The element order is an
  * implementation detail shared by pack and the consumers, a function of (dtype, K, N) only:
- * [K/16][27][N][16] for the bf16 MFMA kernels (K % 16 == 0, N % 32 == 0), [K/8][27][N][8] for the fp32 MFMA
+ * [K/16][27][N][16] for the bf16 / fp16 MFMA kernels (TDX_BF16 / TDX_F16: K % 16 == 0, N % 32 == 0), [K/8][27][N][8] for the fp32 MFMA
  * kernels (K % 8 == 0, N % 32 == 0), else [27][K][N]; dtype = TDX_F32_SPLIT: two bf16 images (hi, lo), each
  * [K/8][27][N][8], in the fp32 operand's buffer where K % 16 == 0 and N % 32 == 0, else the fp32 layouts. */
 int tdx_conv3_pack_weight(const float* w, void* wf, void* wb, int Cin, int Cout, int dtype, void* stream);
@@ -119,7 +119,7 @@ int tdx_transpose_many(const TdxTransposeJob* jobs, int n, void* stream);
 int tdx_conv3_fwd(const void* x1, int C1, const void* x2, int C2, const void* wf, const float* bias, void* y,
                   int B, int X, int Y, int Z, int Cout, int dtype, int impl, void* stream);
 
-/* Which bf16 matrix-core kernel serves this shape (same call; the kernels form the same products and sum them in fp32
+/* Which 16-bit (bf16 / fp16) matrix-core kernel serves this shape (same call; the kernels form the same products and sum them in fp32
  * in different orders, so their bf16 results agree up to ~1 ulp on a few % of the elements, not bit for bit.  Kernel
  * selection depends on the grid, on B -- a launch must fill the chip -- and on whether a scratch arena is bound
  * (tdx_set_scratch), so the last bit of a sample's output can change with the batch size it is computed in (B = 1
@@ -156,7 +156,7 @@ int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, const void*
  * init_shared != 0 (NULL: zeros); it is added to the bf16-rounded conv result in the store loop.  Used for the first conv of the
  * U-Net, whose input is cat(encode_x(x), encode_c_local(c).expand(B)) (ddpm.py:495-501): the
  * conditioning half of that conv is the same for every sample of a batch and for every reverse step
- * of a sampling run, so it is computed once and passed as `init`.  bf16 MFMA path only
+ * of a sampling run, so it is computed once and passed as `init`.  16-bit (bf16 / fp16) MFMA path only
  * (C1 % 16 == 0, Cout % 32 == 0).  stats/G/eps/gn_workspace as in tdx_conv3_fwd_gn, or stats = NULL. */
 int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void* wf, const float* bias, const void* init,
                           int init_shared, void* y, float* stats, int G, float eps, void* gn_workspace, int B, int X,
@@ -169,7 +169,7 @@ int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void* wf, const
  * overwriting.  workspace: tdx_conv3_bwd_data_workspace_bytes().
  * Reproducibility: on the brick / ring kernels the boundary voxels' halo-shell terms are ADDED onto the stored main term
  * (tdx_conv3_shell.hip): a voxel on exactly one face gets one read-add-write, edge and corner voxels get up to 7 hardware
- * atomics (global_atomic_pk_add_bf16 / global_atomic_add_f32) in whatever order the workgroups finish, each with its own
+ * atomics (global_atomic_pk_add_bf16 / _f16 / global_atomic_add_f32) in whatever order the workgroups finish, each with its own
  * rounding in the tensor's dtype -- those voxels (1-3 % of the boundary shell) are not bit-reproducible from run to run,
  * in bf16 within 2^-8 relative per add.  TDX_SHELL_DETERMINISTIC=1 (environment, read per call) replaces the atomics by
  * a position buffer in `workspace` and a fixed-order fold: bit-identical results, one more small launch per call.
@@ -206,7 +206,7 @@ int tdx_conv1_fwd(const void* x1, int C1, const void* x2, int C2, const float* w
  *   y[b, v, :] = silu(GroupNorm(h)[b, v, :]) + bias + x1[b, v, :] @ w[0:C1, :] + x2[b, v, :] @ w[C1:, :]
  * h: the block's second conv output (B, V, Cout), stats: its (B, groups, 2) mean / rstd from tdx_conv3_fwd_gn, gamma /
  * beta: the GroupNorm affine.  Same arithmetic as tdx_conv1_fwd(..., add = NULL) into a temporary followed by
- * tdx_gn_apply(h, ..., res = temporary, act = 1), without writing or re-reading the temporary.  bf16 tensors on the
+ * tdx_gn_apply(h, ..., res = temporary, act = 1), without writing or re-reading the temporary.  bf16 / fp16 tensors on the
  * matrix-core kernel only: TDX_EDTYPE / TDX_ESHAPE otherwise (run the two calls). */
 int tdx_conv1_fwd_gn(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
                      const void* h, const float* stats, const float* gamma, const float* beta, int groups, void* y,
