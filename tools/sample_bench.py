@@ -20,7 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--trajectories", type=int, default=8)
 ap.add_argument("--timesteps", type=int, default=1000)
 ap.add_argument("--steps", type=int, default=0, help="time only this many reverse steps and extrapolate (0 = full loop)")
-ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32s"])
+ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "f32", "f32s"])
 ap.add_argument("--no-graph", action="store_true")
 a = ap.parse_args()
 if a.dtype == "f32s":  # fp32 tensors, split-precision convs
@@ -29,7 +29,7 @@ if a.dtype == "f32s":  # fp32 tensors, split-precision convs
 rank, world, local = parallel.init_from_env("nccl")
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
-diff = bench.build_model(dev, torch.bfloat16 if a.dtype == "bf16" else torch.float32, timesteps=a.timesteps)
+diff = bench.build_model(dev, bench.MODE_DTYPE[a.dtype], timesteps=a.timesteps)
 ids = list(parallel.shard_trajectories(a.trajectories, rank, world))
 x, c, cell_idx = bench.synthetic_inputs(len(ids), dev)
 C = {Conditioning.Type.CELL_TYPE: c}
