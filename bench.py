@@ -593,7 +593,7 @@ def pin_host_threads(local_rank, local_world):
     """Before anything touches the GPU: bind this rank's host threads (the issuing thread, autograd's backward thread, the
     collective's proxy thread) to cores of its GPU's NUMA node -- eight ranks x two busy threads on one host otherwise
     migrate across sockets and stretch the enqueue path the step depends on when per-GPU batches are small.  The GPU's
-    node comes from sysfs (amdgpu display-class PCI functions in bus order = HIP's default device order; `numa_node` /
+    node comes from sysfs (AMD display / accelerator-class PCI functions in bus order = HIP's default device order; `numa_node` /
     `local_cpulist`), without a HIP call; the node's cores are split evenly among the ranks that share it.  Where sysfs
     says nothing (a container without it, one NUMA node) the allowed cores are split evenly by rank.  Returns what was
     done, for extra.overlap.host_affinity."""
@@ -608,7 +608,8 @@ def pin_host_threads(local_rank, local_world):
     try:
         gpus = []
         for dev in sorted(Path("/sys/bus/pci/devices").iterdir()):
-            if (dev / "vendor").read_text().strip() == "0x1002" and (dev / "class").read_text().strip().startswith("0x03"):
+            # AMD GPUs: display controllers (0x03....) or, for the Instinct parts, processing accelerators (0x12....)
+            if (dev / "vendor").read_text().strip() == "0x1002" and (dev / "class").read_text().strip()[:4] in ("0x03", "0x12"):
                 gpus.append(dev)
         if len(gpus) >= local_world:
             mine = gpus[local_rank]
