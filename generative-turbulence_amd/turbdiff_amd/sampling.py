@@ -198,7 +198,11 @@ class GraphSampler:
             self._arena = L.scratch_arena(self.dev)  # held for as long as the graph lives (the arena map is bounded)
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=s):
+        # capture_error_mode "thread_local": only THIS thread's calls are checked against the capture.  In a process with an RCCL
+        # communicator the watchdog thread of ProcessGroupNCCL polls the events of recent collectives (a barrier just before the
+        # sampling leg is enough); under the default "global" mode its hipEventQuery during our capture raises
+        # hipErrorStreamCaptureUnsupported and aborts the process (seen in 2 of 6 runs of the captured data-parallel step)
+        with torch.cuda.graph(self.graph, stream=s, capture_error_mode="thread_local"):
             self._step()
         self.x_t.copy_(state[0]); self.t.copy_(state[1]); self.offset.copy_(state[2])
         # The graph has the addresses of the packed weight operands (ops._pack_cache) baked in.  Keep those

@@ -529,7 +529,13 @@ class GraphedTrainingStep:
             slot.gen = torch.zeros(1, dtype=torch.int32, device=dev)  # replay counter, read by the captured bucket marks
             ddp.begin_capture(slot.gen)
 
-        with torch.cuda.graph(slot.graph, stream=s):
+        # "thread_local": the backward's launches come from autograd's thread and are captured all the same (capture is a
+        # property of the stream); what the mode relaxes is the CHECK of other threads' runtime calls -- ProcessGroupNCCL's
+        # watchdog polls the events of the warm-up steps' collectives, and under the default "global" mode that hipEventQuery
+        # raises hipErrorStreamCaptureUnsupported inside our capture and aborts the process (2 of 6 runs)
+        if ddp is not None:
+            torch.cuda.synchronize(dev)  # the warm-up steps' collectives are done before the capture begins
+        with torch.cuda.graph(slot.graph, stream=s, capture_error_mode="thread_local"):
             if ddp is not None:
                 slot.gen.add_(1)
             slot.loss = body().detach()  # (no autograd graph outlives the capture: its nodes belong to this stream)
