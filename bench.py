@@ -279,6 +279,11 @@ def live_traffic(mode, batch, timeout_s=240):
 
 
 CONV_CALLS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add", "tdx_conv3_bwd_weight"}
+# The headline's timed region carries HIP events only around the launches its roofline block is about (22 calls a step); the
+# per-call table (`kernels`, events around all ~66 conv calls) and, at N > 1, the events around backward() and the all-reduce
+# waits come from a second, instrumented leg of the same K steps (their cost is within the leg-to-leg noise of +-0.2 ms on
+# one GPU; the point is that the headline region of a data-parallel run holds no per-bucket instrumentation)
+FWD_CALLS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn"}
 
 
 def merged_kernel_times(timer, where=None):
@@ -683,7 +688,7 @@ def main():
         # the launcher's code.  Nothing is exec'd from a process that holds a GPU context.
         sys.exit(self_launch(args.gpus))
 
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("TDX_BENCH_FORCE_DDP") == "1":
         # Data-parallel runs: RCCL's kernels and the persistent conv kernels must fit the chip together.  The conv kernels
         # take 224 CUs (TDX_PERSISTENT_CUS, below); RCCL is held to at most 32 channels (= workgroups, one CU each) unless
         # the caller chose otherwise -- 221 MB of gradients per ~22 ms step need ~10 GB/s per rank, far below what 32
@@ -692,7 +697,7 @@ def main():
 
     # roofline.traffic of the headline mode, measured on THIS box in this run: before anything here touches the GPU
     if (args.gpus == 1 and not args.no_live_traffic and not args.no_extra and os.environ.get("TDX_BENCH_CHILD") != "1"
-            and "WORLD_SIZE" not in os.environ):
+            and "WORLD_SIZE" not in os.environ and os.environ.get("TDX_BENCH_FORCE_DDP") != "1"):
         t_live = time.perf_counter()
         live_modes = [args.dtype] + ([m for m in ("fp16", "bf16", "f32s", "f32") if m != args.dtype] if not args.no_parity_modes else [])
         deadline = t_live + 300.0  # all passes together (normally ~30 s); a pass that fails or stalls ends the attempt for every mode
@@ -713,11 +718,16 @@ def main():
 
     # TDX_BENCH_BACKEND=gloo + TDX_BENCH_ONE_DEVICE=1: all ranks on cuda:0 with gloo collectives -- only for
     # exercising the N > 1 code path on a one-GPU box (tests/test_bench_multirank.py); never a measurement
-    rank, world, local = parallel.init_from_env(os.environ.get("TDX_BENCH_BACKEND", "nccl"))
+    # TDX_BENCH_FORCE_DDP=1 with one rank: the N > 1 code path (communicator, gradient hooks + asynchronous all-reduce on RCCL's
+    # stream, overlap report, captured data-parallel step, sharded sampling leg) on ONE GPU over RCCL at world size 1 -- a dry
+    # run of everything the multi-GPU runs execute except a second peer (tests/test_bench_multirank.py); never a measurement
+    force_ddp = os.environ.get("TDX_BENCH_FORCE_DDP") == "1" and int(os.environ.get("WORLD_SIZE", "1")) == 1
+    rank, world, local = parallel.init_from_env(os.environ.get("TDX_BENCH_BACKEND", "nccl"), force=force_ddp)
     if os.environ.get("TDX_BENCH_ONE_DEVICE") == "1":
         local = 0
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if world > 1:
+    multi = world > 1 or force_ddp  # the data-parallel legs run; the single-GPU extras do not
+    if multi:
         # The ring conv / producer-consumer weight-gradient kernels launch one workgroup per CU and fill its registers and
         # LDS; RCCL's kernels need CUs of their own, and a persistent launch that finds some taken runs in two rounds.
         # Under data parallelism they therefore use 224 of the 256 CUs (28 per XCD) unless the caller chose a number
@@ -737,7 +747,7 @@ def main():
 
     # ---- CPU leg first (rank 0, N = 1): baseline + the oracle's eps-hat for the accuracy probe
     cpu, probe = None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         cpu, probe = cpu_baseline()
         leg_done("cpu_baseline")
 
@@ -764,22 +774,24 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(v):
-        if world > 1:
+        if multi:
             tt = torch.tensor([v], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             return tt.item()
         return v
 
-    ddp = parallel.BucketedDataParallel(diff, compress=args.compress)
+    ddp = parallel.BucketedDataParallel(diff, compress=args.compress, force=force_ddp)
     bwd_events = []  # N > 1: (start, end) events around backward() of every timed step
 
-    def run_mode(mode, steps, warmup):
-        """`steps` timed training steps in `mode` -> (elapsed s (max over ranks), merged conv-kernel times, last loss)."""
+    def run_mode(mode, steps, warmup, calls=CONV_CALLS, ddp_timing=None):
+        """`steps` timed training steps in `mode` -> (elapsed s (max over ranks), merged conv-kernel times, last loss).
+        calls: the library calls bracketed with HIP events; ddp_timing: events around backward() and finish()'s waits."""
+        ddp_timing = multi if ddp_timing is None else ddp_timing
         set_mode(diff, mode)
         assert fused_opt or mode != "fp16", "fp16 training needs the loss-scaling optimiser (--optimizer fused)"
         opt = (new_optimizer(diff, mode, LOSS_ELEMENTS(B, cell_idx)) if fused_opt
@@ -805,10 +817,10 @@ def main():
 
         for _ in range(warmup):
             train_step()
-        ddp.timing = world > 1
+        ddp.timing = ddp_timing
         bwd_events.clear()
         ddp.exposed_ms()
-        timer = _lib.KernelTimer(CONV_CALLS)
+        timer = _lib.KernelTimer(calls)
         _lib.TIMER = timer
         barrier()
         t0 = time.perf_counter()
@@ -826,9 +838,16 @@ def main():
         return elapsed, (kern, timer), loss.item(), train_step
 
     leg_done("build_model_and_accuracy_probe")
-    elapsed, (kern, timer), last_loss, train_step = run_mode(args.dtype, K, Wm)
+    elapsed, (kern, timer), last_loss, train_step = run_mode(args.dtype, K, Wm, calls=FWD_CALLS, ddp_timing=False)
     headline_enqueue_ms = run_mode.host_enqueue_ms
+    headline_skipped = getattr(run_mode, "skipped", None)
     leg_done("headline_steps")
+    instrumented_ms = None
+    if not args.no_extra:
+        # the same K steps again with events around EVERY conv call and (N > 1) around backward() and the all-reduce waits
+        el_i, (kern, _), _, train_step = run_mode(args.dtype, K, 1)
+        instrumented_ms = 1e3 * el_i / K
+        leg_done("instrumented_steps")
     value = world * B * V * K / elapsed
     out = {
         "metric": "U-Net fwd+bwd voxels/sec (DDPM training step, 192x64x48x4)",
@@ -852,6 +871,8 @@ def main():
                    "weight_gradients_on_side_stream": os.environ.get("TDX_WGRAD_STREAM", "1") != "0"},
         "loss": last_loss,
     }
+    if args.dtype == "fp16":
+        out["skipped_steps"] = headline_skipped  # steps whose gradients overflowed (0 = every timed step updated)
     if rank == 0:
         rb = roofline_block(timer, args.dtype, B, K)
         if rb:
@@ -861,13 +882,17 @@ def main():
             # the weight gradients run on a side stream beside the data-gradient chain (ops._WgradSide): the two event
             # durations cover overlapped time; TDX_WGRAD_STREAM=0 gives them one after the other
             out["kernels"]["note"] = "tdx_conv3_bwd_weight and tdx_conv3_bwd_data run concurrently: durations overlap"
+        if instrumented_ms is not None:
+            out["kernels"]["measured_in"] = (f"a second leg of the same {K} steps with HIP events around every conv call "
+                                             f"({instrumented_ms:.2f} ms per step with them); the headline region carries events "
+                                             "around the forward conv launches only (roofline)")
     extra = {}
     if accuracy is not None:
         extra["accuracy"] = accuracy
         out["rel_l2_vs_cpu_oracle"] = accuracy[args.dtype]
 
     # ---- N > 1: how much of the gradient all-reduce hides behind backward
-    if world > 1 and not args.no_extra:
+    if multi and not args.no_extra:
         # HIP events of the timed steps themselves: backward's span on the compute stream, and what finish() then
         # still had to wait for (the part of the all-reduce backward did not hide)
         exposed_ev = ddp.exposed_ms()
@@ -893,11 +918,13 @@ def main():
         torch.distributed.all_gather_object(per_rank, {"rank": rank, "host_enqueue_ms_per_step": headline_enqueue_ms,
                                                        "host_affinity": affinity})
         exposed = max_over_ranks(sum(exposed_ev) / max(len(exposed_ev), 1)) * 1e-3
-        extra["overlap"] = {"ms_step": 1e3 * t_step, "ms_step_without_allreduce": 1e3 * t_nocomm,
+        extra["overlap"] = {"ms_step": 1e3 * t_step, "ms_step_instrumented": instrumented_ms,
+                            "ms_step_without_allreduce": 1e3 * t_nocomm,
                             "ms_allreduce_alone": 1e3 * t_comm, "ms_exposed": 1e3 * exposed,
                             "ms_backward": sum(bwd_ms) / max(len(bwd_ms), 1),
                             "method": "HIP events on the compute stream around backward() and around finish()'s waits, "
-                                      "mean over the timed steps, max over ranks",
+                                      "mean over the steps of the instrumented leg (the same K steps right after the "
+                                      "headline's, which carry no such events), max over ranks",
                             "hidden_fraction": (1.0 - exposed / t_comm) if t_comm > 0 else None,
                             "buckets": ddp.bucket_layout(), "compress": args.compress,
                             # per bucket: when in backward its all-reduce was enqueued, how long it takes alone, what
@@ -910,7 +937,7 @@ def main():
                             "payload_MB": sum(b for _, b in (ddp.bucket_layout() or [])) / 1e6}
 
     # ---- the modes that meet the 1e-4 parity gate, same run, same model (N = 1 only: they are not scaling legs)
-    if world == 1 and not args.no_extra and not args.no_parity_modes:
+    if not multi and not args.no_extra and not args.no_parity_modes:
         pm = {}
         for m in ("fp16", "bf16", "f32s", "f32"):
             if m == args.dtype:
@@ -930,14 +957,14 @@ def main():
         set_mode(diff, args.dtype)
         leg_done("parity_modes")
 
-    if not args.no_extra and world == 1:
+    if not args.no_extra and not multi:
         # the host's share of the headline step, eager and with forward + backward replayed from one captured graph
         extra["captured_step"] = host_and_graph_step(diff, x, C, md, args.dtype, 10, 3)
         leg_done("captured_step")
 
     if not args.no_extra:
         set_mode(diff, args.dtype)
-        if world == 1:
+        if not multi:
             # forward only (the north_star's "conv U-Net forward" figure)
             with torch.no_grad():
                 tq = torch.full((B,), 250, device=dev)
@@ -974,7 +1001,7 @@ def main():
                                  "ddpm_samples_per_s_T500": Bs * world / (per_step * 500),
                                  "note": "whole-job aggregate; per-step time x T" + ("" if full else " (extrapolated from the timed steps)")}
             del sampler
-            if world == 1 and args.dtype != "fp16":
+            if not multi and args.dtype != "fp16":
                 # the same captured reverse step on fp16 tensors / fp16 MFMA operands: sampling needs no loss scale, so
                 # this is the at-speed sampler at the reference's own (TF32-grade) precision
                 set_mode(sdiff, "fp16")
@@ -990,7 +1017,7 @@ def main():
                                              "ddpm_samples_per_s_T1000": Bs / (p16 * T)}
                 del s16
                 set_mode(sdiff, args.dtype)
-            if world == 1:
+            if not multi:
                 # the PUBLIC method (what DiffusionTraining.sample / eval_ckpt.py / a dropin user call, reference
                 # diffusion.py:152-158): graph path vs the eager loop (TDX_GRAPH_SAMPLER=0), 30 reverse steps each via
                 # start_from; and the reference's own timing protocol (scripts/evaluate-runtime.py:54-96: B = 1, sync,
@@ -1025,7 +1052,7 @@ def main():
                             "reference's evaluate-runtime.py protocol" + ("" if full else " (full loop only with --steps >= 20)")}
             del sdiff
         leg_done("forward_and_sampling")
-        if world == 1:
+        if not multi:
             extra["cfg1"] = cfg1_leg(dev, with_cpu=not args.no_cpu_baseline)
             leg_done("cfg1_48x32x32")
             extra["real_grid"] = real_grid_leg(dev, B)
@@ -1038,7 +1065,7 @@ def main():
     if extra:
         out["extra"] = extra
 
-    if world == 1 and not args.no_torch_baseline and not args.no_extra:
+    if not multi and not args.no_torch_baseline and not args.no_extra:
         del diff
         torch.cuda.empty_cache()
         # MIOpen's default find mode compiles and times every candidate solver of every conv shape on a cold cache: 614 s
@@ -1069,7 +1096,7 @@ def main():
     # It has never met a second GPU, and a rank that fails alone leaves the others inside a collective: so it runs after
     # everything else is measured, under a watchdog -- if it does not return in time, rank 0 prints the line it has (with a
     # note instead of this leg) and every rank leaves.
-    if world > 1 and not args.no_extra and fused_opt and "overlap" in extra:
+    if multi and not args.no_extra and fused_opt and "overlap" in extra:
         import threading
 
         from turbdiff_amd.training import GraphedTrainingStep
@@ -1123,7 +1150,7 @@ def main():
         out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

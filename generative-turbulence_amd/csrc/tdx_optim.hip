@@ -180,3 +180,70 @@ extern "C" int tdx_radam_step_scaled(const TdxOptTensor* table, const int* chunk
     return radam_step_impl(table, chunk_tensor, chunk_off, nchunks, scaled_norm, scaled_norm + 2, step, lr, beta1, beta2, eps,
                            write_grad, stream);
 }
+
+// ---- gradient staging of the data-parallel step ---------------------------------------------------------------------------
+// The reference's DistributedDataParallel (Lightning strategy, train.py:144-156) copies every gradient into its bucket as
+// the autograd hook fires.  Here the hooks only remember (gradient, bucket slice); when a bucket's last gradient has arrived
+// ONE launch moves all of them, scaled by 1 / world: 139 five-microsecond launches per step become 7 (0.8 ms of kernel time
+// + the gaps between them at B = 6; profiles/r13_ddp_staging.txt).  HBM-bound, 1 read + 1 write of the payload.
+// The items travel BY VALUE in the kernel arguments (no table upload, nothing to keep alive; inside a hipGraph capture the
+// pointers are part of the node).  Block b serves item i with first[i] <= b < first[i + 1], STAGE_CHUNK elements per block.
+#define STAGE_CHUNK 8192
+struct StageArgs {
+    TdxStageItem item[TDX_STAGE_MAX_ITEMS];
+    int first[TDX_STAGE_MAX_ITEMS + 1];
+    int n;
+    float scale;
+};
+
+__global__ void __launch_bounds__(OPT_THREADS) stage_scaled_kernel(const StageArgs a) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = a.n;  // uniform binary search in the (scalar-register) argument block
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.first[mid] <= b) lo = mid; else hi = mid;
+    }
+    const int64_t o = (int64_t)(b - a.first[lo]) * STAGE_CHUNK;
+    const int64_t n = min((int64_t)STAGE_CHUNK, a.item[lo].n - o);
+    const float* __restrict__ s = a.item[lo].src ? (const float*)a.item[lo].src + o : nullptr;
+    float* __restrict__ d = (float*)a.item[lo].dst + o;
+    const float sc = a.scale;
+    const bool vec = ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+    const int64_t n4 = vec ? (n >> 2) : 0;
+    for (int64_t i = threadIdx.x; i < n4; i += OPT_THREADS) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s) {
+            v = reinterpret_cast<const float4*>(s)[i];
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        }
+        reinterpret_cast<float4*>(d)[i] = v;
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += OPT_THREADS) d[i] = s ? s[i] * sc : 0.f;
+}
+
+extern "C" int tdx_stage_scaled(const TdxStageItem* items, int n_items, float scale, void* stream) {
+    TDX_CHECK_ARG(items || n_items == 0);
+    TDX_CHECK_ARG(n_items >= 0);
+    for (int base = 0; base < n_items; base += TDX_STAGE_MAX_ITEMS) {
+        StageArgs a;
+        a.n = 0;
+        a.scale = scale;
+        int blocks = 0;
+        for (int i = base; i < n_items && a.n < TDX_STAGE_MAX_ITEMS; ++i) {
+            TDX_CHECK_ARG(items[i].n >= 0 && (items[i].dst || items[i].n == 0));
+            if (items[i].n == 0) continue;
+            const int64_t nb = (items[i].n + STAGE_CHUNK - 1) / STAGE_CHUNK;
+            TDX_CHECK_ARG(blocks + nb < (int64_t)1 << 30);
+            a.item[a.n] = items[i];
+            a.first[a.n] = blocks;
+            blocks += (int)nb;
+            ++a.n;
+        }
+        if (a.n == 0) continue;
+        for (int i = a.n; i <= TDX_STAGE_MAX_ITEMS; ++i) a.first[i] = blocks;
+        hipLaunchKernelGGL(stage_scaled_kernel, dim3(blocks), dim3(OPT_THREADS), 0, as_stream(stream), a);
+        const int st = tdx_launch_status();
+        if (st != 0) return st;
+    }
+    return 0;
+}

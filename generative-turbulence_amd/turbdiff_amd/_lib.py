@@ -93,6 +93,7 @@ SIGNATURES = {
     "tdx_grad_norm": (_i, [_vp, _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "tdx_radam_step": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
     "tdx_signal_host": (_i, [_vp, _vp, C.c_uint32, _vp]),
+    "tdx_stage_scaled": (_i, [_vp, _i, _f, _vp]),
     "tdx_grad_norm_scaled": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp]),
     "tdx_radam_step_scaled": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _f, _f, _f, _f, _i, _vp]),
 }
@@ -110,6 +111,10 @@ class PackJob(C.Structure):  # TdxPackJob
 
 class TransposeJob(C.Structure):  # TdxTransposeJob
     _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i), ("cols", _i)]
+
+
+class StageItem(C.Structure):  # TdxStageItem
+    _fields_ = [("src", _vp), ("dst", _vp), ("n", _i64)]
 
 
 class FilmGrad(C.Structure):  # TdxFilmGrad

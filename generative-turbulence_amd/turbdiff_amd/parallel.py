@@ -127,6 +127,8 @@ class BucketedDataParallel:
         self._work: list = []
         self._launched: set[int] = set()
         self._seen: set[int] = set()
+        self._staged: list[list] = []                 # bucket -> [(gradient or None, bucket slice)] waiting for _flush()
+        self._views: dict[int, tuple] = {}            # param index -> (bucket, its slice shaped like the parameter, fused staging?)
         self.stats = {"wait_s": 0.0, "steps": 0}
         self.timing = False                            # True: finish() brackets its waits with events on the compute stream
         self._wait_events: list = []
@@ -194,6 +196,11 @@ class BucketedDataParallel:
                 off += n + (-n) % align
             self._flat.append(torch.zeros(off, dtype=p0.dtype, device=p0.device))
             self._wire.append(torch.zeros(off, dtype=torch.bfloat16, device=p0.device) if self.compress == "bf16" else None)
+        self._staged = [[] for _ in buckets]
+        self._views = {}
+        for i, (b, off) in self._slot.items():  # the slices never move: built once, not per hook call
+            p = self.params[i]
+            self._views[i] = (b, self._flat[b][off : off + p.numel()].view_as(p), p.is_cuda and p.dtype == torch.float32)
 
     def bucket_layout(self):
         """[(n_params, bytes)] per bucket, in launch order (None before the buckets exist)."""
@@ -222,12 +229,16 @@ class BucketedDataParallel:
         return hook
 
     def _stage(self, i: int):
-        """g / world -> the parameter's slice of its bucket (one pass); p.grad becomes that slice."""
+        """g / world -> the parameter's slice of its bucket; p.grad becomes that slice.  On the GPU the copy is deferred: the
+        hook only notes (gradient, slice), and _flush() moves a whole bucket in one launch of tdx_stage_scaled when its last
+        gradient has arrived (139 five-microsecond launches per step otherwise); elsewhere one torch.mul per parameter."""
         p = self.params[i]
-        b, off = self._slot[i]
-        view = self._flat[b][off : off + p.numel()].view_as(p)
+        b, view, fusable = self._views[i]
         g = p.grad
-        if g is None:
+        if fusable and (g is None or (g.dtype == torch.float32 and g.is_contiguous() and g.numel() == view.numel()
+                                      and g.device == view.device)):
+            self._staged[b].append((g, view))  # holds g until the bucket's launch
+        elif g is None:
             view.zero_()
         elif g.data_ptr() != view.data_ptr():
             torch.mul(g, 1.0 / self.world, out=view)
@@ -235,8 +246,24 @@ class BucketedDataParallel:
             view.mul_(1.0 / self.world)
         p.grad = view
 
+    def _flush(self, b: int):
+        """The staged gradients of bucket b -> its flat buffer, scaled by 1 / world, on the current stream (one launch per 64)."""
+        items = self._staged[b]
+        if not items:
+            return
+        self._staged[b] = []
+        from . import _lib as L
+
+        tab = (L.StageItem * len(items))()
+        for k, (g, view) in enumerate(items):
+            tab[k].src = None if g is None else g.data_ptr()
+            tab[k].dst = view.data_ptr()
+            tab[k].n = view.numel()
+        L.call("tdx_stage_scaled", tab, len(items), 1.0 / self.world, L.stream())
+
     def _launch(self, b: int):
         assert b not in self._launched, "bucket launched twice in one step"
+        self._flush(b)
         if self._cap is not None:
             # inside a graph capture: no collective can be captured (gloo runs on the host; this runtime has no event-record
             # graph nodes to release an RCCL stream either).  Leave a mark the HOST can see behind the bucket's staging

@@ -451,6 +451,20 @@ int tdx_radam_step(const TdxOptTensor* table, const int* chunk_tensor, const int
                    const float* clip, int64_t step, float lr, float beta1, float beta2, float eps, int write_grad,
                    void* stream);
 
+/* ---- gradient staging of the data-parallel step ---------------------------------------------------
+ * Replaces the per-parameter copy of a gradient into its all-reduce bucket that DistributedDataParallel's autograd hooks
+ * perform (the reference trains under Lightning's DDP strategy, train.py:144-156): dst[k] = src[k] * scale for every item
+ * in ONE launch per TDX_STAGE_MAX_ITEMS items (fp32; src == NULL: dst <- 0; src == dst: scaled in place).  `items` is a
+ * HOST array (its pointers are device pointers) and is not read after the call returns; any alignment (16-byte aligned
+ * pairs take the vector path). */
+#define TDX_STAGE_MAX_ITEMS 64
+typedef struct {
+    const void* src;
+    void* dst;
+    int64_t n;
+} TdxStageItem;
+int tdx_stage_scaled(const TdxStageItem* items, int n_items, float scale, void* stream);
+
 /* ---- FiLM projections of all ResnetBlocks at once -------------------------------------------------
  * Replaces, for every block of the U-Net in one launch, nn.Linear(c_dim, 2 * dim_out) on the conditioning vector and
  * the chunk into (scale, shift) (reference models/ddpm.py:184,191-192), and in the backward its three gradients.

@@ -92,3 +92,32 @@ def test_bench_bare_command_launches_its_own_ranks():
     # item 7a: the captured step ran under data parallelism in the same call
     cs = ov["captured_step"]
     assert "error" not in cs and cs["ms_per_step"] > 0, cs
+
+
+def test_bench_data_parallel_legs_over_rccl_at_world_size_one():
+    """TDX_BENCH_FORCE_DDP=1: the whole N > 1 path of bench.py on the REAL backend (RCCL communicator, gradient hooks with the
+    asynchronous all-reduce on RCCL's stream, 224-CU persistent kernels, overlap report, sharded sampling leg captured right
+    behind an RCCL barrier, the captured data-parallel step with its host-polled collectives) with the one GPU this box has.
+    The two-rank tests above use gloo; what only RCCL does (its watchdog thread, its own stream, its kernels beside the
+    persistent conv kernels) is covered here."""
+    env = dict(os.environ, TDX_BENCH_FORCE_DDP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "TDX_BENCH_BACKEND", "TDX_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(s.getsockname()[1])
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+           "--sample-steps", "3", "--sample-batch", "1"]
+    out = _run_bench(cmd, env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["global_batch"] == 6
+    ov = d["extra"]["overlap"]
+    assert ov["persistent_cus"] == 224 and ov["nccl_max_nchannels"] == "32", ov
+    assert ov["ms_allreduce_alone"] > 0 and ov["ms_backward"] > 0 and len(ov["per_bucket"]) == len(ov["buckets"]) >= 4
+    at = [b["enqueued_at_ms"] for b in ov["per_bucket"]]
+    assert all(a is not None and a > 0 for a in at) and at == sorted(at), at
+    cs = ov["captured_step"]
+    assert "error" not in cs and cs["ms_per_step"] > 0, cs
+    assert d["extra"]["sampling"]["ddpm_samples_per_s_T1000"] > 0

@@ -984,6 +984,43 @@ def test_clip_radam_with_bucket_view_gradients():
             assert torch.allclose(a, b, rtol=2e-6, atol=1e-7)
 
 
+def test_stage_scaled_moves_a_bucket_in_one_launch():
+    """tdx_stage_scaled (the gradient staging of parallel.BucketedDataParallel): dst = src * scale over many tensors per
+    launch -- bit-exact against torch.mul for odd sizes, slices that are only 4-byte aligned, missing gradients (src NULL ->
+    zeros), a gradient that already IS its slice (scaled in place), empty tensors and more items than one launch holds."""
+    from turbdiff_amd import _lib as L
+
+    torch.manual_seed(3)
+    d = torch.device("cuda:0")
+    sizes = [1, 3, 4, 5, 8191, 8192, 8193, 0, 100003, 17, 64 * 3 * 27, 1 << 20] + [7 + 13 * k for k in range(70)]
+    srcs = [torch.randn(n, device=d) for n in sizes]
+    flat = torch.full((sum(sizes) + len(sizes) + 1,), float("nan"), device=d)
+    tab, views, off = (L.StageItem * len(sizes))(), [], 1
+    for k, (n, g) in enumerate(zip(sizes, srcs)):
+        v = flat[off : off + n]  # odd offsets: some slices 16-byte aligned, most not
+        off += n + (k % 2)
+        views.append(v)
+        if k == 5:  # no gradient this step
+            tab[k].src = None
+        elif k == 8:  # the gradient already lives in its slice
+            v.copy_(g)
+            tab[k].src = v.data_ptr()
+        else:
+            tab[k].src = g.data_ptr()
+        tab[k].dst, tab[k].n = v.data_ptr(), n
+    for scale in (0.125, 1.0 / 3.0):
+        views[8].copy_(srcs[8])
+        L.call("tdx_stage_scaled", tab, len(sizes), scale, L.stream())
+        for k, (g, v) in enumerate(zip(srcs, views)):
+            want = torch.zeros_like(g) if k == 5 else g * scale
+            assert torch.equal(v, want), (k, sizes[k])
+    assert torch.isnan(flat[0]) and torch.isnan(flat[off:]).all()  # nothing written outside the slices
+    with pytest.raises(RuntimeError):
+        bad = (L.StageItem * 1)()
+        bad[0].src, bad[0].dst, bad[0].n = srcs[0].data_ptr(), None, 1
+        L.call("tdx_stage_scaled", bad, 1, 1.0, L.stream())
+
+
 @pytest.mark.parametrize("C,src,dst", [(24, (5, 4, 3), (9, 9, 17)), (8, (3, 3, 3), (20, 7, 30)), (64, (13, 9, 10), (6, 4, 5)),
                                        (512, (6, 4, 3), (3, 3, 3))])
 def test_resize_odd_channel_counts_and_large_factors(C, src, dst):
