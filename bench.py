@@ -681,6 +681,7 @@ def main():
                     help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes, ~1 min); quote the committed "
                          "PMC file of this tree's kernels instead")
     args = ap.parse_args()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL's intra-node transport on this driver): before HIP starts
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under

@@ -332,11 +332,17 @@ class BucketedDataParallel:
             self._pending[b] -= n
         flag, base = plan["flag_np"], (generation * 64) & 0x7FFFFFFF
         for k, b in enumerate(plan["order"], 1):
-            deadline = time.perf_counter() + timeout_s
-            while int(flag[0]) < base + k:  # written by the captured tdx_signal_host behind bucket b's staging kernels
-                if time.perf_counter() > deadline:
-                    raise RuntimeError(f"replay_launch: bucket {b} of the captured step never signalled (flag {int(flag[0])}, "
-                                       f"expected >= {base + k})")
+            if k == len(plan["order"]) and self._comm_stream is not None:
+                # the last bucket fills up where the captured backward ends: no polling -- its all-reduce is ordered behind the
+                # whole replay by a stream dependency, and the host runs ahead into finish(), the optimiser and the next replay
+                # instead of sitting out the tail of backward (the gap that left between two steps: 0.5-0.7 ms)
+                self._comm_stream.wait_stream(torch.cuda.current_stream(dev))
+            else:
+                deadline = time.perf_counter() + timeout_s
+                while int(flag[0]) < base + k:  # written by the captured tdx_signal_host behind bucket b's staging kernels
+                    if time.perf_counter() > deadline:
+                        raise RuntimeError(f"replay_launch: bucket {b} of the captured step never signalled (flag {int(flag[0])}, "
+                                           f"expected >= {base + k})")
             if self._comm_stream is not None:
                 with torch.cuda.stream(self._comm_stream):
                     self._launch(b)

@@ -39,7 +39,7 @@ def _module(tag, g):
     return m.to(dev())
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("tag", ["dil", "dil8", "conv_s2", "conv_k5", "deconv"])
 def test_baseline_layers_match_reference_vectors(golden, tag, dtype):
     g = golden("baselines")
@@ -49,8 +49,9 @@ def test_baseline_layers_match_reference_vectors(golden, tag, dtype):
     y.backward(nvc(g[f"{tag}/gy"]).to(dev()).to(dtype))
     # bf16 = bf16 activation storage between the (up to five) layers of a block; ReLU gates amplify a rounding that
     # flips a sign near zero, hence the loose gradient tolerance
-    tol = 1e-5 if dtype == torch.float32 else 3e-2
-    gtol = 1e-4 if dtype == torch.float32 else 0.1
+    # fp16 tensors (round 6) take the vector-ALU kernels: 11-bit storage between the layers
+    tol = {torch.float32: 1e-5, torch.bfloat16: 3e-2, torch.float16: 4e-3}[dtype]
+    gtol = {torch.float32: 1e-4, torch.bfloat16: 0.1, torch.float16: 8e-2}[dtype]  # (measured: up to 5.6e-2 in fp16)
     assert rel_l2(ncv(y.float().cpu()), g[f"{tag}/y"]) < tol
     assert rel_l2(ncv(x.grad.float().cpu()), g[f"{tag}/gx"]) < gtol
     for name, p in m.named_parameters():
