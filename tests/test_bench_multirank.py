@@ -1,4 +1,4 @@
-"""bench.py's N > 1 path (torch.distributed.run launch, barrier + max-over-ranks timing, rank-0 JSON line,
+"""bench.py: the N = 1 line's contract and the N > 1 path (torch.distributed.run launch, barrier + max-over-ranks timing, rank-0 JSON line,
 bucketed gradient all-reduce on the full-size model) exercised with two ranks sharing the test box's one GPU
 over gloo.  The numbers are meaningless; the code path is the one the driver runs on 2 / 4 / 8 GPUs."""
 
@@ -121,3 +121,32 @@ def test_bench_data_parallel_legs_over_rccl_at_world_size_one():
     cs = ov["captured_step"]
     assert "error" not in cs and cs["ms_per_step"] > 0, cs
     assert d["extra"]["sampling"]["ddpm_samples_per_s_T1000"] > 0
+
+
+def test_bench_single_gpu_line_keeps_its_contract():
+    """`python bench.py` at N = 1 (short: no CPU baseline, no extra legs, traffic from the committed PMC file): ONE JSON line with
+    the keys and meanings the driver reads -- BASELINE configs[1]'s metric on its workload, whole-job voxels/s consistent with
+    ms_per_step, the roofline block of the dominant kernel measured in the timed region."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TDX_BENCH_FORCE_DDP", "TDX_BENCH_BACKEND",
+              "TDX_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-extra",
+           "--no-live-traffic"]
+    out = _run_bench(cmd, env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    baseline = json.loads((ROOT / "BASELINE.json").read_text())  # "U-Net fwd+bwd voxels/sec + DDPM samples/sec, 192x64x48x4, ..."
+    assert d["metric"].startswith("U-Net fwd+bwd voxels/sec") and baseline["metric"].startswith("U-Net fwd+bwd voxels/sec")
+    assert "192x64x48x4" in d["metric"] and d["unit"] == "voxels/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "configs[1]" in d["config"]["workload"]
+    assert d["config"]["global_batch"] == 6 and d["config"]["grid"] == [192, 64, 48] and d["config"]["parallelism"] == "dp1"
+    assert abs(d["value"] - 6 * 192 * 64 * 48 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.2 < r["frac"] < 1.0
+    assert r["launches"] == 16 * 4 and r["avg_launch_ms"] > 0  # the brick / ring forward launches of the 4 timed steps
+    assert r["algorithmic_bytes_per_launch"] > 1e8 and (r["traffic"] is None or r["traffic"] > r["algorithmic_bytes_per_launch"] * 0.9)
+    assert 5.0 < d["ms_per_step"] < 200.0 and abs(d["loss"]) < 10.0
