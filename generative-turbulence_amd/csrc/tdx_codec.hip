@@ -11,6 +11,7 @@
 // is read/written as per-plane scalars.  Parameter gradients are reduced per block through LDS
 // and merged with one f32 atomic per value.
 #include "tdx_common.h"
+#include "tdx_conv3.h"  // tdx_deterministic, ordered_sum_launch, the scratch arena
 
 #define CD_THREADS 256
 #define CD_VOX 512  // voxels per block (~4 resident blocks per CU at 192x64x48)
@@ -79,7 +80,11 @@ __global__ void __launch_bounds__(CD_THREADS)
 encode_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ c,
                   const float* __restrict__ wc, float* __restrict__ dwx, float* __restrict__ dbx,
                   float* __restrict__ dwc, float* __restrict__ dbc, float* __restrict__ dc, int B, int64_t V, int D,
-                  int Dtot) {
+                  int Dtot, int64_t slab_stride) {
+    // slab_stride != 0 (TDX_DETERMINISTIC): the four gradient pointers address block 0's zeroed slab; block k merges into slab k
+    // (one contributor per element), the host adds the slabs in order afterwards
+    dwx += blockIdx.x * slab_stride; dbx += blockIdx.x * slab_stride;
+    if (dwc) { dwc += blockIdx.x * slab_stride; dbc += blockIdx.x * slab_stride; }
     const int L = Dtot >> 3, rows = CD_THREADS / L;
     const int lc = threadIdx.x % L, r = threadIdx.x / L;
     const bool active = r < rows;
@@ -168,6 +173,12 @@ encode_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, const f
 }
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+// TDX_DETERMINISTIC: `floats` of per-block slabs in the launching stream's scratch arena (behind its zero block), or nullptr
+static float* det_slabs(int64_t floats) {
+    char* arena = (char*)tdx_scratch_ptr();
+    if (!arena || (int64_t)tdx_scratch_bytes() < 256 + floats * (int64_t)sizeof(float)) return nullptr;
+    return reinterpret_cast<float*>(arena + 256);
+}
 
 extern "C" int tdx_encode_fwd(const float* x, int Fx, const float* wx, const float* bx, const float* c, int Fc,
                               const float* wc, const float* bc, void* y, int B, int64_t V, int D, int dtype,
@@ -190,14 +201,31 @@ extern "C" int tdx_encode_bwd(const void* dy, const float* x, int Fx, const floa
     const int Dtot = c ? 2 * D : D;
     if ((D % 8) || !pow2(Dtot / 8) || Dtot / 8 > 64 || Fx != 4 || (c && Fc != 4)) return TDX_ESHAPE;
     hipStream_t st = as_stream(stream);
+    dim3 grid(ceil_div(V, CD_VOX));
+    if (tdx_deterministic()) {
+        // slab = [dwx (4 D) | dbx (D) | dwc (4 D) | dbc (D)], one per block, in the scratch arena
+        const int64_t slab = 10 * (int64_t)D;
+        float* slabs = det_slabs((int64_t)grid.x * slab);
+        if (!slabs) return TDX_EINVAL;  // no arena (TDX_SCRATCH_MB=0) or too small: refuse rather than merge in arrival order
+        hipError_t e0 = hipMemsetAsync(slabs, 0, (size_t)grid.x * slab * sizeof(float), st);
+        if (e0 != hipSuccess) return (int)e0;
+        TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((encode_bwd_kernel<T, 4>), grid, dim3(CD_THREADS), 0, st, (const T*)dy, x, c, wc,
+                                                     slabs, slabs + 4 * D, c ? slabs + 5 * D : nullptr,
+                                                     c ? slabs + 9 * D : nullptr, dc, B, V, D, Dtot, slab));
+        int rc = tdx_launch_status();
+        if (rc == TDX_OK) rc = ordered_sum_launch(slabs, (int)grid.x, slab, dwx, 1, 4 * D, 4 * D, false, st);
+        if (rc == TDX_OK) rc = ordered_sum_launch(slabs + 4 * D, (int)grid.x, slab, dbx, 1, D, D, false, st);
+        if (rc == TDX_OK && c) rc = ordered_sum_launch(slabs + 5 * D, (int)grid.x, slab, dwc, 1, 4 * D, 4 * D, false, st);
+        if (rc == TDX_OK && c) rc = ordered_sum_launch(slabs + 9 * D, (int)grid.x, slab, dbc, 1, D, D, false, st);
+        return rc;
+    }
     hipError_t e = hipMemsetAsync(dwx, 0, (size_t)D * 4 * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(dbx, 0, (size_t)D * sizeof(float), st);
     if (e == hipSuccess && c) e = hipMemsetAsync(dwc, 0, (size_t)D * 4 * sizeof(float), st);
     if (e == hipSuccess && c) e = hipMemsetAsync(dbc, 0, (size_t)D * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
-    dim3 grid(ceil_div(V, CD_VOX));
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((encode_bwd_kernel<T, 4>), grid, dim3(CD_THREADS), 0, st, (const T*)dy,
-                                                 x, c, wc, dwx, dbx, dwc, dbc, dc, B, V, D, Dtot));
+                                                 x, c, wc, dwx, dbx, dwc, dbc, dc, B, V, D, Dtot, (int64_t)0));
     return tdx_launch_status();
 }
 
@@ -236,8 +264,10 @@ decode_fwd_kernel(const T* __restrict__ h, const float* __restrict__ w, const fl
 template <typename T, int F>
 __global__ void __launch_bounds__(CD_THREADS)
 decode_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ h, const float* __restrict__ w,
-                  T* __restrict__ dh, float* __restrict__ dw, float* __restrict__ db, int64_t V, int D) {
+                  T* __restrict__ dh, float* __restrict__ dw, float* __restrict__ db, int64_t V, int D, int64_t slab_stride) {
     const int b = blockIdx.y;
+    dw += ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * slab_stride;  // TDX_DETERMINISTIC: one zeroed slab per block
+    db += ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * slab_stride;
     const int L = D >> 3, rows = CD_THREADS / L;
     const int lc = threadIdx.x % L, r = threadIdx.x / L;
     const bool active = r < rows;
@@ -300,11 +330,24 @@ extern "C" int tdx_decode_bwd(const float* dy, const void* h, const float* w, vo
     TDX_CHECK_ARG(dy && h && w && dh && dw && db && B > 0 && V > 0 && D > 0);
     if ((D % 8) || !pow2(D / 8) || D / 8 > 64 || F != 4) return TDX_ESHAPE;
     hipStream_t st = as_stream(stream);
+    dim3 grid(ceil_div(V, CD_VOX_DEC), B);
+    if (tdx_deterministic()) {
+        const int64_t slab = (int64_t)F * D + F, nblk = (int64_t)grid.x * grid.y;  // [dw (F D) | db (F)] per block
+        float* slabs = det_slabs(nblk * slab);
+        if (!slabs) return TDX_EINVAL;
+        hipError_t e0 = hipMemsetAsync(slabs, 0, (size_t)nblk * slab * sizeof(float), st);
+        if (e0 != hipSuccess) return (int)e0;
+        TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((decode_bwd_kernel<T, 4>), grid, dim3(CD_THREADS), 0, st, dy, (const T*)h, w,
+                                                     (T*)dh, slabs, slabs + (int64_t)F * D, V, D, slab));
+        int rc = tdx_launch_status();
+        if (rc == TDX_OK) rc = ordered_sum_launch(slabs, (int)nblk, slab, dw, 1, F * D, F * D, false, st);
+        if (rc == TDX_OK) rc = ordered_sum_launch(slabs + (int64_t)F * D, (int)nblk, slab, db, 1, F, F, false, st);
+        return rc;
+    }
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)F * D * sizeof(float), st);
     if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)F * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
-    dim3 grid(ceil_div(V, CD_VOX_DEC), B);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((decode_bwd_kernel<T, 4>), grid, dim3(CD_THREADS), 0, st, dy,
-                                                 (const T*)h, w, (T*)dh, dw, db, V, D));
+                                                 (const T*)h, w, (T*)dh, dw, db, V, D, (int64_t)0));
     return tdx_launch_status();
 }

@@ -5,6 +5,7 @@
 // float4 rows).  f32 accumulation.  These layers are HBM-bound at the U-Net's channel
 // counts (4-174 FLOP/B); the MFMA variant lives in tdx_conv3_mfma.hip (taps = 1).
 #include "tdx_common.h"
+#include "tdx_conv3.h"
 
 #include <stdlib.h>
 // MFMA versions (tdx_conv1_mfma.hip); TDX_CONV1_IMPL=direct forces the vector-ALU kernels
@@ -14,15 +15,19 @@ int conv1_mfma_fwd_launch(const void* x1, int C1, const void* x2, int C2, const 
                           const float* gn_gamma = nullptr, const float* gn_beta = nullptr, int gn_groups = 1,
                           int64_t gn_voxels = 1, bool hf = false);
 bool conv1_wgrad_mfma_supported(int Cin, int Cout);
+// max_split / split_stride (TDX_DETERMINISTIC): at most max_split K splits (0 = the launcher's own choice), split k adds into
+// dw + k * split_stride (and dbias + k * split_stride): zeroed slabs with ONE contributor per element, summed in order afterwards
 int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
-                            int64_t rows, bool transposed, hipStream_t st, bool hf = false);
+                            int64_t rows, bool transposed, hipStream_t st, bool hf = false, int max_split = 0,
+                            int64_t split_stride = 0, int* nsplit_out = nullptr);
 // fp32 MFMA versions (tdx_conv1_mfma_f32.hip)
 bool conv1_mfma_f32_supported(int C1, int C2, int Cout, const float* w, int ldw);
 int conv1_mfma_f32_fwd_launch(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
                               const void* add, void* y, int64_t rows, int Cout, hipStream_t st);
 bool conv1_wgrad_mfma_f32_supported(int Cin, int Cout);
 int conv1_wgrad_mfma_f32_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
-                                int64_t rows, bool transposed, hipStream_t st);
+                                int64_t rows, bool transposed, hipStream_t st, int max_split = 0, int64_t split_stride = 0,
+                                int* nsplit_out = nullptr);
 static bool conv1_force_direct() {
     const char* e = getenv("TDX_CONV1_IMPL");
     return e && e[0] == 'd';
@@ -137,11 +142,14 @@ extern "C" int tdx_conv1_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
 template <typename T>
 __global__ void __launch_bounds__(256)
 conv1_wgrad_kernel(const T* __restrict__ x, int Cin, const T* __restrict__ dy, int Cout, float* __restrict__ dw,
-                   int ldw, float* __restrict__ dbias, int64_t rows, int transposed) {
+                   int ldw, float* __restrict__ dbias, int64_t rows, int transposed, int64_t rows_per_block,
+                   int64_t split_stride) {
     __shared__ float xs[C1_BK][C1_BM + 4];  // [row slice][ci]
     __shared__ float gs[C1_BK][C1_BN + 4];  // [row slice][co]
-    const int64_t rbeg = (int64_t)blockIdx.x * C1W_ROWS;
-    const int64_t rend = min(rows, rbeg + C1W_ROWS);
+    const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t rend = min(rows, rbeg + rows_per_block);
+    dw += (int64_t)blockIdx.x * split_stride;  // TDX_DETERMINISTIC: one zeroed slab per row chunk
+    if (dbias) dbias += (int64_t)blockIdx.x * split_stride;
     const int ci0 = blockIdx.y * C1_BM, co0 = blockIdx.z * C1_BN;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -193,11 +201,52 @@ conv1_wgrad_kernel(const T* __restrict__ x, int Cin, const T* __restrict__ dy, i
     if (dbias && blockIdx.y == 0 && tid < C1_BN && co0 + tid < Cout) atomicAdd(&dbias[co0 + tid], bsum);
 }
 
+// One launch of whichever weight-gradient kernel serves (dtype, Cin, Cout).  max_split / split_stride: see above.
+static int conv1_wgrad_dispatch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias, int64_t rows,
+                                int dtype, bool transposed, hipStream_t st, int max_split, int64_t split_stride, int* nsplit_out) {
+    if (tdx_is_h16(dtype) && !conv1_force_direct() && conv1_wgrad_mfma_supported(Cin, Cout))
+        return conv1_wgrad_mfma_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st, dtype == TDX_F16, max_split,
+                                       split_stride, nsplit_out);
+    if (dtype == TDX_F32 && !conv1_force_direct() && conv1_wgrad_mfma_f32_supported(Cin, Cout))
+        return conv1_wgrad_mfma_f32_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st, max_split, split_stride,
+                                           nsplit_out);
+    int64_t rpb = C1W_ROWS;
+    if (max_split > 0 && ceil_div(rows, rpb) > max_split) rpb = (ceil_div(rows, max_split) + C1_BK - 1) / C1_BK * C1_BK;
+    dim3 grid(ceil_div(rows, rpb), ceil_div(Cin, C1_BM), ceil_div(Cout, C1_BN));
+    if (nsplit_out) *nsplit_out = (int)grid.x;
+    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_wgrad_kernel<T>), grid, dim3(256), 0, st, (const T*)x, Cin,
+                                                  (const T*)dy, Cout, dw, ldw, dbias, rows, transposed ? 1 : 0, rpb, split_stride));
+    return tdx_launch_status();
+}
+
 static int conv1_bwd_weight_impl(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
                                  int64_t rows, int dtype, bool transposed, bool accumulate, hipStream_t st) {
+    const int nrow = transposed ? Cout : Cin, ncol = transposed ? Cin : Cout;
+    if (tdx_deterministic()) {
+        // K split k adds its tile into slab k of the scratch arena (zeroed; one contributor per element, so the f32 atomics
+        // are plain stores in effect), then the slabs are added in order into dw / dbias.  Without an arena: one split.
+        const int64_t slab = ((int64_t)nrow * ncol + Cout + 63) / 64 * 64;  // [nrow][ncol] compact, then the bias gradient
+        char* arena = (char*)tdx_scratch_ptr();
+        const int64_t room = arena ? ((int64_t)tdx_scratch_bytes() - 256) / (int64_t)sizeof(float) / slab : 0;
+        int max_split = (int)std::min<int64_t>(room, 256);
+        if (max_split >= 2) {
+            float* slabs = reinterpret_cast<float*>(arena + 256);
+            int nsplit = 0;
+            // the launcher may use fewer splits than allowed: all max_split slabs are zeroed, only nsplit are summed
+            hipError_t e = hipMemsetAsync(slabs, 0, (size_t)max_split * slab * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+            int rc = conv1_wgrad_dispatch(x, Cin, dy, Cout, slabs, ncol, dbias ? slabs + (int64_t)nrow * ncol : nullptr, rows, dtype,
+                                          transposed, st, max_split, slab, &nsplit);
+            if (rc != TDX_OK) return rc;
+            if (nsplit < 1 || nsplit > max_split) return TDX_EINVAL;
+            rc = ordered_sum_launch(slabs, nsplit, slab, dw, nrow, ncol, ldw, accumulate, st);
+            if (rc != TDX_OK || !dbias) return rc;
+            return ordered_sum_launch(slabs + (int64_t)nrow * ncol, nsplit, slab, dbias, 1, Cout, Cout, accumulate, st);
+        }
+    }
+    const int one_split = tdx_deterministic() ? 1 : 0;
     if (!accumulate) {
         // zero the block that is written (ldw may exceed the row length for sub-blocks)
-        const int nrow = transposed ? Cout : Cin, ncol = transposed ? Cin : Cout;
         hipError_t e = hipMemset2DAsync(dw, (size_t)ldw * sizeof(float), 0, (size_t)ncol * sizeof(float), (size_t)nrow, st);
         if (e != hipSuccess) return (int)e;
         if (dbias) {
@@ -205,14 +254,7 @@ static int conv1_bwd_weight_impl(const void* x, int Cin, const void* dy, int Cou
             if (e != hipSuccess) return (int)e;
         }
     }
-    if (tdx_is_h16(dtype) && !conv1_force_direct() && conv1_wgrad_mfma_supported(Cin, Cout))
-        return conv1_wgrad_mfma_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st, dtype == TDX_F16);
-    if (dtype == TDX_F32 && !conv1_force_direct() && conv1_wgrad_mfma_f32_supported(Cin, Cout))
-        return conv1_wgrad_mfma_f32_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st);
-    dim3 grid(ceil_div(rows, C1W_ROWS), ceil_div(Cin, C1_BM), ceil_div(Cout, C1_BN));
-    TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_wgrad_kernel<T>), grid, dim3(256), 0, st, (const T*)x, Cin,
-                                                  (const T*)dy, Cout, dw, ldw, dbias, rows, transposed ? 1 : 0));
-    return tdx_launch_status();
+    return conv1_wgrad_dispatch(x, Cin, dy, Cout, dw, ldw, dbias, rows, dtype, transposed, st, one_split, 0, nullptr);
 }
 
 extern "C" int tdx_conv1_bwd_weight(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw,

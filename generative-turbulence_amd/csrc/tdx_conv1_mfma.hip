@@ -260,7 +260,7 @@ template <int MT, int NT, bool TR, bool HF>  // tile = (32 MT) ci x (32 NT) co; 
 __global__ void __launch_bounds__(256)
 conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restrict__ dy, int Cout,
                         float* __restrict__ dw, int ldw, float* __restrict__ dbias, int64_t rows, int nsplit,
-                        int n_ci_tiles) {
+                        int n_ci_tiles, int64_t split_stride) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[(MT + NT) * C1W_PLANE];
     unsigned char* sX = smem;
     unsigned char* sG = smem + MT * C1W_PLANE;
@@ -270,6 +270,8 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
     const int col_off = (16 * (g & 1) + 4 * p) * 2;
     const int kh = g >> 1;
+    dw += (int64_t)split * split_stride;  // TDX_DETERMINISTIC: split k merges into its own zeroed slab
+    if (dbias) dbias += (int64_t)split * split_stride;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -400,7 +402,8 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
 }
 
 int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
-                            int64_t rows, bool transposed, hipStream_t st, bool hf) {
+                            int64_t rows, bool transposed, hipStream_t st, bool hf, int max_split, int64_t split_stride,
+                            int* nsplit_out) {
     const int MT = (Cin % 64 == 0) ? 2 : 1, NT = (Cout % 64 == 0) ? 2 : 1;
     const int n_ci = Cin / (32 * MT), n_co = Cout / (32 * NT);
     const int ntiles = n_ci * n_co;
@@ -410,15 +413,17 @@ int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, fl
     int nsplit = (per_cu * 256 + ntiles - 1) / ntiles;
     if (nsplit > nchunks) nsplit = (int)nchunks;
     if (nsplit < 1) nsplit = 1;
+    if (max_split > 0 && nsplit > max_split) nsplit = max_split;
+    if (nsplit_out) *nsplit_out = nsplit;
     dim3 grid((unsigned)(ntiles * nsplit));
 #define C1W_LAUNCH(M, N, T)                                                                                                 \
     do {                                                                                                                    \
         if (hf)                                                                                                            \
             hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<M, N, T, true>), grid, dim3(256), 0, st, (const bf16*)x, Cin,       \
-                               (const bf16*)dy, Cout, dw, ldw, dbias, rows, nsplit, n_ci);                                  \
+                               (const bf16*)dy, Cout, dw, ldw, dbias, rows, nsplit, n_ci, split_stride);                    \
         else                                                                                                                \
             hipLaunchKernelGGL((conv1_wgrad_mfma_kernel<M, N, T, false>), grid, dim3(256), 0, st, (const bf16*)x, Cin,      \
-                               (const bf16*)dy, Cout, dw, ldw, dbias, rows, nsplit, n_ci);                                  \
+                               (const bf16*)dy, Cout, dw, ldw, dbias, rows, nsplit, n_ci, split_stride);                    \
     } while (0)
 #define C1W_PICK(T)                           \
     if (MT == 2 && NT == 2) C1W_LAUNCH(2, 2, T); \

@@ -135,7 +135,8 @@ bool conv1_wgrad_mfma_f32_supported(int Cin, int Cout) { return (Cin % 32) == 0 
 template <int NT, bool TR>  // TR: dw[co][ci] (row stride ldw), MFMA operands swapped so that a lane owns one ci
 __global__ void __launch_bounds__(256, 2)
 conv1_f32_mfma_wgrad_kernel(const float* __restrict__ x, int Cin, const float* __restrict__ dy, int Cout,
-                            float* __restrict__ dw, int ldw, float* __restrict__ dbias, int64_t rows, int64_t rows_per_split) {
+                            float* __restrict__ dw, int ldw, float* __restrict__ dbias, int64_t rows, int64_t rows_per_split,
+                            int64_t split_stride) {
     constexpr int BN = 32 * NT;
     constexpr int GP = (BN % 64 == 0) ? BN + 32 : BN + 64;  // pitch = 32 mod 64 floats
     __shared__ float xs[F1W_RS * F1W_XP];
@@ -147,6 +148,8 @@ conv1_f32_mfma_wgrad_kernel(const float* __restrict__ x, int Cin, const float* _
     const int co0 = blockIdx.z * BN;
     const int64_t rbeg = (int64_t)blockIdx.x * rows_per_split, rend = min(rows, rbeg + rows_per_split);
     const bool active = wave * 32 < nci;
+    dw += (int64_t)blockIdx.x * split_stride;  // TDX_DETERMINISTIC: split k merges into its own zeroed slab
+    if (dbias) dbias += (int64_t)blockIdx.x * split_stride;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -235,21 +238,24 @@ conv1_f32_mfma_wgrad_kernel(const float* __restrict__ x, int Cin, const float* _
 }
 
 int conv1_wgrad_mfma_f32_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
-                                int64_t rows, bool transposed, hipStream_t st) {
+                                int64_t rows, bool transposed, hipStream_t st, int max_split_arg, int64_t split_stride,
+                                int* nsplit_out) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const int nblk = ceil_div(Cin, F1W_CI), nco = Cout / (32 * NT);
     // ~1024 workgroups overall (two per CU resident), each at least 8 slices long
     int64_t nsplit = ceil_div((int64_t)1024, (int64_t)nblk * nco);
     const int64_t max_split = ceil_div(rows, (int64_t)(8 * F1W_RS));
     if (nsplit > max_split) nsplit = max_split;
+    if (max_split_arg > 0 && nsplit > max_split_arg) nsplit = max_split_arg;
     if (nsplit < 1) nsplit = 1;
     int64_t rps = ceil_div(rows, nsplit);
     rps = ceil_div(rps, (int64_t)F1W_RS) * F1W_RS;
     nsplit = ceil_div(rows, rps);
+    if (nsplit_out) *nsplit_out = (int)nsplit;
     dim3 grid((unsigned)nsplit, nblk, nco);
 #define F1W_LAUNCH(N, T)                                                                                                  \
     hipLaunchKernelGGL((conv1_f32_mfma_wgrad_kernel<N, T>), grid, dim3(256), 0, st, (const float*)x, Cin, (const float*)dy, \
-                       Cout, dw, ldw, dbias, rows, rps)
+                       Cout, dw, ldw, dbias, rows, rps, split_stride)
     if (NT == 2 && transposed) F1W_LAUNCH(2, true);
     else if (NT == 2) F1W_LAUNCH(2, false);
     else if (transposed) F1W_LAUNCH(1, true);

@@ -81,6 +81,16 @@ int conv3_wgrad_ring_launch(const void* x1, int C1, const void* x2, int C2, cons
 // TDX_PERSISTENT_CUS in the environment (read per call), a multiple of 8 in [8, 256], default 256.  A data-parallel run
 // sets it below 256 to leave CUs to RCCL's kernels.
 int tdx_persistent_cus();
+// TDX_DETERMINISTIC=1 in the environment (read per call): the fp32 atomic merges of the backward's small parameter gradients are
+// replaced by per-split partials added in a fixed order (tdx_ordered.hip), the halo shell takes its ordered route
+bool tdx_deterministic();
+// dst[r * ld + c] (+)= sum_{k < nslab} slabs[k * stride + r * cols + c], k ascending
+int ordered_sum_launch(const float* slabs, int nslab, int64_t stride, float* dst, int rows, int cols, int64_t ld, bool add,
+                       hipStream_t st);
+// dbias[c] = sum over the nvox rows of dy[v][c] (NDHWC, C % 8 == 0) in a fixed order; part: >= C floats of scratch (256 C used if there)
+size_t bias_grad_ordered_scratch_floats(int C);
+int bias_grad_ordered_launch(const void* dy, int64_t nvox, int C, int dtype, float* dbias, float* part, size_t part_floats,
+                             hipStream_t st);
 // the caller-provided scratch arena (tdx_set_scratch, include/tdx.h); nullptr if none
 void* tdx_scratch_ptr();
 size_t tdx_scratch_bytes();

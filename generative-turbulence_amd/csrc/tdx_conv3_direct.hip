@@ -509,13 +509,16 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 conv3_wgrad_direct_kernel(const T* __restrict__ x1, int C1, const T* __restrict__ x2, int C2,
                           const T* __restrict__ dy, float* __restrict__ dwp, float* __restrict__ dbias, int B, int X,
-                          int Y, int Z, int Cout, int n_ci_tiles) {
+                          int Y, int Z, int Cout, int n_ci_tiles, int64_t vpb, int64_t slab_stride) {
+    // vpb: voxels per block (D3W_VOX).  slab_stride != 0 (TDX_DETERMINISTIC): voxel chunk k STORES its partial sums into
+    // slab k (every element of a slab has exactly one writer); the unpack kernel adds the slabs in order
     __shared__ float xs[D3_BK][D3_BM + 4];  // [voxel slice][ci]
     __shared__ float gs[D3_BK][D3_BN + 4];  // [voxel slice][co]
     const int Cin = C1 + C2;
     const int64_t nvox = (int64_t)B * X * Y * Z;
-    const int64_t vbeg = (int64_t)blockIdx.x * D3W_VOX;
-    const int64_t vend = min(nvox, vbeg + D3W_VOX);
+    const int64_t vbeg = (int64_t)blockIdx.x * vpb;
+    const int64_t vend = min(nvox, vbeg + vpb);
+    dwp += (int64_t)blockIdx.x * slab_stride;
     const int tap = blockIdx.y;
     const int ci0 = (blockIdx.z % n_ci_tiles) * D3_BM, co0 = (blockIdx.z / n_ci_tiles) * D3_BN;
     const int ex = tap / 9 - 1, ey = (tap / 3) % 3 - 1, ez = tap % 3 - 1;
@@ -577,7 +580,9 @@ conv3_wgrad_direct_kernel(const T* __restrict__ x1, int C1, const T* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int co = co0 + tx * 4 + j;
-            if (co < Cout) atomicAdd(&dwp[((int64_t)tap * Cin + ci) * Cout + co], acc[i][j]);
+            if (co >= Cout) continue;
+            if (slab_stride) dwp[((int64_t)tap * Cin + ci) * Cout + co] = acc[i][j];
+            else atomicAdd(&dwp[((int64_t)tap * Cin + ci) * Cout + co], acc[i][j]);
         }
     }
     if (do_bias && tid < D3_BN && co0 + tid < Cout) atomicAdd(&dbias[co0 + tid], bsum);
@@ -846,41 +851,70 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
                                                      conv3_wgrad_mfma_supported(C1, C2, Cout));
     int nslab = 0;
     const float* slab_ptr = nullptr;
+    // TDX_DETERMINISTIC: no bias-gradient atomics inside the weight-gradient kernels -- the bias gradient is summed from dy in a
+    // fixed order afterwards (partials in the slab region, free again once the unpack kernel has read it); the launchers hold
+    // their K splits to the slab capacity (per-split slabs added in order: their default for few splits)
+    const bool det = tdx_deterministic();
+    float* bias_acc = (dbias && !det) ? dbw : nullptr;
+    float* slab_base = dbw + ((Cout + 63) / 64) * 64;
+    auto ordered_bias = [&]() -> int {
+        if (!det || !dbias) return TDX_OK;
+        return bias_grad_ordered_launch(dy, (int64_t)B * X * Y * Z, Cout, dtype, dbias, slab_base,
+                                        (size_t)W3_MAX_SLABS * 27 * Cin * Cout, st);
+    };
+    // the fp32-tensor kernels split K 256-fold on the fine levels and merge with atomics by default (8 slabs); deterministic runs
+    // give them the slab capacity the 16-bit kernels use
+    const int cap_f32 = det ? w3_slab_capacity(Cin, Cout) : W3_MAX_SLABS;
+    auto many_slabs = [&]() -> int {  // more slabs than the 16 x 16 unpack kernel walks: the per-tap summing unpack
+        hipLaunchKernelGGL(conv3_unpack_sum_kernel, dim3(ceil_div(Cin, 8), ceil_div(Cout, 32), 27), dim3(256), 0, st, dw, dbw, dbias,
+                           Cin, Cout, slab_ptr, nslab);
+        const int rc2 = tdx_launch_status();
+        return rc2 != TDX_OK ? rc2 : ordered_bias();
+    };
     if (dtype == TDX_F32 && impl == TDX_CONV_SPLIT && conv3_wgrad_mfma_split_supported(C1, C2, Cout)) {
         float* slabs = dbw + ((Cout + 63) / 64) * 64;
-        int rc = conv3_wgrad_mfma_split_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs,
-                                               W3_MAX_SLABS, &nslab);
+        int rc = conv3_wgrad_mfma_split_launch(x1, C1, x2, C2, dy, dwp, bias_acc, B, X, Y, Z, Cout, st, slabs,
+                                               cap_f32, &nslab);
         slab_ptr = slabs;
         if (rc != TDX_OK) return rc;
+        if (nslab > W3_MAX_SLABS) return many_slabs();
     } else if (dtype == TDX_F32 && impl != TDX_CONV_DIRECT && conv3_wgrad_mfma_f32_supported(C1, C2, Cout)) {
         float* slabs = dbw + ((Cout + 63) / 64) * 64;
-        int rc = conv3_wgrad_mfma_f32_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs,
-                                             W3_MAX_SLABS, &nslab);
+        int rc = conv3_wgrad_mfma_f32_launch(x1, C1, x2, C2, dy, dwp, bias_acc, B, X, Y, Z, Cout, st, slabs,
+                                             cap_f32, &nslab);
         slab_ptr = slabs;
         if (rc != TDX_OK) return rc;
+        if (nslab > W3_MAX_SLABS) return many_slabs();
     } else if (use_mfma) {
         if (!tdx_is_h16(dtype)) return TDX_EDTYPE;
         if (!conv3_wgrad_mfma_supported(C1, C2, Cout)) return TDX_ESHAPE;
         float* slabs = dbw + ((Cout + 63) / 64) * 64;
         const int cap = w3_slab_capacity(Cin, Cout);
-        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, dbias ? dbw : nullptr, B, X, Y, Z, Cout, st, slabs, cap, &nslab,
+        int rc = conv3_wgrad_mfma_launch(x1, C1, x2, C2, dy, dwp, bias_acc, B, X, Y, Z, Cout, st, slabs, cap, &nslab,
                                          dtype == TDX_F16);
         slab_ptr = slabs;
         if (rc != TDX_OK) return rc;
-        if (nslab > W3_MAX_SLABS) {
-            hipLaunchKernelGGL(conv3_unpack_sum_kernel, dim3(ceil_div(Cin, 8), ceil_div(Cout, 32), 27), dim3(256), 0, st, dw, dbw,
-                               dbias, Cin, Cout, slab_ptr, nslab);
-            return tdx_launch_status();
-        }
+        if (nslab > W3_MAX_SLABS) return many_slabs();
     } else {
         const int64_t nvox = (int64_t)B * X * Y * Z;
         const int nci = ceil_div(Cin, D3_BM), nco = ceil_div(Cout, D3_BN);
-        dim3 grid(ceil_div(nvox, D3W_VOX), 27, nci * nco);
+        int64_t vpb = D3W_VOX, slab_stride = 0;
+        float* out = dwp;
+        if (det) {  // at most min(capacity, 64) voxel chunks, one slab each
+            const int chunks = std::min(w3_slab_capacity(Cin, Cout), 64);
+            vpb = (ceil_div(nvox, chunks) + D3_BK - 1) / D3_BK * D3_BK;
+            slab_stride = (int64_t)27 * Cin * Cout;
+            out = slab_base;
+            nslab = ceil_div(nvox, vpb);
+            slab_ptr = slab_base;
+        }
+        dim3 grid(ceil_div(nvox, vpb), 27, nci * nco);
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv3_wgrad_direct_kernel<T>), grid, dim3(256), 0, st,
-                                                      (const T*)x1, C1, (const T*)x2, C2, (const T*)dy, dwp,
-                                                      dbias ? dbw : nullptr, B, X, Y, Z, Cout, nci));
+                                                      (const T*)x1, C1, (const T*)x2, C2, (const T*)dy, out,
+                                                      bias_acc, B, X, Y, Z, Cout, nci, vpb, slab_stride));
     }
     hipLaunchKernelGGL(conv3_unpack_wgrad_kernel, dim3(ceil_div(Cin, 16), ceil_div(Cout, 16)), dim3(256), 0, st, dwp, dw,
                        dbw, dbias, Cin, Cout, slab_ptr, nslab);
-    return tdx_launch_status();
+    const int rc_unpack = tdx_launch_status();
+    return rc_unpack != TDX_OK ? rc_unpack : ordered_bias();
 }

@@ -513,7 +513,8 @@ int conv3_shell_launch(const void* dy, const void* wb, void* d1, int D1, void* d
     R.start[3] = total;
     R.pstart[3] = prows;
     const char* det_env = getenv("TDX_SHELL_DETERMINISTIC");
-    float* sbuf = (sbuf_ != nullptr && det_env && atoi(det_env) != 0 && (N % 8) == 0) ? (float*)sbuf_ : nullptr;
+    const bool det = (det_env && atoi(det_env) != 0) || tdx_deterministic();
+    float* sbuf = (sbuf_ != nullptr && det && (N % 8) == 0) ? (float*)sbuf_ : nullptr;
     const int64_t lo_offset = (int64_t)27 * K * N;
     // 64-wide channel tiles where the launch fills the chip without them; two K slices per iteration (half the
     // barriers, twice the loads in flight: the deep levels walk K = 512 with one or two workgroups per CU) where the

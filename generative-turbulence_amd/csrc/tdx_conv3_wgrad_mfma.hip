@@ -373,6 +373,8 @@ int conv3_wgrad_mfma_launch(const void* x1, int C1, const void* x2, int C2, cons
     int nsplit = ((NT == 2 ? 256 : 512) + ntiles - 1) / ntiles;
     if (nsplit > nbricks) nsplit = nbricks;
     if (nsplit < 1) nsplit = 1;
+    // TDX_DETERMINISTIC: never the atomic merge -- hold the K splits to the slabs the workspace has (added in order by the unpack kernel)
+    if (tdx_deterministic() && slabs != nullptr && nsplit > max_slabs) nsplit = max_slabs > 0 ? max_slabs : 1;
     size_t lds = W3_XBYTES + (size_t)NT * W3_GPLANE;
 #ifdef W3_STAMPS
     lds += 4 * W3_NSTAMP * 8;

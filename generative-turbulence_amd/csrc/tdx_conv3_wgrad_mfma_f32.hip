@@ -259,6 +259,8 @@ int conv3_wgrad_mfma_f32_launch(const void* x1, int C1, const void* x2, int C2, 
     int nsplit = (256 + ntiles - 1) / ntiles;
     if (nsplit > nbricks) nsplit = nbricks;
     if (nsplit < 1) nsplit = 1;
+    // TDX_DETERMINISTIC: never the atomic merge -- hold the K splits to the slabs the workspace has (added in order by the unpack kernel)
+    if (tdx_deterministic() && slabs != nullptr && nsplit > max_slabs) nsplit = max_slabs > 0 ? max_slabs : 1;
     const size_t lds = (size_t)(WF_BX(NT) + 2) * WF_HY * WF_HZ * WF_ROW + (size_t)NT * WF_BX(NT) * WF_BY * WF_BZ * WF_ROW;
     dim3 grid((unsigned)(ntiles * nsplit));
     const bool use_slabs = slabs != nullptr && nsplit <= max_slabs;

@@ -302,6 +302,8 @@ int conv3_wgrad_mfma_split_launch(const void* x1, int C1, const void* x2, int C2
     int nsplit = (256 + ntiles - 1) / ntiles;  // one workgroup per CU: one resident wave of workgroups
     if (nsplit > nbricks) nsplit = nbricks;
     if (nsplit < 1) nsplit = 1;
+    // TDX_DETERMINISTIC: never the atomic merge -- hold the K splits to the slabs the workspace has (added in order by the unpack kernel)
+    if (tdx_deterministic() && slabs != nullptr && nsplit > max_slabs) nsplit = max_slabs > 0 ? max_slabs : 1;
     const size_t lds = (size_t)2 * WS_XBYTES + 2 * WS_GBYTES;
     dim3 grid((unsigned)(ntiles * nsplit));
     const bool use_slabs = slabs != nullptr && nsplit <= max_slabs;

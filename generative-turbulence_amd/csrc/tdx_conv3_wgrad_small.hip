@@ -285,6 +285,8 @@ int conv3_wgrad_small_launch(const void* x1, int C1, const void* x2, int C2, con
     const int n_ci = Cin / 32, n_co = Cout / (32 * NT);
     const int ntiles = n_ci * n_co;
     int nsplit = std::max(1, std::min(g.ngroups, ceil_div(256, ntiles)));
+    // TDX_DETERMINISTIC: never the atomic merge -- hold the K splits to the slabs the workspace has (added in order by the unpack kernel)
+    if (tdx_deterministic() && slabs != nullptr && nsplit > max_slabs) nsplit = max_slabs > 0 ? max_slabs : 1;
     const bool use_slabs = slabs != nullptr && nsplit <= max_slabs;
     const int64_t slab_stride = use_slabs ? (int64_t)27 * Cin * Cout : 0;
     float* out = use_slabs ? slabs : dwp;

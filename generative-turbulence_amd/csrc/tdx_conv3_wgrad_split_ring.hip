@@ -307,6 +307,8 @@ int conv3_wgrad_split_ring_launch(const void* x1, int C1, const void* x2, int C2
     // a workgroup should walk several bricks, or the double buffering has nothing to overlap
     if (nbricks < 4 * nsplit) return TDX_ESHAPE;
     const size_t lds = (size_t)2 * SR_SET;
+    // TDX_DETERMINISTIC: never the atomic merge -- hold the K splits to the slabs the workspace has (added in order by the unpack kernel)
+    if (tdx_deterministic() && slabs != nullptr && nsplit > max_slabs) nsplit = max_slabs > 0 ? max_slabs : 1;
     const bool use_slabs = slabs != nullptr && nsplit <= max_slabs;
     const int64_t slab_stride = use_slabs ? (int64_t)27 * Cin * Cout : 0;
     float* out = use_slabs ? slabs : dwp;

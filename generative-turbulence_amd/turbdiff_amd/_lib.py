@@ -153,6 +153,15 @@ SCRATCH_MAX_ARENAS = int(os.environ.get("TDX_SCRATCH_MAX_ARENAS", "6"))
 # entry points that may use the arena (K-split slabs of the small-grid kernels, the zero block of the DMA kernels)
 ARENA_USERS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_fwd_partial", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add",
                "tdx_conv3_bwd_weight", "tdx_attn_fwd"}  # tdx_attn_fwd: partial (O, m, l) of the stream-K schedule
+# TDX_DETERMINISTIC=1: these merge their parameter gradients through per-split slabs in the launching stream's arena as well
+DET_ARENA_USERS = {"tdx_conv1_bwd_weight", "tdx_conv1_bwd_weight_oc", "tdx_encode_bwd", "tdx_decode_bwd"}
+
+
+def deterministic() -> bool:
+    """TDX_DETERMINISTIC=1 in the environment (read per call, like the library does): run-to-run reproducible gradients."""
+    return os.environ.get("TDX_DETERMINISTIC", "0") not in ("", "0")
+
+
 # bind + launch of an arena user is one critical section: the library keeps ONE arena pointer per process and ctypes
 # releases the GIL during a foreign call, so a second launching thread could otherwise re-bind between the two
 _LAUNCH_LOCK = threading.RLock()
@@ -331,7 +340,7 @@ TIMER: KernelTimer | None = None
 
 def call(name: str, *args, work: float = 0.0, meta=None):
     """meta: None, a dict, or a zero-argument callable returning one (evaluated only while a timer is attached)."""
-    if name in ARENA_USERS:
+    if name in ARENA_USERS or (name in DET_ARENA_USERS and deterministic()):
         with _LAUNCH_LOCK:
             ensure_scratch()  # the arena of the launching stream
             rc = _launch(name, args, work, meta)

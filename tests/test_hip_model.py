@@ -260,6 +260,91 @@ def _check_modes_against_oracle(monkeypatch, diff, inputs, md, ref_loss, leaves,
     diff.model.set_compute_dtype(torch.float32)
 
 
+@pytest.mark.parametrize("mode,impl,dtype", [("bf16", "auto", torch.bfloat16), ("fp16", "auto", torch.float16),
+                                             ("f32s", "split", torch.float32), ("f32", "auto", torch.float32)])
+@pytest.mark.parametrize("grid,B", [((96, 32, 24), 2), ((192, 64, 48), 3), ((50, 26, 22), 2)])
+def test_deterministic_switch_gives_bit_identical_gradients(grid, B, mode, impl, dtype, monkeypatch):
+    """TDX_DETERMINISTIC=1: three backward passes of the same training step leave the SAME BITS in all 139 parameter
+    gradients (by default 136 of them differ run to run: halo-shell atomics, and fp32 atomic merges of the bias / 1x1 /
+    encoder / decoder / first-conv gradients) -- at a small grid, at the benchmark's grid (ring / producer-consumer kernels,
+    many K splits) and at a ragged one -- and the gradients are the default path's to fp32 summation order."""
+    from turbdiff_amd.models.ddpm import GaussianDiffusion
+
+    net, _ = _full_size_problem(seed=5)
+    X, Y, Z = grid
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 4, X, Y, Z, generator=g).to(dev())
+    c_local = torch.randn(4, X, Y, Z, generator=g)
+    noise = torch.randn(B, 4, X, Y, Z, generator=g).to(dev())
+    t = torch.tensor([3, 250, 499][:B]).to(dev())
+    m = torch.zeros(X, Y, Z, dtype=torch.bool)
+    m[1:-1, 1:-1, 1:-1] = True
+    md = SimpleNamespace(cell_idx=m.flatten().nonzero().flatten().to(dev()))
+    diff = GaussianDiffusion(net, timesteps=500, beta_schedule="log-snr-linear", noise_bcs=True).to(dev())
+    monkeypatch.setenv("TDX_CONV_IMPL", impl)
+    diff.model.set_compute_dtype(dtype)
+    S = 2.0**12 if mode == "fp16" else 1.0
+
+    def grads():
+        diff.zero_grad(set_to_none=True)
+        loss, _ = diff.p_losses(x, t, cond(c_local), md, None, noise=noise)
+        (loss * S).backward()
+        torch.cuda.synchronize()
+        return loss.item(), {n: p.grad.clone() for n, p in diff.model.named_parameters()}
+
+    base_loss, base = grads()  # the default path (atomics)
+    monkeypatch.setenv("TDX_DETERMINISTIC", "1")
+    runs = [grads() for _ in range(3)]
+    monkeypatch.delenv("TDX_DETERMINISTIC")
+    assert all(r[0] == base_loss for r in runs)
+    differ = [n for r in runs[1:] for n in r[1] if not torch.equal(r[1][n], runs[0][1][n])]
+    assert not differ, (mode, sorted(set(differ)))
+    # the same numbers as the default path up to summation order (bf16: the shell's packed atomics round in bf16 per add,
+    # the ordered route adds in fp32 -- and that difference travels down the backward pass)
+    tol = {"bf16": 2e-2, "fp16": 3e-3, "f32s": 2e-5, "f32": 2e-5}[mode]
+    for n, g0 in base.items():
+        if g0.norm() > 0:
+            assert rel_l2(runs[0][1][n].float().cpu(), g0.float().cpu()) < tol, (mode, n)
+    monkeypatch.delenv("TDX_CONV_IMPL")
+    diff.model.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_deterministic_switch_reproduces_a_training_run(mode, monkeypatch):
+    """TDX_DETERMINISTIC=1 over whole optimiser steps: two runs of four training steps from the same weights and seeds
+    (t and noise drawn on the device, clip + RAdam through ClipRAdam, weights re-packed every step; fp16 under its loss
+    scale) end in bit-identical parameters and losses."""
+    import bench
+    from turbdiff_amd.models.ddpm import GaussianDiffusion
+
+    monkeypatch.setenv("TDX_DETERMINISTIC", "1")
+    net, sd = _full_size_problem(seed=9)
+    grid, B = (96, 32, 24), 2
+    x, c_local, cell_idx = bench.synthetic_inputs(B, dev(), grid)
+    md = SimpleNamespace(cell_idx=cell_idx)
+    diff = GaussianDiffusion(net, timesteps=500, beta_schedule="log-snr-linear", noise_bcs=True).to(dev())
+    bench.set_mode(diff, mode)
+    ends = []
+    for run in range(2):
+        diff.model.load_state_dict(sd)
+        opt = bench.new_optimizer(diff, mode, bench.LOSS_ELEMENTS(B, cell_idx))
+        torch.manual_seed(123)
+        losses = []
+        for step in range(4):
+            loss, _ = diff(x, cond(c_local), md, None)
+            opt.scale_loss(loss).backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        ends.append((losses, {n: p.detach().clone() for n, p in diff.model.named_parameters()}))
+    assert ends[0][0] == ends[1][0], (ends[0][0], ends[1][0])
+    assert ends[0][0][0] != ends[0][0][3]  # the weights did move
+    differ = [n for n in ends[0][1] if not torch.equal(ends[0][1][n], ends[1][1][n])]
+    assert not differ, differ
+    bench.set_mode(diff, "f32")
+
+
 @pytest.mark.timeout(1500)
 def test_benchmark_batch_gradients_match_oracle(monkeypatch):
     """The benchmarked shape itself: B = 6 at 192 x 64 x 48 (per-sample strides, level-1 launches on the ring kernels,
