@@ -4,8 +4,8 @@
 // weight / bias gradients of the 1x1 convs, of the encoders / decoder and of the first conv): their sums depend on arrival
 // order in the last bits (4e-7 relative, profiles/r13_determinism_probe.txt).  With the switch every such merge goes through
 // per-split partials that are added in a FIXED order by the two kernels below, and the halo shell takes its ordered route
-// (TDX_SHELL_DETERMINISTIC): a training step then produces the same bits every run.  The reference has no such switch of
-// its own -- it inherits torch.use_deterministic_algorithms (Lightning's `deterministic` flag).
+// (TDX_SHELL_DETERMINISTIC): a training step then produces the same bits every run.  The reference sets no determinism flag
+// of its own; under torch the counterpart would be torch.use_deterministic_algorithms.
 //
 // What stays unordered: the f64 atomics of the GroupNorm / loss statistics.  Their sums differ between runs by ~1e-16
 // relative before they are rounded to fp32 once, i.e. a visible difference needs a sum within 1e-16 of an fp32 rounding
