@@ -584,6 +584,41 @@ def real_grid_leg(dev, B):
     return res
 
 
+def deterministic_leg(diff, x, C, md, mode, B, cell_idx):
+    """TDX_DETERMINISTIC=1 (csrc/tdx_ordered.hip): time per training step with every fp32 atomic merge of the backward pass on its
+    ordered route, and whether two identical backward passes leave the same bits in every parameter gradient -- with the
+    switch and, for comparison, without it."""
+    def two_passes():
+        t = torch.full((B,), ACCURACY_T, device=x.device, dtype=torch.long)
+        noise = torch.randn(x.shape, device=x.device, generator=torch.Generator(device=x.device).manual_seed(1))
+        S = 2.0 ** 12 if mode == "fp16" else 1.0
+        runs = []
+        for _ in range(2):
+            diff.zero_grad(set_to_none=True)
+            loss, _ = diff.p_losses(x, t, C, md, None, noise=noise)
+            (loss * S).backward()
+            torch.cuda.synchronize()
+            runs.append({n: p.grad.clone() for n, p in diff.model.named_parameters()})
+        diff.zero_grad(set_to_none=True)
+        return sum(not torch.equal(runs[0][n], runs[1][n]) for n in runs[0]), len(runs[0])
+
+    set_mode(diff, mode)
+    differ_default, n = two_passes()
+    before = os.environ.get("TDX_DETERMINISTIC")
+    os.environ["TDX_DETERMINISTIC"] = "1"  # read per call by the library and by _lib.call
+    try:
+        differ_det, _ = two_passes()
+        ms = timed_train_steps(diff, x, C, md, mode, 10, 3)
+    finally:
+        if before is None:
+            del os.environ["TDX_DETERMINISTIC"]
+        else:
+            os.environ["TDX_DETERMINISTIC"] = before
+    return {"ms_per_step": ms, "parameter_gradients": n, "differing_between_two_runs": differ_det,
+            "differing_between_two_runs_by_default": differ_default,
+            "note": "TDX_DETERMINISTIC=1: ordered merges instead of fp32 atomics in the backward pass; two identical backward passes compared bit for bit"}
+
+
 def _parse_cpulist(text):
     out = []
     for part in text.strip().split(","):
@@ -1061,6 +1096,8 @@ def main():
                 extra["real_grid"]["modes"]["bf16"]["ms_per_step"] / (REAL_GRID[0] * REAL_GRID[1] * REAL_GRID[2])
                 / (out["ms_per_step"] / V)) if args.dtype == "bf16" else None
             leg_done("real_grid_194x50x50")
+            extra["deterministic"] = deterministic_leg(diff, x, C, md, args.dtype, B, cell_idx)
+            leg_done("deterministic_switch")
             extra["cfg5_attention"] = cfg5_attention_leg(dev)
             leg_done("cfg5_attention")
     if extra:
