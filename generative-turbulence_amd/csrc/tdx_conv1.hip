@@ -16,10 +16,11 @@ int conv1_mfma_fwd_launch(const void* x1, int C1, const void* x2, int C2, const 
                           int64_t gn_voxels = 1, bool hf = false);
 bool conv1_wgrad_mfma_supported(int Cin, int Cout);
 // max_split / split_stride (TDX_DETERMINISTIC): at most max_split K splits (0 = the launcher's own choice), split k adds into
-// dw + k * split_stride (and dbias + k * split_stride): zeroed slabs with ONE contributor per element, summed in order afterwards
+// dw + k * split_stride (and dbias + k * split_stride): zeroed slabs with ONE contributor per element, summed in order afterwards;
+// plan_only: report the number of splits the launch would use (nsplit_out) without launching
 int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
                             int64_t rows, bool transposed, hipStream_t st, bool hf = false, int max_split = 0,
-                            int64_t split_stride = 0, int* nsplit_out = nullptr);
+                            int64_t split_stride = 0, int* nsplit_out = nullptr, bool plan_only = false);
 // fp32 MFMA versions (tdx_conv1_mfma_f32.hip)
 bool conv1_mfma_f32_supported(int C1, int C2, int Cout, const float* w, int ldw);
 int conv1_mfma_f32_fwd_launch(const void* x1, int C1, const void* x2, int C2, const float* w, int ldw, const float* bias,
@@ -27,7 +28,7 @@ int conv1_mfma_f32_fwd_launch(const void* x1, int C1, const void* x2, int C2, co
 bool conv1_wgrad_mfma_f32_supported(int Cin, int Cout);
 int conv1_wgrad_mfma_f32_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
                                 int64_t rows, bool transposed, hipStream_t st, int max_split = 0, int64_t split_stride = 0,
-                                int* nsplit_out = nullptr);
+                                int* nsplit_out = nullptr, bool plan_only = false);
 static bool conv1_force_direct() {
     const char* e = getenv("TDX_CONV1_IMPL");
     return e && e[0] == 'd';
@@ -203,17 +204,19 @@ conv1_wgrad_kernel(const T* __restrict__ x, int Cin, const T* __restrict__ dy, i
 
 // One launch of whichever weight-gradient kernel serves (dtype, Cin, Cout).  max_split / split_stride: see above.
 static int conv1_wgrad_dispatch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias, int64_t rows,
-                                int dtype, bool transposed, hipStream_t st, int max_split, int64_t split_stride, int* nsplit_out) {
+                                int dtype, bool transposed, hipStream_t st, int max_split, int64_t split_stride, int* nsplit_out,
+                                bool plan_only = false) {
     if (tdx_is_h16(dtype) && !conv1_force_direct() && conv1_wgrad_mfma_supported(Cin, Cout))
         return conv1_wgrad_mfma_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st, dtype == TDX_F16, max_split,
-                                       split_stride, nsplit_out);
+                                       split_stride, nsplit_out, plan_only);
     if (dtype == TDX_F32 && !conv1_force_direct() && conv1_wgrad_mfma_f32_supported(Cin, Cout))
         return conv1_wgrad_mfma_f32_launch(x, Cin, dy, Cout, dw, ldw, dbias, rows, transposed, st, max_split, split_stride,
-                                           nsplit_out);
+                                           nsplit_out, plan_only);
     int64_t rpb = C1W_ROWS;
     if (max_split > 0 && ceil_div(rows, rpb) > max_split) rpb = (ceil_div(rows, max_split) + C1_BK - 1) / C1_BK * C1_BK;
     dim3 grid(ceil_div(rows, rpb), ceil_div(Cin, C1_BM), ceil_div(Cout, C1_BN));
     if (nsplit_out) *nsplit_out = (int)grid.x;
+    if (plan_only) return TDX_OK;
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv1_wgrad_kernel<T>), grid, dim3(256), 0, st, (const T*)x, Cin,
                                                   (const T*)dy, Cout, dw, ldw, dbias, rows, transposed ? 1 : 0, rpb, split_stride));
     return tdx_launch_status();
@@ -231,14 +234,18 @@ static int conv1_bwd_weight_impl(const void* x, int Cin, const void* dy, int Cou
         int max_split = (int)std::min<int64_t>(room, 256);
         if (max_split >= 2) {
             float* slabs = reinterpret_cast<float*>(arena + 256);
-            int nsplit = 0;
-            // the launcher may use fewer splits than allowed: all max_split slabs are zeroed, only nsplit are summed
-            hipError_t e = hipMemsetAsync(slabs, 0, (size_t)max_split * slab * sizeof(float), st);
-            if (e != hipSuccess) return (int)e;
-            int rc = conv1_wgrad_dispatch(x, Cin, dy, Cout, slabs, ncol, dbias ? slabs + (int64_t)nrow * ncol : nullptr, rows, dtype,
-                                          transposed, st, max_split, slab, &nsplit);
+            float* bias_slab = dbias ? slabs + (int64_t)nrow * ncol : nullptr;
+            int nsplit = 0;  // what the launcher will use (often far fewer than allowed): only those slabs are zeroed and summed
+            int rc = conv1_wgrad_dispatch(x, Cin, dy, Cout, slabs, ncol, bias_slab, rows, dtype, transposed, st, max_split, slab,
+                                          &nsplit, true);
             if (rc != TDX_OK) return rc;
             if (nsplit < 1 || nsplit > max_split) return TDX_EINVAL;
+            hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nsplit * slab * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+            int launched = 0;
+            rc = conv1_wgrad_dispatch(x, Cin, dy, Cout, slabs, ncol, bias_slab, rows, dtype, transposed, st, max_split, slab, &launched);
+            if (rc != TDX_OK) return rc;
+            if (launched != nsplit) return TDX_EINVAL;
             rc = ordered_sum_launch(slabs, nsplit, slab, dw, nrow, ncol, ldw, accumulate, st);
             if (rc != TDX_OK || !dbias) return rc;
             return ordered_sum_launch(slabs + (int64_t)nrow * ncol, nsplit, slab, dbias, 1, Cout, Cout, accumulate, st);

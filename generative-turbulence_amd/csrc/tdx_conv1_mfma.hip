@@ -403,7 +403,7 @@ conv1_wgrad_mfma_kernel(const bf16* __restrict__ x, int Cin, const bf16* __restr
 
 int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
                             int64_t rows, bool transposed, hipStream_t st, bool hf, int max_split, int64_t split_stride,
-                            int* nsplit_out) {
+                            int* nsplit_out, bool plan_only) {
     const int MT = (Cin % 64 == 0) ? 2 : 1, NT = (Cout % 64 == 0) ? 2 : 1;
     const int n_ci = Cin / (32 * MT), n_co = Cout / (32 * NT);
     const int ntiles = n_ci * n_co;
@@ -415,6 +415,7 @@ int conv1_wgrad_mfma_launch(const void* x, int Cin, const void* dy, int Cout, fl
     if (nsplit < 1) nsplit = 1;
     if (max_split > 0 && nsplit > max_split) nsplit = max_split;
     if (nsplit_out) *nsplit_out = nsplit;
+    if (plan_only) return TDX_OK;
     dim3 grid((unsigned)(ntiles * nsplit));
 #define C1W_LAUNCH(M, N, T)                                                                                                 \
     do {                                                                                                                    \

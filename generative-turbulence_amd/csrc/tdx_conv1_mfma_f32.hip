@@ -239,7 +239,7 @@ conv1_f32_mfma_wgrad_kernel(const float* __restrict__ x, int Cin, const float* _
 
 int conv1_wgrad_mfma_f32_launch(const void* x, int Cin, const void* dy, int Cout, float* dw, int ldw, float* dbias,
                                 int64_t rows, bool transposed, hipStream_t st, int max_split_arg, int64_t split_stride,
-                                int* nsplit_out) {
+                                int* nsplit_out, bool plan_only) {
     const int NT = (Cout % 64 == 0) ? 2 : 1;
     const int nblk = ceil_div(Cin, F1W_CI), nco = Cout / (32 * NT);
     // ~1024 workgroups overall (two per CU resident), each at least 8 slices long
@@ -252,6 +252,7 @@ int conv1_wgrad_mfma_f32_launch(const void* x, int Cin, const void* dy, int Cout
     rps = ceil_div(rps, (int64_t)F1W_RS) * F1W_RS;
     nsplit = ceil_div(rows, rps);
     if (nsplit_out) *nsplit_out = (int)nsplit;
+    if (plan_only) return TDX_OK;
     dim3 grid((unsigned)nsplit, nblk, nco);
 #define F1W_LAUNCH(N, T)                                                                                                  \
     hipLaunchKernelGGL((conv1_f32_mfma_wgrad_kernel<N, T>), grid, dim3(256), 0, st, (const float*)x, Cin, (const float*)dy, \
