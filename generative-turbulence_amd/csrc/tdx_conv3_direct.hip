@@ -668,6 +668,13 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     TDX_CHECK_ARG(x1 && wf && y && stats && gn_workspace && B > 0 && X > 0 && Y > 0 && Z > 0 && C1 > 0 && C2 >= 0);
     TDX_CHECK_ARG(Cout > 0 && G > 0 && (Cout % G) == 0 && (C2 == 0 || x2));
     const bool clean = (impl & TDX_WS_CLEAN) != 0;
+    if (tdx_deterministic()) {
+        // the conv kernels' epilogues merge their moments with f64 atomics in arrival order; deterministic runs take the conv and
+        // then the statistics pass over its result, whose block partials are exact in f64 (gn_stats_launch)
+        int rc = tdx_conv3_fwd(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, dtype, impl & 0xff, stream);
+        if (rc != TDX_OK) return rc;
+        return gn_stats_launch(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, clean, as_stream(stream));
+    }
     impl &= 0xff;
     const bool use_mfma =
         tdx_is_h16(dtype) && (impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && mfma_ok(dtype, C1, C2, Cout)));

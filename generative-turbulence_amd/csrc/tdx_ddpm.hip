@@ -3,6 +3,7 @@
 // the (B,C,V) <-> (B,V,C) transposes which go through an LDS tile so that both sides are
 // coalesced.
 #include "tdx_common.h"
+#include "tdx_conv3.h"  // tdx_deterministic
 
 extern "C" int tdx_version(void) { return 1; }
 extern "C" const char* tdx_arch(void) { return "gfx950"; }
@@ -211,7 +212,7 @@ extern "C" int tdx_p_sample_step(const float* x_t, const float* eps, const float
 __global__ void __launch_bounds__(256)
 masked_loss_kernel(const float* __restrict__ e, const float* __restrict__ n, const uint8_t* __restrict__ mask, int l1,
                    double* __restrict__ acc, float* __restrict__ grad, float gscale, int64_t V,
-                   const int64_t* __restrict__ n_cells_dev, double samples) {
+                   const int64_t* __restrict__ n_cells_dev, double samples, double quant) {
     if (n_cells_dev) gscale = (float)(1.0 / (samples * (double)*n_cells_dev));
     const int64_t base = (int64_t)blockIdx.y * V;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -230,7 +231,11 @@ masked_loss_kernel(const float* __restrict__ e, const float* __restrict__ n, con
     double ws = wave_sum((double)s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ws;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) {
+        double t = part[0] + part[1] + part[2] + part[3];
+        if (quant != 0.0) t = rint(t * quant) / quant;  // TDX_DETERMINISTIC: exact (order-independent) f64 sums, see gn_stats_launch
+        atomicAdd(acc, t);
+    }
 }
 // the same pass with 16-B accesses, two independent trips in flight per thread (V % 4 == 0: every sample and feature
 // plane starts on a 16-B boundary).  The scalar kernel above walks 36 dependent-free but ROLLED trips of 4-B loads per
@@ -238,7 +243,7 @@ masked_loss_kernel(const float* __restrict__ e, const float* __restrict__ n, con
 __global__ void __launch_bounds__(256)
 masked_loss_vec_kernel(const float* __restrict__ e, const float* __restrict__ n, const uint8_t* __restrict__ mask, int l1,
                        double* __restrict__ acc, float* __restrict__ grad, float gscale, int64_t V,
-                       const int64_t* __restrict__ n_cells_dev, double samples) {
+                       const int64_t* __restrict__ n_cells_dev, double samples, double quant) {
     if (n_cells_dev) gscale = (float)(1.0 / (samples * (double)*n_cells_dev));
     const int64_t base = (int64_t)blockIdx.y * V;
     const int64_t V4 = V >> 2, stride = (int64_t)gridDim.x * blockDim.x;
@@ -271,7 +276,11 @@ masked_loss_vec_kernel(const float* __restrict__ e, const float* __restrict__ n,
     double ws = wave_sum((double)s);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ws;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) {
+        double t = part[0] + part[1] + part[2] + part[3];
+        if (quant != 0.0) t = rint(t * quant) / quant;  // TDX_DETERMINISTIC: exact (order-independent) f64 sums, see gn_stats_launch
+        atomicAdd(acc, t);
+    }
 }
 __global__ void masked_loss_finish(const double* acc, float* loss, double inv, const int64_t* n_cells_dev, double samples) {
     if (n_cells_dev) inv = 1.0 / (samples * (double)*n_cells_dev);
@@ -286,16 +295,17 @@ static int masked_loss_launch(const float* eps_hat, const float* noise, const ui
     if (err != hipSuccess) return (int)err;
     const double samples = (double)B * F;
     const double inv = n_cells_dev ? 0.0 : 1.0 / (samples * (double)n_cells);
+    const double quant = tdx_deterministic() ? 1048576.0 : 0.0;  // block partials on a 2^-20 grid: exact up to a total of 2^33
     const bool vec = (V % 4) == 0 && ((uintptr_t)eps_hat % 16) == 0 && ((uintptr_t)noise % 16) == 0 && ((uintptr_t)mask % 4) == 0 &&
                      (grad == nullptr || ((uintptr_t)grad % 16) == 0);
     if (vec) {
         dim3 grid((unsigned)min((int64_t)128, (V / 4 + 511) / 512), B * F);
         hipLaunchKernelGGL(masked_loss_vec_kernel, grid, dim3(256), 0, as_stream(stream), eps_hat, noise, mask, l1,
-                           (double*)workspace, grad, (float)inv, V, n_cells_dev, samples);
+                           (double*)workspace, grad, (float)inv, V, n_cells_dev, samples, quant);
     } else {
         dim3 grid((unsigned)min((int64_t)64, (V + 255) / 256), B * F);
         hipLaunchKernelGGL(masked_loss_kernel, grid, dim3(256), 0, as_stream(stream), eps_hat, noise, mask, l1,
-                           (double*)workspace, grad, (float)inv, V, n_cells_dev, samples);
+                           (double*)workspace, grad, (float)inv, V, n_cells_dev, samples, quant);
     }
     hipLaunchKernelGGL(masked_loss_finish, dim3(1), dim3(1), 0, as_stream(stream), (const double*)workspace, loss, inv,
                        n_cells_dev, samples);

@@ -13,6 +13,7 @@
 //             atomics, deterministic) -> finalize -> apply pass
 #define TDX_NT_LOADS 1  // activations are streamed once per pass: nontemporal 16-B loads (+0.4 % step)
 #include "tdx_common.h"
+#include "tdx_conv3.h"
 
 #define GN_THREADS 256
 #define GN_MAX_BLOCKS 512  // streaming blocks per sample; bounds the backward partial-sum buffer
@@ -21,8 +22,10 @@
 // per-channel partial sums of two quantities, reduced over the block and added (f64 atomics)
 // into acc[(b*C + c)*2 + {0,1}]
 template <int NQ>
+// store (TDX_DETERMINISTIC): `acc` is this block's own table -- the partial is stored, not added; gn_stats_merge_kernel adds
+// the blocks' tables in block order
 __device__ __forceinline__ void block_channel_reduce(float (&s)[NQ][8], int L, int lane_c, bool active,
-                                                     double* __restrict__ acc, int C) {
+                                                     double* __restrict__ acc, int C, bool store = false) {
     __shared__ float red[GN_THREADS][NQ * 8 + 1];
     const int tid = threadIdx.x;
 #pragma unroll
@@ -37,14 +40,15 @@ __device__ __forceinline__ void block_channel_reduce(float (&s)[NQ][8], int L, i
         const int lc = c >> 3, j = c & 7;
         double t = 0.0;
         for (int r = 0; r < rows; ++r) t += (double)red[r * L + lc][q * 8 + j];
-        atomicAdd(&acc[(size_t)c * NQ + q], t);
+        if (store) acc[(size_t)c * NQ + q] = t;
+        else atomicAdd(&acc[(size_t)c * NQ + q], t);
     }
     (void)lane_c;
 }
 
 template <typename T>
 __global__ void __launch_bounds__(GN_THREADS)
-gn_stats_kernel(const T* __restrict__ x, double* __restrict__ acc, int64_t V, int C, int vpb) {
+gn_stats_kernel(const T* __restrict__ x, double* __restrict__ acc, int64_t V, int C, int vpb, double* __restrict__ part) {
     const int b = blockIdx.y;
     const int L = C >> 3;
     const int rows = GN_THREADS / L;
@@ -79,7 +83,25 @@ gn_stats_kernel(const T* __restrict__ x, double* __restrict__ acc, int64_t V, in
             for (int j = 0; j < 8; ++j) { s[0][j] += a.v[j]; s[1][j] += a.v[j] * a.v[j]; }
         }
     }
-    block_channel_reduce<2>(s, L, lc, active, acc + (size_t)b * C * 2, C);
+    if (part) block_channel_reduce<2>(s, L, lc, active, part + ((size_t)b * gridDim.x + blockIdx.x) * C * 2, C, true);
+    else block_channel_reduce<2>(s, L, lc, active, acc + (size_t)b * C * 2, C);
+}
+
+// TDX_DETERMINISTIC: acc[b][c][q] = sum over the sample's blocks of part[b][blk][c][q], in block order (f64)
+__global__ void __launch_bounds__(256) gn_stats_merge_kernel(const double* __restrict__ part, double* __restrict__ acc, int nblk,
+                                                            int C2, int total) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int b = e / C2, r = e - b * C2;
+    const double* p = part + (size_t)b * nblk * C2 + r;
+    double v = 0.0;
+    int k = 0;
+    for (; k + 4 <= nblk; k += 4) {  // four loads in flight, added in block order
+        const double a0 = p[(size_t)k * C2], a1 = p[(size_t)(k + 1) * C2], a2 = p[(size_t)(k + 2) * C2], a3 = p[(size_t)(k + 3) * C2];
+        v = (((v + a0) + a1) + a2) + a3;
+    }
+    for (; k < nblk; ++k) v += p[(size_t)k * C2];
+    acc[e] = v;
 }
 
 // per (b, g): mean / rstd from per-channel (sum, sumsq)
@@ -167,9 +189,22 @@ int gn_stats_launch(const void* x, float* stats, int B, int64_t V, int C, int G,
     // trips took 27 us for 7 MB, profiles/r11_batch_scaling.txt -- but not so many that the f64 atomics take over
     int64_t vpb = ((int64_t)B * V + 127) / 128;
     vpb = vpb < 32 ? 32 : (vpb > GN_VOX_PER_BLOCK ? GN_VOX_PER_BLOCK : (vpb + 31) / 32 * 32);
+    double* part = nullptr;
+    if (tdx_deterministic()) {
+        // no f64 atomics in arrival order: at most 64 blocks per sample, each stores its own table in the scratch arena (one
+        // writer per element), gn_stats_merge_kernel adds them in block order
+        if (ceil_div(V, vpb) > 64) vpb = (ceil_div(V, 64) + 31) / 32 * 32;
+        const size_t need = (size_t)B * ceil_div(V, vpb) * C * 2 * sizeof(double);
+        if (tdx_scratch_ptr() != nullptr && tdx_scratch_bytes() >= 256 + need) part = reinterpret_cast<double*>((char*)tdx_scratch_ptr() + 256);
+        else vpb = (V + 31) / 32 * 32;  // no arena (TDX_SCRATCH_MB=0): ONE block per sample adds into the zeroed table -- slow, still ordered
+    }
     dim3 grid(ceil_div(V, vpb), B);
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(GN_THREADS), 0, stream,
-                                                  (const T*)x, acc, V, C, (int)vpb));
+                                                  (const T*)x, acc, V, C, (int)vpb, part));
+    if (part) {
+        const int total = B * C * 2;
+        hipLaunchKernelGGL(gn_stats_merge_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, part, acc, (int)grid.x, C * 2, total);
+    }
     hipLaunchKernelGGL(gn_stats_finalize, dim3(B * G), dim3(64), 0, stream, acc, stats, B, C, G, V, eps, 1);
     return tdx_launch_status();
 }

@@ -7,9 +7,10 @@
 // (TDX_SHELL_DETERMINISTIC): a training step then produces the same bits every run.  The reference sets no determinism flag
 // of its own; under torch the counterpart would be torch.use_deterministic_algorithms.
 //
-// What stays unordered: the f64 atomics of the GroupNorm / loss statistics.  Their sums differ between runs by ~1e-16
-// relative before they are rounded to fp32 once, i.e. a visible difference needs a sum within 1e-16 of an fp32 rounding
-// boundary (about 1e-8 per statistic).
+// The f64 atomics of the forward go as well: tdx_conv3_fwd_gn takes the conv and then the statistics pass over its result
+// (no moments from the conv epilogues), whose blocks store their own f64 tables for an ordered merge (tdx_groupnorm.hip);
+// the loss adds block partials rounded to a 2^-20 grid, on which f64 additions are exact -- order-independent -- up to 2^33.
+// (Inference-only entries -- tdx_conv3_fwd_partial -- keep their epilogue moments.)
 #include "tdx_common.h"
 #include "tdx_conv3.h"
 

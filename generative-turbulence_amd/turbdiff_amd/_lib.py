@@ -154,7 +154,7 @@ SCRATCH_MAX_ARENAS = int(os.environ.get("TDX_SCRATCH_MAX_ARENAS", "6"))
 ARENA_USERS = {"tdx_conv3_fwd", "tdx_conv3_fwd_gn", "tdx_conv3_fwd_partial", "tdx_conv3_bwd_data", "tdx_conv3_bwd_data_add",
                "tdx_conv3_bwd_weight", "tdx_attn_fwd"}  # tdx_attn_fwd: partial (O, m, l) of the stream-K schedule
 # TDX_DETERMINISTIC=1: these merge their parameter gradients through per-split slabs in the launching stream's arena as well
-DET_ARENA_USERS = {"tdx_conv1_bwd_weight", "tdx_conv1_bwd_weight_oc", "tdx_encode_bwd", "tdx_decode_bwd"}
+DET_ARENA_USERS = {"tdx_conv1_bwd_weight", "tdx_conv1_bwd_weight_oc", "tdx_encode_bwd", "tdx_decode_bwd", "tdx_gn_stats"}
 
 
 def deterministic() -> bool:

@@ -179,7 +179,8 @@ int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void* wf, const
  * step bit-reproducible from run to run: the fp32 atomic merges of tdx_conv3_bwd_weight (bias gradient; weight gradient of the
  * vector-ALU path and of many-split fp32-tensor launches), tdx_conv1_bwd_weight(_oc), tdx_encode_bwd and tdx_decode_bwd become
  * per-split partials added in a fixed order (csrc/tdx_ordered.hip; the last three take their slabs from the tdx_set_scratch arena
- * and return TDX_EINVAL / fall back to one split without one).  +0.9 ms on the 21-ms B = 6 step.  The reference itself sets no
+ * and return TDX_EINVAL / fall back to one split without one); the forward's f64 statistics merges are ordered too
+ * (tdx_conv3_fwd_gn = conv + a statistics pass with per-block tables; the loss sums on an exact grid).  +1.5 ms on the 21-ms B = 6 step.  The reference itself sets no
  * determinism flag (grep: none in train.py / config/); under torch the counterpart would be torch.use_deterministic_algorithms. */
 size_t tdx_conv3_bwd_data_workspace_bytes(int B, int X, int Y, int Z, int Cin, int dtype, int impl);
 int tdx_conv3_bwd_data(const void* dy, const void* wb, void* dx1, int C1, void* dx2, int C2, int accumulate,

@@ -296,7 +296,10 @@ def test_deterministic_switch_gives_bit_identical_gradients(grid, B, mode, impl,
     monkeypatch.setenv("TDX_DETERMINISTIC", "1")
     runs = [grads() for _ in range(3)]
     monkeypatch.delenv("TDX_DETERMINISTIC")
-    assert all(r[0] == base_loss for r in runs)
+    # (the deterministic forward takes its GroupNorm statistics from the stored conv result, the default one from the conv
+    # kernels' fp32 accumulators: the losses agree to the tensors' rounding, not bit for bit)
+    assert len({r[0] for r in runs}) == 1
+    assert abs(runs[0][0] - base_loss) < (2e-3 if mode in ("bf16", "fp16") else 1e-5) * abs(base_loss)
     differ = [n for r in runs[1:] for n in r[1] if not torch.equal(r[1][n], runs[0][1][n])]
     assert not differ, (mode, sorted(set(differ)))
     # the same numbers as the default path up to summation order (bf16: the shell's packed atomics round in bf16 per add,
