@@ -482,7 +482,7 @@ int attn_fwd_mfma_launch(const void* qkv, void* out, float* lse, int B, int N, i
     const char* envb = getenv("TDX_ATTN_BOUND");
     if (!(envb && envb[0] == '0') && tdx_scratch_ptr() != nullptr && tdx_scratch_bytes() >= head && B * H <= 256 && a.ntile >= 8) {
         float* km = reinterpret_cast<float*>((char*)tdx_scratch_ptr() + 64);
-        if (hipMemsetAsync(km, 0, (size_t)B * H * sizeof(float), st) != hipSuccess) return TDX_EINVAL;
+        if (tdx_zero_async(km, (size_t)B * H * sizeof(float), st) != TDX_OK) return TDX_EINVAL;
         const dim3 kg(min(ceil_div(N, 64), 64), B * H);
         if (dtype == TDX_F16) hipLaunchKernelGGL(attn_kmax_kernel<f16>, kg, dim3(256), 0, st, (const f16*)qkv, km, N, H);
         else hipLaunchKernelGGL(attn_kmax_kernel<bf16>, kg, dim3(256), 0, st, (const bf16*)qkv, km, N, H);

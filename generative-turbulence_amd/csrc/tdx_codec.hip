@@ -173,6 +173,9 @@ encode_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x, const f
 }
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static hipError_t codec_zero(float* p, size_t n, hipStream_t st) {  // (a kernel, not hipMemsetAsync: tdx_common.h)
+    return tdx_zero_async(p, n * sizeof(float), st) == TDX_OK ? hipSuccess : hipErrorUnknown;
+}
 // TDX_DETERMINISTIC: `floats` of per-block slabs in the launching stream's scratch arena (behind its zero block), or nullptr
 static float* det_slabs(int64_t floats) {
     char* arena = (char*)tdx_scratch_ptr();
@@ -207,8 +210,8 @@ extern "C" int tdx_encode_bwd(const void* dy, const float* x, int Fx, const floa
         const int64_t slab = 10 * (int64_t)D;
         float* slabs = det_slabs((int64_t)grid.x * slab);
         if (!slabs) return TDX_EINVAL;  // no arena (TDX_SCRATCH_MB=0) or too small: refuse rather than merge in arrival order
-        hipError_t e0 = hipMemsetAsync(slabs, 0, (size_t)grid.x * slab * sizeof(float), st);
-        if (e0 != hipSuccess) return (int)e0;
+        int e0 = tdx_zero_async(slabs, (size_t)grid.x * slab * sizeof(float), st);
+        if (e0 != TDX_OK) return e0;
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((encode_bwd_kernel<T, 4>), grid, dim3(CD_THREADS), 0, st, (const T*)dy, x, c, wc,
                                                      slabs, slabs + 4 * D, c ? slabs + 5 * D : nullptr,
                                                      c ? slabs + 9 * D : nullptr, dc, B, V, D, Dtot, slab));
@@ -219,10 +222,10 @@ extern "C" int tdx_encode_bwd(const void* dy, const float* x, int Fx, const floa
         if (rc == TDX_OK && c) rc = ordered_sum_launch(slabs + 9 * D, (int)grid.x, slab, dbc, 1, D, D, false, st);
         return rc;
     }
-    hipError_t e = hipMemsetAsync(dwx, 0, (size_t)D * 4 * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(dbx, 0, (size_t)D * sizeof(float), st);
-    if (e == hipSuccess && c) e = hipMemsetAsync(dwc, 0, (size_t)D * 4 * sizeof(float), st);
-    if (e == hipSuccess && c) e = hipMemsetAsync(dbc, 0, (size_t)D * sizeof(float), st);
+    hipError_t e = codec_zero(dwx, (size_t)D * 4, st);
+    if (e == hipSuccess) e = codec_zero(dbx, (size_t)D, st);
+    if (e == hipSuccess && c) e = codec_zero(dwc, (size_t)D * 4, st);
+    if (e == hipSuccess && c) e = codec_zero(dbc, (size_t)D, st);
     if (e != hipSuccess) return (int)e;
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((encode_bwd_kernel<T, 4>), grid, dim3(CD_THREADS), 0, st, (const T*)dy,
                                                  x, c, wc, dwx, dbx, dwc, dbc, dc, B, V, D, Dtot, (int64_t)0));
@@ -335,8 +338,8 @@ extern "C" int tdx_decode_bwd(const float* dy, const void* h, const float* w, vo
         const int64_t slab = (int64_t)F * D + F, nblk = (int64_t)grid.x * grid.y;  // [dw (F D) | db (F)] per block
         float* slabs = det_slabs(nblk * slab);
         if (!slabs) return TDX_EINVAL;
-        hipError_t e0 = hipMemsetAsync(slabs, 0, (size_t)nblk * slab * sizeof(float), st);
-        if (e0 != hipSuccess) return (int)e0;
+        int e0 = tdx_zero_async(slabs, (size_t)nblk * slab * sizeof(float), st);
+        if (e0 != TDX_OK) return e0;
         TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((decode_bwd_kernel<T, 4>), grid, dim3(CD_THREADS), 0, st, dy, (const T*)h, w,
                                                      (T*)dh, slabs, slabs + (int64_t)F * D, V, D, slab));
         int rc = tdx_launch_status();
@@ -344,8 +347,8 @@ extern "C" int tdx_decode_bwd(const float* dy, const void* h, const float* w, vo
         if (rc == TDX_OK) rc = ordered_sum_launch(slabs + (int64_t)F * D, (int)nblk, slab, db, 1, F, F, false, st);
         return rc;
     }
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)F * D * sizeof(float), st);
-    if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)F * sizeof(float), st);
+    hipError_t e = codec_zero(dw, (size_t)F * D, st);
+    if (e == hipSuccess) e = codec_zero(db, (size_t)F, st);
     if (e != hipSuccess) return (int)e;
     TDX_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((decode_bwd_kernel<T, 4>), grid, dim3(CD_THREADS), 0, st, dy,
                                                  (const T*)h, w, (T*)dh, dw, db, V, D, (int64_t)0));

@@ -249,6 +249,11 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n) {
     return xcd * base + min(xcd, rem) + k;
 }
 
+// Zero fills as kernel launches (tdx_ordered.hip): hipMemsetAsync becomes a memset NODE in a captured graph, which this runtime
+// does not order against earlier kernel nodes writing the memory's previous owner -- never use it on a path that can be captured
+int tdx_zero_async(void* p, size_t bytes, hipStream_t st);
+int tdx_zero2d_async(void* p, size_t pitch_bytes, size_t width_bytes, size_t rows, hipStream_t st);
+
 // dtype dispatch for launchers: calls f.template operator()<T>()
 #define TDX_DISPATCH_DTYPE(dtype, ...)                 \
     do {                                               \

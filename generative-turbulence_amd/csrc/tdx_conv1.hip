@@ -240,8 +240,8 @@ static int conv1_bwd_weight_impl(const void* x, int Cin, const void* dy, int Cou
                                           &nsplit, true);
             if (rc != TDX_OK) return rc;
             if (nsplit < 1 || nsplit > max_split) return TDX_EINVAL;
-            hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nsplit * slab * sizeof(float), st);
-            if (e != hipSuccess) return (int)e;
+            rc = tdx_zero_async(slabs, (size_t)nsplit * slab * sizeof(float), st);
+            if (rc != TDX_OK) return rc;
             int launched = 0;
             rc = conv1_wgrad_dispatch(x, Cin, dy, Cout, slabs, ncol, bias_slab, rows, dtype, transposed, st, max_split, slab, &launched);
             if (rc != TDX_OK) return rc;
@@ -254,11 +254,11 @@ static int conv1_bwd_weight_impl(const void* x, int Cin, const void* dy, int Cou
     const int one_split = tdx_deterministic() ? 1 : 0;
     if (!accumulate) {
         // zero the block that is written (ldw may exceed the row length for sub-blocks)
-        hipError_t e = hipMemset2DAsync(dw, (size_t)ldw * sizeof(float), 0, (size_t)ncol * sizeof(float), (size_t)nrow, st);
-        if (e != hipSuccess) return (int)e;
+        int e = tdx_zero2d_async(dw, (size_t)ldw * sizeof(float), (size_t)ncol * sizeof(float), (size_t)nrow, st);
+        if (e != TDX_OK) return e;
         if (dbias) {
-            e = hipMemsetAsync(dbias, 0, (size_t)Cout * sizeof(float), st);
-            if (e != hipSuccess) return (int)e;
+            e = tdx_zero_async(dbias, (size_t)Cout * sizeof(float), st);
+            if (e != TDX_OK) return e;
         }
     }
     return conv1_wgrad_dispatch(x, Cin, dy, Cout, dw, ldw, dbias, rows, dtype, transposed, st, one_split, 0, nullptr);

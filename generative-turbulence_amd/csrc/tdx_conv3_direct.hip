@@ -691,8 +691,8 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
         }
         double* acc = (double*)gn_workspace;
         if (!clean) {
-            hipError_t e = hipMemsetAsync(acc, 0, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
-            if (e != hipSuccess) return (int)e;
+            int e = tdx_zero_async(acc, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
+            if (e != TDX_OK) return e;
         }
         Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
         int rc = f32_split ? conv3_mfma_split_launch(x1, C1, x2, C2, wf, bias, y, g, Cout, false, st, acc)
@@ -714,8 +714,8 @@ extern "C" int tdx_conv3_fwd_gn(const void* x1, int C1, const void* x2, int C2, 
     }
     double* acc = (double*)gn_workspace;
     if (!clean) {
-        hipError_t e = hipMemsetAsync(acc, 0, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
-        if (e != hipSuccess) return (int)e;
+        int e = tdx_zero_async(acc, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
+        if (e != TDX_OK) return e;
     }
     Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
     int rc = conv3_ring_launch(x1, C1, x2, C2, wf, bias, y, B, X, Y, Z, Cout, false, st, acc, nullptr, 0, nullptr, nullptr, nullptr, hf);
@@ -739,8 +739,8 @@ extern "C" int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void
     hipStream_t st = as_stream(stream);
     double* acc = stats ? (double*)gn_workspace : nullptr;
     if (acc && !clean) {
-        hipError_t e = hipMemsetAsync(acc, 0, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
-        if (e != hipSuccess) return (int)e;
+        int e = tdx_zero_async(acc, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
+        if (e != TDX_OK) return e;
     }
     Conv3Geom g = {B, X, Y, Z, X, Y, Z, 0};
     Conv3Ext ext = {ld1, 0, init, init_shared != 0};
@@ -851,8 +851,8 @@ extern "C" int tdx_conv3_bwd_weight(const void* x1, int C1, const void* x2, int 
     float* dwp = (float*)workspace;
     float* dbw = dwp + (size_t)27 * Cin * Cout;  // bias-gradient accumulator
     if (!clean) {
-        hipError_t e = hipMemsetAsync(dwp, 0, ((size_t)27 * Cin * Cout + Cout) * sizeof(float), st);
-        if (e != hipSuccess) return (int)e;
+        int e = tdx_zero_async(dwp, ((size_t)27 * Cin * Cout + Cout) * sizeof(float), st);
+        if (e != TDX_OK) return e;
     }
     const bool use_mfma = impl == TDX_CONV_MFMA || (impl == TDX_CONV_AUTO && tdx_is_h16(dtype) &&
                                                      conv3_wgrad_mfma_supported(C1, C2, Cout));

@@ -102,8 +102,8 @@ __global__ void cell_mask_kernel(const int64_t* __restrict__ idx, int64_t n, uin
 }
 extern "C" int tdx_cell_mask(const int64_t* cell_idx, int64_t n_cells, uint8_t* mask, int64_t V, void* stream) {
     TDX_CHECK_ARG(mask && V > 0 && n_cells >= 0);
-    hipError_t e = hipMemsetAsync(mask, 0, (size_t)V, as_stream(stream));
-    if (e != hipSuccess) return (int)e;
+    int e = tdx_zero_async(mask, (size_t)V, as_stream(stream));
+    if (e != TDX_OK) return e;
     if (n_cells > 0) {
         TDX_CHECK_ARG(cell_idx);
         hipLaunchKernelGGL(cell_mask_kernel, dim3(ceil_div(n_cells, 256)), dim3(256), 0, as_stream(stream), cell_idx,
@@ -291,8 +291,8 @@ extern "C" size_t tdx_masked_loss_workspace_bytes(void) { return 16; }
 static int masked_loss_launch(const float* eps_hat, const float* noise, const uint8_t* mask, int64_t n_cells,
                               const int64_t* n_cells_dev, int l1, float* loss, float* grad, int B, int F, int64_t V,
                               void* workspace, void* stream) {
-    hipError_t err = hipMemsetAsync(workspace, 0, 16, as_stream(stream));
-    if (err != hipSuccess) return (int)err;
+    int err = tdx_zero_async(workspace, 16, as_stream(stream));
+    if (err != TDX_OK) return err;
     const double samples = (double)B * F;
     const double inv = n_cells_dev ? 0.0 : 1.0 / (samples * (double)n_cells);
     const double quant = tdx_deterministic() ? 1048576.0 : 0.0;  // block partials on a 2^-20 grid: exact up to a total of 2^33

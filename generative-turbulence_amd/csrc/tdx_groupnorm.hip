@@ -181,8 +181,8 @@ int gn_stats_launch(const void* x, float* stats, int B, int64_t V, int C, int G,
     if (!gn_shape_ok(C, G)) return TDX_ESHAPE;
     double* acc = (double*)workspace;
     if (!clean) {
-        hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * C * 2 * sizeof(double), stream);
-        if (e != hipSuccess) return (int)e;
+        int e = tdx_zero_async(acc, (size_t)B * C * 2 * sizeof(double), stream);
+        if (e != TDX_OK) return e;
     }
     // voxels per block: 1024 on big tensors; on the small ones of the deep U-Net levels (where this pass is used: the
     // small-grid conv kernels do not accumulate moments) enough blocks to put ~128 on the chip -- 12 blocks of 256 serial

@@ -108,3 +108,40 @@ int bias_grad_ordered_launch(const void* dy, int64_t nvox, int C, int dtype, flo
     if (rc != TDX_OK) return rc;
     return ordered_sum_launch(part, (int)nblk, C, dbias, 1, C, C, false, st);
 }
+
+// ---- zero fill as a KERNEL ------------------------------------------------------------------------------------------------
+// hipMemsetAsync inside a captured hipGraph becomes a memset node, and on this runtime a small memset node is not ordered
+// against EARLIER kernel nodes that still write the previous owner of the same (graph-pool) memory: replayed, the fill can land
+// before such a late write, which then sits in the freshly "zeroed" accumulator -- one garbage element in the encoder / decoder
+// gradients from the second replay of a captured training step on, found when the captured step stopped forking its weight
+// gradients onto a side stream (which had hidden it: record_stream kept those blocks from being reused).  torch itself zeroes
+// with fill kernels.  Every zero fill of the library goes through these two launches; a kernel node is ordered like any other.
+__global__ void __launch_bounds__(256) zero_bytes_kernel(unsigned char* __restrict__ p, size_t bytes) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i >= bytes) return;
+    if (i + 16 <= bytes && (reinterpret_cast<uintptr_t>(p + i) & 15) == 0) {
+        *reinterpret_cast<uint4*>(p + i) = make_uint4(0, 0, 0, 0);
+    } else {
+        const size_t e = i + 16 < bytes ? i + 16 : bytes;
+        for (size_t k = i; k < e; ++k) p[k] = 0;
+    }
+}
+__global__ void __launch_bounds__(256) zero_rows_kernel(unsigned char* __restrict__ p, size_t pitch, size_t width, size_t rows) {
+    const size_t per_row = (width + 3) / 4;  // 4-byte pieces (width and pitch are multiples of 4: fp32 matrices)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_row * rows) return;
+    const size_t r = i / per_row, c = (i - r * per_row) * 4;
+    *reinterpret_cast<unsigned*>(p + r * pitch + c) = 0u;
+}
+int tdx_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return TDX_OK;
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, st, (unsigned char*)p, bytes);
+    return tdx_launch_status();
+}
+int tdx_zero2d_async(void* p, size_t pitch, size_t width, size_t rows, hipStream_t st) {
+    if (width == 0 || rows == 0) return TDX_OK;
+    if ((pitch % 4) || (width % 4) || (reinterpret_cast<uintptr_t>(p) % 4)) return TDX_EINVAL;
+    const size_t n = (width / 4) * rows;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned char*)p, pitch, width, rows);
+    return tdx_launch_status();
+}

@@ -27,6 +27,7 @@ cell indices), ``cell_types`` (X, Y, Z) int64 in [0, 6), and the per-feature ``m
 from __future__ import annotations
 
 import math
+import os
 import time
 from types import SimpleNamespace
 
@@ -34,6 +35,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from . import ops
 from .data.ofles import Variable
 from .models.cell_type_embeddings import CellTypeEmbedding
 from .models.conditioning import Conditioning
@@ -535,10 +537,19 @@ class GraphedTrainingStep:
         # raises hipErrorStreamCaptureUnsupported inside our capture and aborts the process (2 of 6 runs)
         if ddp is not None:
             torch.cuda.synchronize(dev)  # the warm-up steps' collectives are done before the capture begins
-        with torch.cuda.graph(slot.graph, stream=s, capture_error_mode="thread_local"):
-            if ddp is not None:
-                slot.gen.add_(1)
-            slot.loss = body().detach()  # (no autograd graph outlives the capture: its nodes belong to this stream)
+        # The weight gradients' side stream (ops._WgradSide) pays in eager mode (+0.2-0.4 ms hidden) and COSTS in a replayed graph
+        # (B = 6: 21.09 ms captured with the fork, 20.81 without; eager 20.29 / 20.46): the captured step keeps everything on one
+        # stream unless TDX_GRAPH_WGRAD_STREAM=1 asks for the fork (A/B switch)
+        fork = ops.WGRAD_STREAM
+        if os.environ.get("TDX_GRAPH_WGRAD_STREAM", "0") != "1":
+            ops.WGRAD_STREAM = False
+        try:
+            with torch.cuda.graph(slot.graph, stream=s, capture_error_mode="thread_local"):
+                if ddp is not None:
+                    slot.gen.add_(1)
+                slot.loss = body().detach()  # (no autograd graph outlives the capture: its nodes belong to this stream)
+        finally:
+            ops.WGRAD_STREAM = fork
         if ddp is not None:
             slot.ddp_plan = ddp.end_capture()
         torch.autograd.graph.increment_version([p for p in tr.model.parameters()])

@@ -286,3 +286,54 @@ def test_graph_capture_beside_an_rccl_communicator(tmp_path):
     assert p.exitcode == 0
     outs = torch.load(tmp_path / "capture.pt")
     assert len(outs) == 12 and all(outs)
+
+
+@pytest.mark.parametrize("fork", ["0", "1"])
+@pytest.mark.parametrize("full_size", [False, True])
+def test_captured_step_stays_correct_over_replays_with_and_without_the_side_stream(fork, full_size, monkeypatch):
+    """Every parameter gradient of every replay against the eager step's, five replays, with the weight gradients on the
+    capture's own stream (the default since round 6) and forked onto the side stream (TDX_GRAPH_WGRAD_STREAM=1).  Regression:
+    hipMemsetAsync inside a capture becomes a memset NODE that this runtime does not order against earlier kernel nodes still
+    writing the previous owner of the same graph-pool block -- from the SECOND replay on, one element of the encoder / decoder
+    gradients was garbage as soon as the capture stopped forking (the fork's record_stream had kept those blocks from being
+    reused).  The library zeroes with kernels now (tdx_zero_async)."""
+    sys.path.insert(0, str(ROOT / "generative-turbulence_amd"))
+    from turbdiff_amd.training import GraphedTrainingStep
+
+    monkeypatch.setenv("TDX_GRAPH_WGRAD_STREAM", fork)
+    dev = torch.device("cuda:0")
+    if full_size:
+        sys.path.insert(0, str(ROOT))
+        import bench
+        from turbdiff_amd.models.conditioning import Conditioning
+
+        diff = bench.build_model(dev)
+        bench.set_mode(diff, "bf16")
+        xs, c, idx = bench.synthetic_inputs(2, dev, (96, 32, 24))
+        C, md = {Conditioning.Type.CELL_TYPE: c}, SimpleNamespace(cell_idx=idx)
+        ts = torch.tensor([3, 250], device=dev)
+        ns = torch.randn(xs.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+        tol = 3e-2  # bf16: the halo shell's atomics alone move gradients by up to 6e-3 between two eager runs
+    else:
+        diff, x, C, md, t, noise = _build(dev)
+        xs, ts, ns = x[0:1], t[0:1], noise[0:1]
+        tol = 1e-4
+    diff.zero_grad(set_to_none=True)
+    loss, _ = diff.p_losses(xs, ts, C, md, None, noise=ns)
+    loss.backward()
+    torch.cuda.synchronize()
+    eager_loss = loss.item()
+    eager = {n: p.grad.detach().clone() for n, p in diff.model.named_parameters()}
+    del loss
+    gs = GraphedTrainingStep(_GraphTask(diff, None), inject=True)
+    gs.set_draws(ts, ns)
+    batch = SimpleNamespace(x=xs, C=C, cell_idx=md.cell_idx)
+    for replay in range(5):
+        l = gs(batch)
+        torch.cuda.synchronize()
+        assert abs(l.item() - eager_loss) < 1e-5 * abs(eager_loss) or full_size and abs(l.item() - eager_loss) < 1e-3 * abs(eager_loss)
+        for n, p in diff.model.named_parameters():
+            g, r = p.grad.detach(), eager[n]
+            assert torch.isfinite(g).all(), (n, replay)
+            if r.norm() > 1e-6:
+                assert ((g - r).norm() / r.norm()).item() < tol, (n, replay)
