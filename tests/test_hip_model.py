@@ -348,6 +348,53 @@ def test_deterministic_switch_reproduces_a_training_run(mode, monkeypatch):
     bench.set_mode(diff, "f32")
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_captured_training_run_equals_the_eager_one_bit_for_bit(mode, monkeypatch):
+    """With TDX_DETERMINISTIC=1 every merge of the backward pass is ordered, so 25 optimiser steps on the same (x, t, noise) from the
+    same weights must end in the SAME parameter bits and losses whether forward + backward are issued eagerly (weight gradients on
+    the side stream) or replayed from one captured graph (one stream, weights re-packed inside the graph, loss scale read from a
+    device scalar in fp16): the captured path checked against the eager one over a whole run, not to a tolerance."""
+    import bench
+    from turbdiff_amd.training import GraphedTrainingStep
+
+    monkeypatch.setenv("TDX_DETERMINISTIC", "1")
+    diff = bench.build_model(dev())
+    bench.set_mode(diff, mode)
+    sd0 = {k: v.clone() for k, v in diff.state_dict().items()}
+    B, grid = 2, (96, 32, 24)
+    x, c_local, idx = bench.synthetic_inputs(B, dev(), grid)
+    C, md = cond(c_local), SimpleNamespace(cell_idx=idx)
+    t = torch.tensor([3, 250], device=dev())
+    noise = torch.randn(x.shape, device=dev(), generator=torch.Generator(device=dev()).manual_seed(1))
+    ends = {}
+    for kind in ("eager", "graph"):
+        diff.load_state_dict(sd0)
+        diff.zero_grad(set_to_none=True)
+        opt = bench.new_optimizer(diff, mode, bench.LOSS_ELEMENTS(B, idx))
+        losses = []
+        if kind == "graph":
+            gs = GraphedTrainingStep(bench._Task(diff, opt), inject=True)
+            gs.set_draws(t, noise)
+            batch = SimpleNamespace(x=x, C=C, cell_idx=idx)
+        for step in range(25):
+            if kind == "graph":
+                loss = gs(batch)
+            else:
+                opt.zero_grad(set_to_none=True)
+                loss, _ = diff.p_losses(x, t, C, md, None, noise=noise)
+                opt.scale_loss(loss).backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+            del loss  # (no eager autograd graph may be alive when the capture begins)
+        torch.cuda.synchronize()
+        ends[kind] = ([l.item() for l in losses], {n: p.detach().clone() for n, p in diff.model.named_parameters()})
+    assert ends["eager"][0] == ends["graph"][0]
+    assert ends["eager"][0][0] != ends["eager"][0][-1]
+    differ = [n for n in ends["eager"][1] if not torch.equal(ends["eager"][1][n], ends["graph"][1][n])]
+    assert not differ, differ
+    bench.set_mode(diff, "f32")
+
+
 @pytest.mark.timeout(1500)
 def test_benchmark_batch_gradients_match_oracle(monkeypatch):
     """The benchmarked shape itself: B = 6 at 192 x 64 x 48 (per-sample strides, level-1 launches on the ring kernels,
