@@ -405,7 +405,8 @@ class DenoisingModel(nn.Module):
             c_local = local_conditioning(C)
             if c_local is not None:
                 parts.append(self.geometry_embedding(c_local).expand((batch_size, -1)))
-        return self.process_c(torch.cat(parts, dim=-1))
+        # (one part is the common case: torch.cat of a single tensor is a device-to-device memcpy -- a memcpy NODE in a captured step)
+        return self.process_c(parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1))
 
     def conditioning_table(self, C, timesteps: int):
         """(timesteps, c_dim) tensor whose row t is conditioning_vector(t, C, 1) -- when that vector depends on t alone (no
