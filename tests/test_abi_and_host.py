@@ -482,3 +482,20 @@ def test_fp16_compute_mode_host_side():
         ClipRAdam(p, loss_scale=1000.0)
     opt = ClipRAdam(p, loss_scale=2.0**10)
     assert opt.scale_loss(torch.tensor(1.5)).item() == 1536.0 and ClipRAdam(p).scale_loss(torch.tensor(1.5)).item() == 1.5
+
+
+def test_library_sources_zero_with_kernels_not_memsets():
+    """A hipMemsetAsync inside a captured hipGraph is a memset NODE, which this runtime does not order against earlier kernel
+    nodes that still write the previous owner of reused graph-pool memory (garbage in the encoder / decoder
+    gradients from the second replay of a captured training step on).  Every zero fill of the library goes through
+    tdx_zero_async / tdx_zero2d_async (kernel launches); this keeps a new hipMemset* call from slipping back in."""
+    import re
+
+    csrc = ROOT / "generative-turbulence_amd" / "csrc"
+    offenders = []
+    for f in sorted(list(csrc.glob("*.hip")) + list(csrc.glob("*.h"))):
+        for k, line in enumerate(f.read_text().splitlines(), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bhipMemset\w*\s*\(", code):
+                offenders.append(f"{f.name}:{k}: {line.strip()}")
+    assert not offenders, "\n".join(offenders)
