@@ -737,7 +737,8 @@ extern "C" int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void
     const bool clean = (impl & TDX_WS_CLEAN) != 0;
     if (!mfma_ok(dtype, C1, 0, Cout)) return tdx_is_h16(dtype) ? TDX_ESHAPE : TDX_EDTYPE;
     hipStream_t st = as_stream(stream);
-    double* acc = stats ? (double*)gn_workspace : nullptr;
+    const bool det = tdx_deterministic();  // then: conv, and the ordered statistics pass over its result (as tdx_conv3_fwd_gn)
+    double* acc = (stats && !det) ? (double*)gn_workspace : nullptr;
     if (acc && !clean) {
         int e = tdx_zero_async(acc, (size_t)TDX_GN_REPLICAS * B * Cout * 2 * sizeof(double), st);
         if (e != TDX_OK) return e;
@@ -747,6 +748,7 @@ extern "C" int tdx_conv3_fwd_partial(const void* x1, int C1, int ld1, const void
     int rc = conv3_mfma_launch(x1, C1, nullptr, 0, wf, bias, y, g, Cout, false, st, acc, nullptr, 0, nullptr, nullptr, nullptr,
                                &ext, nullptr, dtype == TDX_F16);
     if (rc != TDX_OK || !stats) return rc;
+    if (det) return gn_stats_launch(y, stats, B, (int64_t)X * Y * Z, Cout, G, eps, dtype, gn_workspace, clean, st);
     return gn_finalize_launch(acc, stats, B, Cout, G, (int64_t)X * Y * Z, eps, TDX_GN_REPLICAS, st);
 }
 

@@ -10,7 +10,7 @@
 // The f64 atomics of the forward go as well: tdx_conv3_fwd_gn takes the conv and then the statistics pass over its result
 // (no moments from the conv epilogues), whose blocks store their own f64 tables for an ordered merge (tdx_groupnorm.hip);
 // the loss adds block partials rounded to a 2^-20 grid, on which f64 additions are exact -- order-independent -- up to 2^33.
-// (Inference-only entries -- tdx_conv3_fwd_partial -- keep their epilogue moments.)
+// tdx_conv3_fwd_partial (the sampler's first conv) does the same: a sampling run is bit-reproducible too.
 #include "tdx_common.h"
 #include "tdx_conv3.h"
 

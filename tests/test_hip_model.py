@@ -676,6 +676,27 @@ def test_graph_sampler_equals_eager_loop(golden, nb):
     assert rel_l2(solo[0], out_graph[1]) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sampling_is_bit_reproducible_under_the_deterministic_switch(golden, dtype, monkeypatch):
+    """TDX_DETERMINISTIC=1: the captured sampler gives the SAME BITS when replayed (the GroupNorm statistics of the forward merge
+    through per-block tables in block order instead of f64 atomics; the first conv's partial-forward entry included), and the
+    eager loop on the same noise gives those bits too."""
+    from turbdiff_amd.sampling import GraphSampler
+
+    monkeypatch.setenv("TDX_DETERMINISTIC", "1")
+    g = golden("sample_cfg1")
+    diff = build_cfg1(golden, noise_bcs=True, dtype=dtype)
+    x_bcs, C, cidx = g["x_bcs"].to(dev()), cond(g["c_local"]), g["cell_idx"].to(dev())
+    gs = GraphSampler(diff, x_bcs, C, cidx, seed=42, trajectory_ids=[5, 9])
+    first = gs.sample().clone()
+    assert torch.isfinite(first).all()
+    for _ in range(3):
+        assert torch.equal(gs.sample(), first)
+    stream = gs.noise_stream()
+    eager = diff.p_sample_loop(x_bcs, C, cidx, noise_fn=lambda like: next(stream))
+    assert torch.equal(eager, first)
+
+
 @pytest.mark.parametrize("nb", [True, False])
 def test_p_sample_loop_default_path_is_the_graph_sampler(golden, nb):
     """`GaussianDiffusion.p_sample_loop` without injected noise -- what `DiffusionTrainer.sample`,
