@@ -873,7 +873,10 @@ class _WgradSide:
         if self.on:
             idx = device.index
             if idx not in _SIDE:
-                _SIDE[idx] = torch.cuda.Stream(device=device)
+                # from the HIGH-priority pool: torch hands out default-priority handles round-robin from 32 per device, so the 32nd
+                # stream a caller creates later would BE a default-priority side stream -- and inherit its 4-KiB arena (no small-grid
+                # kernels on that stream).  The priority itself changes nothing measurable (21.07 / 21.01 / 21.00 vs 21.05 / 21.01 / 21.00 ms)
+                _SIDE[idx] = torch.cuda.Stream(device=device, priority=int(os.environ.get("TDX_WGRAD_STREAM_PRIORITY", "-1")))
                 L.declare_zero_block_only(_SIDE[idx])
             self.side, self.main = _SIDE[idx], torch.cuda.current_stream(device)
 
