@@ -874,7 +874,10 @@ def main():
         return elapsed, (kern, timer), loss.item(), train_step
 
     leg_done("build_model_and_accuracy_probe")
-    elapsed, (kern, timer), last_loss, train_step = run_mode(args.dtype, K, Wm, calls=FWD_CALLS, ddp_timing=False)
+    # one step of lazy initialisation (per-stream scratch arenas, zero-kept workspaces, pack plans, kernel attributes: all made at
+    # first use) runs before the W warm-up steps, so that a call with --warmup 0 times K steps of the product, not its set-up
+    # (257 ms for the first step against 21): config.untimed_steps says so
+    elapsed, (kern, timer), last_loss, train_step = run_mode(args.dtype, K, Wm + 1, calls=FWD_CALLS, ddp_timing=False)
     headline_enqueue_ms = run_mode.host_enqueue_ms
     headline_skipped = getattr(run_mode, "skipped", None)
     leg_done("headline_steps")
@@ -901,6 +904,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: turbdiff U-Net dim32 x 4 levels GN(8), 192x64x48 (u,p), "
                                "DDPM train step (fwd+bwd+clip+RAdam)", "per_gpu_batch": B, "global_batch": B * world,
                    "grid": list(GRID), "timesteps": 500, "parallelism": f"dp{world}",
+                   "untimed_steps": f"{Wm} warm-up (--warmup) + 1 of lazy initialisation before them",
                    "optimizer": "ClipRAdam (fused clip 0.1 + RAdam)" if fused_opt else "clip_grad_norm_ + torch.optim.RAdam",
                    # what was switched away from the defaults through the environment (INTEGRATION.md lists the switches)
                    "switches": {k: v for k, v in sorted(os.environ.items()) if k.startswith("TDX_") and not k.startswith("TDX_BENCH_")},
