@@ -172,7 +172,8 @@ def declare_zero_block_only(stream) -> None:
     """The given torch stream will only launch arena users that read the 16-byte zero block (tdx_conv3_bwd_weight):
     it gets a 4-KiB arena instead of TDX_SCRATCH_MB.  (torch draws stream handles from a pool of 32 per device and priority: a
     stream a caller creates much later can be the same handle -- its convs then run without the small-grid kernels, correct but
-    on the brick kernels; ops._WgradSide therefore takes its stream from the high-priority pool, which callers rarely use.)"""
+    on the brick kernels.  A high-priority side stream would avoid the collision but slows every kernel beside a live RCCL
+    communicator -- ops._WgradSide, TDX_WGRAD_STREAM_PRIORITY.)"""
     _SMALL_STREAMS.add((stream.device.index, stream.cuda_stream))
 
 

@@ -873,10 +873,12 @@ class _WgradSide:
         if self.on:
             idx = device.index
             if idx not in _SIDE:
-                # from the HIGH-priority pool: torch hands out default-priority handles round-robin from 32 per device, so the 32nd
-                # stream a caller creates later would BE a default-priority side stream -- and inherit its 4-KiB arena (no small-grid
-                # kernels on that stream).  The priority itself changes nothing measurable (21.07 / 21.01 / 21.00 vs 21.05 / 21.01 / 21.00 ms)
-                _SIDE[idx] = torch.cuda.Stream(device=device, priority=int(os.environ.get("TDX_WGRAD_STREAM_PRIORITY", "-1")))
+                # Default priority.  torch hands out default-priority handles round-robin from 32 per device, so the 32nd stream a
+                # caller creates later IS this one (and inherits its 4-KiB arena: no small-grid kernels on that stream -- correct,
+                # slower).  Taking the side stream from the high-priority pool avoids that and costs nothing on one GPU (21.07 /
+                # 21.01 / 21.00 vs 21.05 / 21.01 / 21.00 ms) -- but beside a live RCCL communicator it takes the step from 21.2 to
+                # 33.0 ms (every kernel slower: forward convs 0.40 -> 0.30 of the peak), so it stays an opt-in (TDX_WGRAD_STREAM_PRIORITY=-1)
+                _SIDE[idx] = torch.cuda.Stream(device=device, priority=int(os.environ.get("TDX_WGRAD_STREAM_PRIORITY", "0")))
                 L.declare_zero_block_only(_SIDE[idx])
             self.side, self.main = _SIDE[idx], torch.cuda.current_stream(device)
 
